@@ -1,0 +1,122 @@
+/*
+ * evogp_hip.h — C ABI of the MI355X (gfx950) tree-evaluation / genetic-operation engine.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one of the five host launchers
+ * the reference declares in  src/evogp/cuda/kernel.h:23-97  and calls from
+ * src/evogp/cuda/torch_wrapper.cu  (generate :68, mutate :121, crossover :173,
+ * evaluate :220, SR_fitness :267).  Argument order, meaning and units are the
+ * reference's; the differences are deliberate and minimal:
+ *
+ *   - every function takes the HIP stream to enqueue on as its last argument
+ *     (the reference uses the legacy default stream, SURVEY.md §8b "Threading / streams");
+ *   - every function returns an int: 0 on success, a hipError_t value when the launch
+ *     failed, or a negative EVOGP_E_* code for an argument the kernels cannot honour
+ *     (the reference's launchers return void and never check, torch_wrapper.cu:84,135,188,231,282);
+ *   - evogp_hip_generate has one extra argument, tree_index_offset, added to the
+ *     tree index before it is hashed into the per-tree RNG seed (reference: generate.cu:35,40
+ *     uses the local thread index).  0 reproduces the reference; a rank offset makes a
+ *     population sharded over several GPUs bit-identical to the single-GPU one.
+ *
+ * All pointers are DEVICE pointers (HBM), row-major, contiguous, exactly the layouts of
+ * the reference's Forest tensors (src/evogp/tree/forest.py:13-40):
+ *     value  float32 [pop][gp_len]   node payload (var index / constant / function id / OUT bits)
+ *     type   int16   [pop][gp_len]   NodeType, bit 7 = OUT_NODE
+ *     size   int16   [pop][gp_len]   subtree size, size[t][0] = live length of tree t
+ * Output rows are written on [0, len) and zero-filled on [len, gp_len) (the reference leaves
+ * the tail uninitialised: torch_wrapper.cu:64-66, generate.cu:167-172).
+ *
+ * No torch types, no C++ types: this header is plain C and is what a cgo / JNI / ctypes /
+ * libtorch binding includes (INTEGRATION.md shows the libtorch and ctypes stubs).
+ */
+#ifndef EVOGP_HIP_H
+#define EVOGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* encodings shared with the reference (src/evogp/cuda/defs.h:5-57) */
+#define EVOGP_MAX_STACK 1024      /* defs.h:5  — upper bound on gp_len                     */
+#define EVOGP_MAX_FULL_DEPTH 10   /* defs.h:5  — length of depth2leaf_probs                */
+#define EVOGP_NUM_FUNCS 29        /* defs.h:56 — Function::END, length of roulette_funcs   */
+
+/* negative return codes (argument errors detected on the host before any launch) */
+#define EVOGP_E_BADARG (-1)       /* size/shape argument out of the range the reference's wrapper accepts */
+#define EVOGP_E_NULLPTR (-2)      /* a required pointer is NULL */
+#define EVOGP_E_UNSUPPORTED (-3)  /* var_len/out_len larger than the interpreter's staging area */
+
+typedef void *evogp_stream_t; /* a hipStream_t; NULL = the null stream */
+
+/* kernel.h:23-38 `generate`.  keys: u32[2]; depth2leaf_probs: f32[10]; roulette_funcs: f32[29]
+ * (cumulative); const_samples: f32[const_samples_len].  Outputs: [pop_size][gp_len]. */
+int evogp_hip_generate(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                       unsigned const_samples_len, float out_prob, float const_prob,
+                       const unsigned *keys, const float *depth2leaf_probs,
+                       const float *roulette_funcs, const float *const_samples,
+                       float *value_res, int16_t *type_res, int16_t *size_res,
+                       unsigned tree_index_offset, evogp_stream_t stream);
+
+/* kernel.h:40-53 `mutate`.  out[n] = old[n] with the subtree at mutate_indices[n] replaced by the
+ * whole tree new[n]; old[n] is copied when the index is outside [0, len(old[n])) or the result
+ * would exceed gp_len (mutation.cu:150-160,170-180). */
+int evogp_hip_mutate(int pop_size, int gp_len,
+                     const float *value_ori, const int16_t *type_ori, const int16_t *size_ori,
+                     const int *mutate_indices,
+                     const float *value_new, const int16_t *type_new, const int16_t *size_new,
+                     float *value_res, int16_t *type_res, int16_t *size_res,
+                     evogp_stream_t stream);
+
+/* kernel.h:55-69 `crossover`.  out[n] = ori[left_idx[n]] with the subtree at left_node_idx[n]
+ * replaced by subtree right_node_idx[n] of ori[right_idx[n]]; the left tree is copied when
+ * right_idx[n] is outside [0, pop_size_ori) or the result would exceed gp_len
+ * (mutation.cu:256-266,279-289).  Node indices outside the live tree (undefined behaviour in the
+ * reference) also produce a copy of the left tree. */
+int evogp_hip_crossover(int pop_size_ori, int pop_size_new, int gp_len,
+                        const float *value_ori, const int16_t *type_ori, const int16_t *size_ori,
+                        const int *left_idx, const int *right_idx,
+                        const int *left_node_idx, const int *right_node_idx,
+                        float *value_res, int16_t *type_res, int16_t *size_res,
+                        evogp_stream_t stream);
+
+/* kernel.h:71-81 `evaluate`.  results[n][:] = tree_n(variables[n][:]);
+ * variables: f32[pop][var_len], results: f32[pop][out_len]. */
+int evogp_hip_evaluate(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                       const float *value, const int16_t *type, const int16_t *size,
+                       const float *variables, float *results, evogp_stream_t stream);
+
+/* kernel.h:83-97 `SR_fitness`.  fitnesses[t] = (1/D) * sum_d sum_o err(labels[d][o] - tree_t(X[d])_o),
+ * err = square (use_mse != 0) or abs.  variables: f32[D][var_len], labels: f32[D][out_len].
+ * kernel_type 0..4 is accepted for compatibility (forward.cu:827-856); every value runs the same
+ * fused kernel. */
+int evogp_hip_sr_fitness(unsigned pop_size, unsigned data_points, unsigned gp_len,
+                         unsigned var_len, unsigned out_len, int use_mse,
+                         const float *value, const int16_t *type, const int16_t *size,
+                         const float *variables, const float *labels, float *fitnesses,
+                         unsigned kernel_type, evogp_stream_t stream);
+
+/* Non-replicating batch evaluation (replaces the repeat_interleave + tree_evaluate
+ * composition of src/evogp/tree/forest.py:143-176): results[t][d][:] = tree_t(variables[d][:]),
+ * variables: f32[D][var_len], results: f32[pop][D][out_len]. */
+int evogp_hip_batch_evaluate(unsigned pop_size, unsigned data_points, unsigned gp_len,
+                             unsigned var_len, unsigned out_len,
+                             const float *value, const int16_t *type, const int16_t *size,
+                             const float *variables, float *results, evogp_stream_t stream);
+
+/* Average duration in milliseconds of the most recent `evogp_hip_*` launch sequence that was
+ * bracketed by evogp_hip_timer_begin/_end on `stream` (hipEvent pair recorded on that stream).
+ * Used by bench.py to time the kernel on the stream it is launched on. */
+int evogp_hip_timer_begin(evogp_stream_t stream);
+int evogp_hip_timer_end(evogp_stream_t stream, float *elapsed_ms);
+
+/* Human-readable text for a return code of any function above. */
+const char *evogp_hip_error_string(int code);
+
+/* ABI version of this header: bumped when a signature changes. */
+int evogp_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVOGP_HIP_H */
