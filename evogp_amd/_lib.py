@@ -1,0 +1,62 @@
+"""Loader for the C-ABI engine ``evogp_amd/lib/libevogp_hip.so`` (include/evogp_hip.h).
+
+There is NO fallback: if the shared object is missing or fails to load, importing the package
+raises.  The library is built in-tree by ``__graft_entry__.build()`` / ``make -C evogp_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libevogp_hip.so")
+
+ABI_VERSION = 1
+
+_vp = C.c_void_p
+_u = C.c_uint
+_i = C.c_int
+_f = C.c_float
+
+# name -> argtypes, exactly the prototypes of include/evogp_hip.h
+PROTOTYPES = {
+    "evogp_hip_generate": [_u, _u, _u, _u, _u, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
+    "evogp_hip_mutate": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evogp_hip_crossover": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evogp_hip_evaluate": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evogp_hip_sr_fitness": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
+    "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evogp_hip_timer_begin": [_vp],
+    "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
+    "evogp_hip_abi_version": [],
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP engine first "
+            "(python -c 'import __graft_entry__ as g; g.build()'  or  make -C evogp_amd/csrc). "
+            "evogp_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+        fn.argtypes = argtypes
+        fn.restype = _i
+    lib.evogp_hip_error_string.argtypes = [_i]
+    lib.evogp_hip_error_string.restype = C.c_char_p
+    got = lib.evogp_hip_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libevogp_hip.so ABI version {got}, expected {ABI_VERSION}: rebuild the engine")
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int, what: str) -> None:
+    """Map a non-zero return code to RuntimeError — the error convention of the reference's
+    TORCH_CHECKs (src/evogp/cuda/torch_wrapper.cu:7-17,48-54)."""
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {lib.evogp_hip_error_string(code).decode()} (code {code})")

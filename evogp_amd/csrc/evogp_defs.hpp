@@ -1,0 +1,97 @@
+// evogp_defs.hpp — encodings, RNG and wave helpers shared by every gfx950 kernel.
+//
+// The numeric encodings are the wire format of the Forest tensors and therefore identical to the
+// reference's (src/evogp/cuda/defs.h:5-57); everything else here is original CDNA4 code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace evogp {
+
+constexpr int kMaxStack = 1024;    // defs.h:5  upper bound on gp_len
+constexpr int kMaxFullDepth = 10;  // defs.h:5  entries of depth2leaf_probs
+constexpr int kNumFuncs = 29;      // defs.h:56 Function::END
+constexpr float kDelta = 1e-9f;    // defs.h:7
+constexpr float kMaxVal = 1e9f;    // defs.h:8
+constexpr int kWave = 64;          // CDNA wavefront
+
+enum NodeType : int { T_VAR = 0, T_CONST = 1, T_UFUNC = 2, T_BFUNC = 3, T_TFUNC = 4, T_MASK = 0x7F, T_OUT = 0x80 };
+
+enum Func : int {
+    F_IF = 0,
+    F_ADD = 1, F_SUB, F_MUL, F_DIV, F_LOOSE_DIV, F_POW, F_LOOSE_POW, F_MAX, F_MIN, F_LT, F_GT, F_LE, F_GE,
+    F_SIN = 14, F_COS, F_TAN, F_SINH, F_COSH, F_TANH, F_LOG, F_LOOSE_LOG, F_EXP, F_INV, F_LOOSE_INV, F_NEG, F_ABS,
+    F_SQRT, F_LOOSE_SQRT,
+    F_END = 29
+};
+
+// ---- per-tree RNG ---------------------------------------------------------------------------
+// Seed hash: FNV-1a-64 over the 12 little-endian bytes of {n, k1, k2}, truncated to 32 bits
+// (kernel.h:157-172).
+__host__ __device__ inline uint32_t seed_hash(uint32_t n, uint32_t k1, uint32_t k2) {
+    const uint32_t w[3] = {n, k1, k2};
+    uint64_t h = 14695981039346656037ULL;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            h ^= (uint64_t)((w[i] >> (8 * b)) & 0xFFu);
+            h *= 1099511628211ULL;
+        }
+    }
+    return (uint32_t)h;
+}
+
+// L'Ecuyer's three-component Tausworthe generator ("taus88") as Thrust parameterises it
+// (the reference's RandomEngine, kernel.h:20): all three LFSRs start from the raw seed.
+struct Taus88 {
+    uint32_t a, b, c;
+    __host__ __device__ explicit Taus88(uint32_t s) : a(s), b(s), c(s) {}
+    __host__ __device__ static inline uint32_t step(uint32_t z, int k, int q, int s) {
+        const uint32_t t = ((z << q) ^ z) >> (k - s);
+        return ((z & (0xFFFFFFFFu << (32 - k))) << s) ^ t;
+    }
+    __host__ __device__ inline uint32_t next() {
+        a = step(a, 31, 13, 12);
+        b = step(b, 29, 2, 4);
+        c = step(c, 28, 3, 17);
+        return a ^ b ^ c;
+    }
+    // thrust::uniform_real_distribution<float>(0,1): float(u32) * 2^-32, u32->f32 rounds to nearest
+    // (so 1.0f is reachable).
+    __host__ __device__ inline float uniform() { return (float)next() * 2.3283064365386963e-10f; }
+};
+
+__device__ inline float bits2f(uint32_t u) { return __uint_as_float(u); }
+__device__ inline uint32_t f2bits(float f) { return __float_as_uint(f); }
+
+// broadcast a wave-uniform value into an SGPR so the compiler keeps control flow scalar
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// full-wave fixed-order sum (deterministic butterfly over 64 lanes)
+__device__ inline float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ inline int wave_max(int x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int y = __shfl_xor(x, off, 64);
+        x = y > x ? y : x;
+    }
+    return x;
+}
+// inclusive prefix sum across the 64 lanes
+__device__ inline int wave_scan_incl(int x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
+} // namespace evogp

@@ -1,0 +1,290 @@
+// interp.hpp — the wave-uniform stack-machine interpreter (gfx950).
+//
+// Semantics restate src/evogp/cuda/forward.cu:79-244 (_process_node) and :246-302
+// (_treeGPEvalByStack); the execution model is new:
+//
+//   * one 64-lane wave interprets ONE tree; every lane works on K different input rows, so the
+//     opcode, the operand-stack height and every branch are wave-uniform: decode runs on the scalar
+//     unit (SGPR compares + s_cbranch) and never diverges, and its cost is shared by 64*K rows;
+//   * the tree is loaded coalesced, one node per lane, pre-decoded into an {opcode, payload}
+//     pair that stays in two VGPRs; the interpreter fetches instruction j with two v_readlane
+//     — no memory access in the inner loop;
+//   * the operand stack lives in VGPRs: K ext_vectors of DEPTH floats indexed with the uniform
+//     stack height, which the gfx9 back end lowers to s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off;
+//     the top of stack is cached in its own registers; the variables of the lane's input rows
+//     live in VGPRs as well (another indexed vector per row).
+//
+// Trees are scanned in reverse prefix order (leaves push, functions pop), exactly as the reference
+// does after reversing the arrays (forward.cu:281-296).
+#pragma once
+#include "evogp_defs.hpp"
+
+#include <type_traits>
+
+namespace evogp {
+
+typedef float v32f __attribute__((ext_vector_type(32)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <int N> struct VecOf;
+template <> struct VecOf<16> { using type = v16f; };
+template <> struct VecOf<32> { using type = v32f; };
+
+constexpr int kMaxOutRegs = 16; // multi-output accumulators kept in registers
+
+// Handler ids produced by the pre-decoder.  The six ids every default SR function set uses come
+// first so the scalar dispatch reaches them in three compares.
+enum : uint32_t {
+    H_CONST = 0, H_VAR = 1, H_ADD = 2, H_SUB = 3, H_MUL = 4, H_DIV = 5,
+    H_BIN_OTHER = 6,  // + (f - F_LOOSE_DIV): LOOSE_DIV .. GE  -> 6..14
+    H_BIN_ZERO = 15,  // binary node with an id that is not a binary function: yields 0
+    H_UN = 16,        // + (f - F_SIN): SIN .. LOOSE_SQRT -> 16..30
+    H_UN_ZERO = 31,   // unary node with an unknown id: yields 0
+    H_IF = 32         // ternary (any id)
+};
+constexpr uint32_t kNoOut = 0xFFFFFFFFu;
+
+struct Decoded {
+    uint32_t op;   // handler id
+    uint32_t pay;  // CONST: value bits; VAR: variable index; function: output index or kNoOut
+    int delta;     // change of stack height: 1 - arity
+};
+
+// Pre-decode one node (forward.cu:86-115 for the type/value unpacking).  `multi` selects the
+// multi-output conventions (type masked, OUT flag honoured); in single-output mode the raw type
+// is compared, so any type outside 0..3 runs the ternary path as in the reference (:213-224).
+__device__ inline Decoded decode_node(int type, float value, bool multi, int var_len, int out_len) {
+    Decoded d;
+    bool is_out = false;
+    if (multi) { is_out = (type & T_OUT) != 0; type &= T_MASK; }
+    d.pay = kNoOut;
+    if (type == T_CONST) { d.op = H_CONST; d.pay = f2bits(value); d.delta = 1; return d; }
+    if (type == T_VAR) {
+        int v = (int)value;
+        v = v < 0 ? 0 : (v >= var_len ? var_len - 1 : v); // the reference does not range-check (forward.cu:100-101)
+        d.op = H_VAR; d.pay = (uint32_t)v; d.delta = 1; return d;
+    }
+    uint32_t f = (uint32_t)value;
+    if (multi && is_out) {
+        const uint32_t bits = f2bits(value);
+        f = (uint32_t)(int)(int16_t)(bits & 0xFFFFu);
+        const uint32_t oi = (uint32_t)(int)(int16_t)(bits >> 16);
+        if (oi < (uint32_t)out_len) d.pay = oi;
+    }
+    if (type == T_UFUNC) {
+        d.op = (f >= (uint32_t)F_SIN && f <= (uint32_t)F_LOOSE_SQRT) ? H_UN + (f - F_SIN) : H_UN_ZERO;
+        d.delta = 0;
+    } else if (type == T_BFUNC) {
+        if (f >= (uint32_t)F_ADD && f <= (uint32_t)F_DIV) d.op = H_ADD + (f - F_ADD);
+        else if (f >= (uint32_t)F_LOOSE_DIV && f <= (uint32_t)F_GE) d.op = H_BIN_OTHER + (f - F_LOOSE_DIV);
+        else d.op = H_BIN_ZERO;
+        d.delta = -1;
+    } else {
+        d.op = H_IF; d.delta = -2;
+    }
+    return d;
+}
+
+// ---- node arithmetic (forward.cu:125-224) ------------------------------------------------------
+__device__ inline float op_unary(uint32_t h, float a) {
+    switch (h) {
+    case H_UN + (F_SIN - F_SIN): return sinf(a);
+    case H_UN + (F_COS - F_SIN): return cosf(a);
+    case H_UN + (F_TAN - F_SIN): return tanf(a);
+    case H_UN + (F_SINH - F_SIN): return sinhf(a);
+    case H_UN + (F_COSH - F_SIN): return coshf(a);
+    case H_UN + (F_TANH - F_SIN): return tanhf(a);
+    case H_UN + (F_LOG - F_SIN): return logf(a);
+    case H_UN + (F_LOOSE_LOG - F_SIN): return a == 0.0f ? -kMaxVal : logf(fabsf(a));
+    case H_UN + (F_EXP - F_SIN): return expf(a);
+    case H_UN + (F_INV - F_SIN): return a == 0.0f ? __builtin_nanf("") : 1.0f / a;
+    case H_UN + (F_LOOSE_INV - F_SIN): { const float d = fabsf(a) <= kDelta ? copysignf(kDelta, a) : a; return 1.0f / d; }
+    case H_UN + (F_NEG - F_SIN): return -a;
+    case H_UN + (F_ABS - F_SIN): return fabsf(a);
+    case H_UN + (F_SQRT - F_SIN): return sqrtf(a);
+    case H_UN + (F_LOOSE_SQRT - F_SIN): return sqrtf(fabsf(a));
+    default: return 0.0f; // unknown ids leave the zero-initialised result (forward.cu:117)
+    }
+}
+
+__device__ inline float op_binary_other(uint32_t h, float a, float b) {
+    switch (h) {
+    case H_BIN_OTHER + (F_LOOSE_DIV - F_LOOSE_DIV): { const float d = fabsf(b) <= kDelta ? copysignf(kDelta, b) : b; return a / d; }
+    case H_BIN_OTHER + (F_POW - F_LOOSE_DIV): return powf(a, b);
+    case H_BIN_OTHER + (F_LOOSE_POW - F_LOOSE_DIV): return (a == 0.0f && b == 0.0f) ? 0.0f : powf(fabsf(a), b);
+    case H_BIN_OTHER + (F_MAX - F_LOOSE_DIV): return a >= b ? a : b;
+    case H_BIN_OTHER + (F_MIN - F_LOOSE_DIV): return a <= b ? a : b;
+    case H_BIN_OTHER + (F_LT - F_LOOSE_DIV): return a < b ? 1.0f : -1.0f;
+    case H_BIN_OTHER + (F_GT - F_LOOSE_DIV): return a > b ? 1.0f : -1.0f;
+    case H_BIN_OTHER + (F_LE - F_LOOSE_DIV): return a <= b ? 1.0f : -1.0f;
+    case H_BIN_OTHER + (F_GE - F_LOOSE_DIV): return a >= b ? 1.0f : -1.0f;
+    default: return 0.0f;
+    }
+}
+
+// Operand stack in registers for K input rows per lane.  Height h counts the elements; the top
+// element is tos[k], element e (e < h-1) is s[k][e+1]; pushing at h == 0 parks the (meaningless)
+// tos in s[k][0].  DEPTH is the largest height supported.
+template <int K, int DEPTH>
+struct RegStack {
+    typename VecOf<DEPTH>::type s[K];
+    float tos[K];
+    int h; // wave-uniform
+};
+
+// Execute `n` pre-decoded instructions held one per lane in (opv, payv), lanes 0..n-1 in
+// execution order.  vars[k] holds input row k of this lane; outs[k] the multi-output accumulators.
+template <bool MO, int K, int DEPTH, int VL>
+__device__ inline void run_chunk(uint32_t opv, uint32_t payv, int n, RegStack<K, DEPTH> &st,
+                                 const typename VecOf<VL>::type (&vars)[K], v16f (&outs)[K]) {
+    for (int j = 0; j < n; ++j) {
+        const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)opv, j);
+        const uint32_t pay = (uint32_t)__builtin_amdgcn_readlane((int)payv, j);
+        if (op < H_ADD) { // leaf: push
+            const int h = st.h;
+#pragma unroll
+            for (int k = 0; k < K; ++k) st.s[k][h] = st.tos[k];
+            if (op == H_CONST) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) st.tos[k] = bits2f(pay);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) st.tos[k] = vars[k][pay];
+            }
+            st.h = h + 1;
+            continue;
+        }
+        float r[K], last[K];
+        if (op < H_UN) { // binary: a = top (left operand), b = next (right operand)
+            const int h = st.h - 1;
+            float b[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) b[k] = st.s[k][h];
+            st.h = h;
+            if (op < H_MUL) {
+                if (op == H_ADD) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) r[k] = st.tos[k] + b[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) r[k] = st.tos[k] - b[k];
+                }
+            } else if (op < H_BIN_OTHER) {
+                if (op == H_MUL) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) r[k] = st.tos[k] * b[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) r[k] = b[k] == 0.0f ? __builtin_nanf("") : st.tos[k] / b[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) r[k] = op_binary_other(op, st.tos[k], b[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) last[k] = b[k];
+        } else if (op < H_IF) { // unary
+#pragma unroll
+            for (int k = 0; k < K; ++k) { last[k] = st.tos[k]; r[k] = op_unary(op, st.tos[k]); }
+        } else { // ternary IF: cond = top, then = next, else = third
+            const int h = st.h - 2;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float b = st.s[k][h + 1], c = st.s[k][h];
+                r[k] = st.tos[k] > 0.0f ? b : c;
+                last[k] = c;
+            }
+            st.h = h;
+        }
+        if (MO) {
+            // every function node hands its LAST popped operand to its parent; OUT nodes add their
+            // value to an output accumulator (forward.cu:237-243)
+            if (pay != kNoOut) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) outs[k][pay] += r[k];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) r[k] = last[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) st.tos[k] = r[k];
+    }
+}
+
+// Result of the structural pre-pass over one tree.
+enum TreeClass : int { TREE_OK = 0, TREE_DEEP = 1, TREE_BAD = 2 };
+
+// Classify a tree: walk it in chunks of 64 nodes in execution (reverse prefix) order, prefix-sum
+// the stack-height deltas, and check 1 <= height everywhere, final height == 1, and the maximum
+// height against the register stack.  type/value point at the tree's row; len is already clamped.
+// Returns TreeClass; *height_out receives the maximum operand-stack height.
+__device__ inline int classify_tree(const int16_t *__restrict__ type, const float *__restrict__ value, int len,
+                                    bool multi, int var_len, int out_len, int max_height, int *height_out = nullptr) {
+    if (len <= 0) return TREE_BAD;
+    const int lane = threadIdx.x & 63;
+    int carry = 0, hmax = 0, hmin = 1;
+    for (int base = 0; base < len; base += kWave) {
+        const int r = base + lane;
+        int delta = 0;
+        if (r < len) {
+            const int i = len - 1 - r;
+            delta = decode_node(type[i], value[i], multi, var_len, out_len).delta;
+        }
+        const int hh = carry + wave_scan_incl(delta);
+        const int hv = r < len ? hh : 1;
+        hmax = max(hmax, wave_max(hv));
+        hmin = min(hmin, -wave_max(-hv));
+        carry = __shfl(hh, 63, 64);
+    }
+    if (height_out) *height_out = hmax;
+    if (hmin < 1 || carry != 1) return TREE_BAD;
+    return hmax > max_height ? TREE_DEEP : TREE_OK;
+}
+
+// ---- general (any depth, any var_len) interpreter: operand stack in scratch memory ---------------
+// One wave, lanes are input rows (K = 1).  Used only for trees/configurations the register path
+// cannot take; correctness first.  `x_row` points at this lane's input row in global memory.
+constexpr int kGeneralOuts = 256;
+
+template <bool MO>
+__device__ inline float run_general(const int16_t *__restrict__ type, const float *__restrict__ value, int len,
+                                    const float *__restrict__ x_row, int var_len, int out_len, float *outs,
+                                    float *stk /* [kMaxStack + 2] private */) {
+    int h = 0;
+    if (MO) for (int o = 0; o < out_len; ++o) outs[o] = 0.0f;
+    for (int i = len - 1; i >= 0; --i) {
+        const Decoded d = decode_node(uni((int)type[i]), bits2f(uni(f2bits(value[i]))), MO, var_len, out_len);
+        const uint32_t op = d.op;
+        if (op < H_ADD) {
+            stk[h++] = op == H_CONST ? bits2f(d.pay) : x_row[d.pay];
+            continue;
+        }
+        float r, last;
+        if (op < H_UN) {
+            const float a = stk[h - 1], b = stk[h - 2];
+            h -= 2;
+            if (op == H_ADD) r = a + b;
+            else if (op == H_SUB) r = a - b;
+            else if (op == H_MUL) r = a * b;
+            else if (op == H_DIV) r = b == 0.0f ? __builtin_nanf("") : a / b;
+            else r = op_binary_other(op, a, b);
+            last = b;
+        } else if (op < H_IF) {
+            const float a = stk[--h];
+            r = op_unary(op, a);
+            last = a;
+        } else {
+            const float a = stk[h - 1], b = stk[h - 2], c = stk[h - 3];
+            h -= 3;
+            r = a > 0.0f ? b : c;
+            last = c;
+        }
+        if (MO) {
+            if (d.pay != kNoOut) outs[d.pay] += r;
+            r = last;
+        }
+        stk[h++] = r;
+    }
+    return h > 0 ? stk[h - 1] : 0.0f;
+}
+
+} // namespace evogp

@@ -1,0 +1,33 @@
+// launch.hpp — host-side helpers shared by the C-ABI launchers (device properties, work counters).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "../../include/evogp_hip.h"
+
+#ifndef EVOGP_SR_DEFAULT_K
+#define EVOGP_SR_DEFAULT_K 4
+#endif
+#ifndef EVOGP_SR_DEFAULT_DEPTH
+#define EVOGP_SR_DEFAULT_DEPTH 16
+#endif
+
+namespace evogp {
+
+struct DeviceInfo {
+    int device = -1;
+    int num_cus = 256;
+    int max_waves_per_cu = 32;
+    size_t lds_per_cu = 160 * 1024;
+};
+
+// Properties of the CURRENT device (cached per device id).
+const DeviceInfo &device_info();
+
+// A zero-initialised 32-bit work counter in device memory for one launch on `stream`
+// (dynamic batch distribution inside persistent kernels).  Counters come from a small per-device
+// ring; the slot is cleared with hipMemsetAsync on `stream` before it is handed out, so reuse is
+// ordered by the stream.  Returns nullptr and sets *err on failure.
+unsigned *acquire_counter(hipStream_t stream, hipError_t *err);
+
+} // namespace evogp

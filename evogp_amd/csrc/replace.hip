@@ -1,0 +1,159 @@
+// replace.hip — subtree replacement: the shared primitive of mutation and crossover (gfx950).
+//
+// Replaces  _gpTreeReplace / treeGPMutationKernel / treeGPCrossoverKernel
+// (src/evogp/cuda/mutation.cu:5-115, 118-184, 224-309).  The reference runs one THREAD per output
+// tree: three serial element-wise copy loops through an 8 KB local-memory staging buffer, a serial
+// root-to-node walk to find the ancestors, and row-strided (uncoalesced) loads and stores.
+//
+// Here one WAVE builds one output tree and every lane owns one output POSITION j, so every load and
+// store is a contiguous run across the lanes:
+//
+//     j <  p            out[j] = left[j], size += diff if j is an ancestor of p
+//     p <= j < p + m    out[j] = donor[q + j - p]                      (value, type AND size)
+//     p + m <= j < len  out[j] = left[j - diff]
+//     len <= j          out[j] = 0                                     (reference: uninitialised)
+//
+// with o = size_left[p], diff = m - o, len = S + diff.  "j is an ancestor of p" needs no tree walk:
+// in prefix order it is simply  j < p < j + size_left[j]  — one compare per lane, evaluated in
+// parallel (fuzz-checked against the reference's walk through oracle/_ref).
+//
+// HBM traffic per output tree: the live prefix of the left row, the donor subtree, and one full
+// output row (8 B per node each) — the algorithmic bytes of SURVEY.md §8d.
+#include "evogp_defs.hpp"
+#include "launch.hpp"
+
+namespace evogp {
+
+constexpr int kRepBlock = 256; // 4 waves, one output tree per wave per iteration
+
+struct Row {
+    const float *v;
+    const int16_t *t;
+    const int16_t *s;
+};
+
+// Build one output row.  fallback => copy the left tree.  All arguments are wave-uniform.
+__device__ inline void build_row(const Row &L, const Row &R, int S, int p, int q, int m, bool fallback, int gp_len,
+                                 float *ov, int16_t *ot, int16_t *os) {
+    const int lane = threadIdx.x & 63;
+    int o = 0, diff = 0;
+    if (fallback) { p = S; m = 0; q = 0; } // "everything is the untouched prefix"
+    else { o = uni((int)L.s[p]); diff = m - o; }
+    const int len = S + diff;
+    for (int j = lane; j < gp_len; j += kWave) {
+        float v = 0.0f;
+        int t = 0, s = 0;
+        if (j < p) {
+            v = L.v[j]; t = L.t[j]; s = L.s[j];
+            if (j + s > p) s += diff; // ancestor of the replaced node (mutation.cu:38-88)
+        } else if (j < p + m) {
+            const int k = q + (j - p);
+            v = R.v[k]; t = R.t[k]; s = R.s[k];
+        } else if (j < len) {
+            const int k = j - diff;
+            v = L.v[k]; t = L.t[k]; s = L.s[k];
+        }
+        ov[j] = v; ot[j] = (int16_t)t; os[j] = (int16_t)s;
+    }
+}
+
+struct MutateParams {
+    const float *ov; const int16_t *ot; const int16_t *os; // old forest
+    const int *idx;
+    const float *nv; const int16_t *nt; const int16_t *ns; // new (donor) forest, whole trees
+    float *rv; int16_t *rt; int16_t *rs;
+    int pop, gp_len;
+};
+
+__global__ __launch_bounds__(kRepBlock) void mutate_kernel(MutateParams a) {
+    const int wave = uni((int)(blockIdx.x * (kRepBlock / 64) + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * (kRepBlock / 64);
+    for (int n = wave; n < a.pop; n += nwaves) {
+        const size_t off = (size_t)n * a.gp_len;
+        const Row L{a.ov + off, a.ot + off, a.os + off}, R{a.nv + off, a.nt + off, a.ns + off};
+        int S = uni((int)L.s[0]);
+        S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+        const int p = uni(a.idx[n]);
+        const int m = uni((int)R.s[0]);
+        bool fallback = p < 0 || p >= S || m < 1 || m > a.gp_len; // mutation.cu:150-160 (+ donor sanity)
+        if (!fallback) fallback = S + (m - uni((int)L.s[p])) > a.gp_len; // :170-180
+        build_row(L, R, S, p, 0, m, fallback, a.gp_len, a.rv + off, a.rt + off, a.rs + off);
+    }
+}
+
+struct CrossParams {
+    const float *v; const int16_t *t; const int16_t *s; // survivor forest
+    const int *left_idx, *right_idx, *left_node, *right_node;
+    float *rv; int16_t *rt; int16_t *rs;
+    int pop_ori, pop_new, gp_len;
+};
+
+__global__ __launch_bounds__(kRepBlock) void crossover_kernel(CrossParams a) {
+    const int wave = uni((int)(blockIdx.x * (kRepBlock / 64) + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * (kRepBlock / 64);
+    for (int n = wave; n < a.pop_new; n += nwaves) {
+        int li = uni(a.left_idx[n]);
+        li = li < 0 ? 0 : (li >= a.pop_ori ? a.pop_ori - 1 : li); // the reference does not check (mutation.cu:246-248)
+        const int ri = uni(a.right_idx[n]);
+        const size_t lo = (size_t)li * a.gp_len, off = (size_t)n * a.gp_len;
+        const Row L{a.v + lo, a.t + lo, a.s + lo};
+        int S = uni((int)L.s[0]);
+        S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+        const int p = uni(a.left_node[n]), q = uni(a.right_node[n]);
+        bool fallback = ri < 0 || ri >= a.pop_ori; // mutation.cu:256-266
+        Row R = L;
+        int m = 0;
+        if (!fallback) {
+            const size_t ro = (size_t)ri * a.gp_len;
+            R = Row{a.v + ro, a.t + ro, a.s + ro};
+            const int RS = uni((int)R.s[0]);
+            // node indices outside the live trees are undefined in the reference; here: copy left
+            fallback = p < 0 || p >= S || q < 0 || q >= RS || q >= a.gp_len;
+            if (!fallback) {
+                m = uni((int)R.s[q]);
+                fallback = m < 1 || q + m > a.gp_len || S + (m - uni((int)L.s[p])) > a.gp_len; // :279-289
+            }
+        }
+        build_row(L, R, S, p, q, m, fallback, a.gp_len, a.rv + off, a.rt + off, a.rs + off);
+    }
+}
+
+static unsigned grid_for(long trees) {
+    const DeviceInfo &dev = device_info();
+    long blocks = (trees + (kRepBlock / 64) - 1) / (kRepBlock / 64);
+    const long cap = (long)dev.num_cus * 8 * 4; // persistent beyond 4 rounds of full occupancy
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+} // namespace evogp
+
+using namespace evogp;
+
+extern "C" int evogp_hip_mutate(int pop_size, int gp_len, const float *value_ori, const int16_t *type_ori,
+                                const int16_t *size_ori, const int *mutate_indices, const float *value_new,
+                                const int16_t *type_new, const int16_t *size_new, float *value_res,
+                                int16_t *type_res, int16_t *size_res, evogp_stream_t stream_) {
+    if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack) return EVOGP_E_BADARG; // torch_wrapper.cu:103-104
+    if (!value_ori || !type_ori || !size_ori || !mutate_indices || !value_new || !type_new || !size_new || !value_res ||
+        !type_res || !size_res)
+        return EVOGP_E_NULLPTR;
+    MutateParams a{value_ori, type_ori, size_ori, mutate_indices, value_new, type_new, size_new,
+                   value_res, type_res, size_res, pop_size, gp_len};
+    hipLaunchKernelGGL(mutate_kernel, dim3(grid_for(pop_size)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int evogp_hip_crossover(int pop_size_ori, int pop_size_new, int gp_len, const float *value_ori,
+                                   const int16_t *type_ori, const int16_t *size_ori, const int *left_idx,
+                                   const int *right_idx, const int *left_node_idx, const int *right_node_idx,
+                                   float *value_res, int16_t *type_res, int16_t *size_res, evogp_stream_t stream_) {
+    if (pop_size_ori <= 0 || pop_size_new <= 0 || gp_len <= 0 || gp_len > kMaxStack) return EVOGP_E_BADARG; // :154-156
+    if (!value_ori || !type_ori || !size_ori || !left_idx || !right_idx || !left_node_idx || !right_node_idx ||
+        !value_res || !type_res || !size_res)
+        return EVOGP_E_NULLPTR;
+    CrossParams a{value_ori, type_ori, size_ori, left_idx, right_idx, left_node_idx, right_node_idx,
+                  value_res, type_res, size_res, pop_size_ori, pop_size_new, gp_len};
+    hipLaunchKernelGGL(crossover_kernel, dim3(grid_for(pop_size_new)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}

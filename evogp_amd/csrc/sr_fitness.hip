@@ -1,0 +1,369 @@
+// sr_fitness.hip — fused symbolic-regression fitness for a whole population (gfx950).
+//
+// Replaces the reference's  SR_fitness  dispatcher and its four kernel strategies
+// (src/evogp/cuda/forward.cu:402-479, 481-549, 551-692, 694-825, 827-856) with ONE fused kernel:
+//
+//   fitness[t] = (1/D) * sum_d sum_o err(labels[d][o] - tree_t(X[d])_o)        err = square | abs
+//
+// Work decomposition ("tile-resident" persistent workgroups):
+//   * the D datapoints are cut into tiles of 64*K rows; wave w of a workgroup OWNS tile w for its
+//     whole life: the lane's K input rows and labels are loaded from HBM once into VGPRs and never
+//     touched again (the dataset is read once per workgroup, not once per tree);
+//   * the workgroup pulls batches of B consecutive trees from a global atomic counter (dynamic
+//     load balance: tree lengths vary 1..gp_len).  For each batch the waves first split the B
+//     trees between them to classify them (valid? operand stack <= DEPTH?), then EVERY wave
+//     interprets all B trees on its own tile: it loads the tree coalesced (one node per lane),
+//     pre-decodes it into two VGPRs and runs the wave-uniform register-stack interpreter
+//     (interp.hpp).  All waves of a workgroup execute the same instruction stream on different
+//     rows, so they reach the batch barrier together;
+//   * per tree each wave reduces its 64*K errors with a fixed butterfly and parks the partial sum
+//     in LDS; after the batch barrier one thread per tree adds the partials in tile order and
+//     writes the mean — no memset of the output, no float atomics, no second "average" kernel,
+//     bit-reproducible from run to run.
+//
+// HBM traffic per launch = the live prefixes of value/type (6 B per node), size[t][0], 4 B of
+// fitness per tree, the dataset once per workgroup: the algorithmic bytes of SURVEY.md §8d (trees
+// are re-read once per tile from L2).  The kernel is bound by instruction issue (scalar decode +
+// VALU), not by HBM; see DESIGN.md.
+//
+// Trees the register path cannot take (operand stack deeper than DEPTH) are marked with a sentinel
+// NaN and evaluated by sr_general_kernel — a wave-per-tree interpreter with its stack in scratch
+// memory — launched right behind the fast kernel on the same stream; it only touches marked trees.
+// Configurations the register path cannot take at all (more than 32 variables, more than 16
+// outputs) run entirely on the general kernel.  Malformed trees (stack underflow, final height
+// != 1 — the reference asserts, forward.cu:298-301) get a NaN fitness.
+#include "interp.hpp"
+#include "launch.hpp"
+
+namespace evogp {
+
+constexpr uint32_t kSentinelDeep = 0x7FC0DEEDu; // quiet-NaN payload: "evaluate me in the general kernel"
+constexpr int kMaxBatch = 64;                    // trees per batch (LDS partial-sum slots)
+constexpr int kMaxWaves = 16;
+
+struct SrParams {
+    const float *value;
+    const int16_t *type;
+    const int16_t *size;
+    const float *X;  // [D][var_len]
+    const float *y;  // [D][out_len]
+    float *fitness;  // [pop]            (fitness mode)
+    float *results;  // [pop][D][out_len] (store mode: batch evaluation, no reduction)
+    unsigned *counter; // batch counter (zeroed before the launch)
+    int pop, D, gp_len, var_len, out_len;
+    int use_mse;
+    int batch;       // trees per batch, <= kMaxBatch
+    int ntiles;      // ceil(D / (64*K))
+};
+
+__device__ inline float err_term(float diff, int use_mse) { return use_mse ? diff * diff : fabsf(diff); }
+
+// K rows per lane, DEPTH-entry register stack, VL variable registers, MO = multi-output,
+// MAXW = waves per workgroup the launch bound allows.
+template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE>
+__global__ __launch_bounds__(MAXW * 64) void sr_fast_kernel(SrParams p) {
+    __shared__ float part[2][kMaxBatch][kMaxWaves]; // per-tree partial sums, double-buffered by batch parity
+    __shared__ int cls_s[2][kMaxBatch];
+    __shared__ int next_s[2];
+
+    using VARS = typename VecOf<VL>::type;
+    constexpr int TILE = kWave * K;
+    const int lane = threadIdx.x & 63;
+    const int w = uni((int)(threadIdx.x >> 6));
+    const int W = blockDim.x >> 6;
+    // a wave owns tile w; when there are more tiles than waves it also takes w+W, w+2W, ...
+    // (rows are then re-loaded per tree — the slow corner, only for D > 64*K*MAXW)
+    const bool single = p.ntiles <= W;
+
+    VARS vars[K];
+    float yv[K];
+    int d[K], dc[K];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            d[k] = tile * TILE + k * kWave + lane;
+            dc[k] = d[k] < p.D ? d[k] : p.D - 1;
+            const float *xr = p.X + (size_t)dc[k] * p.var_len;
+#pragma unroll
+            for (int v = 0; v < VL; ++v) vars[k][v] = v < p.var_len ? xr[v] : 0.0f;
+            yv[k] = (MO || STORE) ? 0.0f : p.y[dc[k]];
+        }
+    };
+    if (single) load_tile(w < p.ntiles ? w : 0);
+
+    if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)p.batch);
+    __syncthreads();
+    int par = 0;
+    for (;;) {
+        const int t0 = uni(next_s[par]);
+        if (t0 >= p.pop) break;
+        const int nb = p.pop - t0 < p.batch ? p.pop - t0 : p.batch;
+        if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)p.batch); // prefetch
+
+        // ---- phase 1: classify the batch, trees split between the waves ----
+        for (int b = w; b < nb; b += W) {
+            const size_t row = (size_t)(t0 + b) * p.gp_len;
+            int len = uni((int)p.size[row]);
+            len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
+            const int c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH);
+            if (lane == 0) cls_s[par][b] = c;
+        }
+        __syncthreads();
+
+        // ---- phase 2: every wave interprets every tree of the batch on its own rows ----
+        for (int b = 0; b < nb; ++b) {
+            const int cls_b = uni(cls_s[par][b]);
+            if (cls_b != TREE_OK) {
+                if (STORE && cls_b == TREE_BAD) { // malformed tree: the whole result row is NaN
+                    for (int tile = w; tile < p.ntiles; tile += W)
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int dd = tile * TILE + k * kWave + lane;
+                            if (dd < p.D)
+                                for (int o = 0; o < p.out_len; ++o)
+                                    p.results[((size_t)(t0 + b) * p.D + dd) * p.out_len + o] = __builtin_nanf("");
+                        }
+                }
+                continue;
+            }
+            const size_t row = (size_t)(t0 + b) * p.gp_len;
+            const float *tv = p.value + row;
+            const int16_t *tt = p.type + row;
+            int len = uni((int)p.size[row]);
+            len = len > p.gp_len ? p.gp_len : len;
+
+            float acc = 0.0f;
+            for (int tile = w; tile < p.ntiles; tile += W) {
+                if (!single) load_tile(tile);
+                v16f outs[K];
+                if (MO) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+#pragma unroll
+                        for (int o = 0; o < kMaxOutRegs; ++o) outs[k][o] = 0.0f;
+                }
+                RegStack<K, DEPTH> st;
+                st.h = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) st.tos[k] = 0.0f;
+                for (int base = 0; base < len; base += kWave) {
+                    const int r = base + lane;
+                    uint32_t opv = 0, payv = 0;
+                    if (r < len) {
+                        const int i = len - 1 - r;
+                        const Decoded dn = decode_node(tt[i], tv[i], MO, p.var_len, p.out_len);
+                        opv = dn.op; payv = dn.pay;
+                    }
+                    const int n = len - base < kWave ? len - base : kWave;
+                    run_chunk<MO, K, DEPTH, VL>(opv, payv, n, st, vars, outs);
+                }
+                if (STORE) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (d[k] < p.D) {
+                            float *rr = p.results + ((size_t)(t0 + b) * p.D + d[k]) * p.out_len;
+                            if (!MO) rr[0] = st.tos[k];
+                            else {
+#pragma unroll
+                                for (int o = 0; o < kMaxOutRegs; ++o)
+                                    if (o < p.out_len) rr[o] = outs[k][o];
+                            }
+                        }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float e;
+                    if (!MO) {
+                        e = err_term(yv[k] - st.tos[k], p.use_mse);
+                    } else {
+                        e = 0.0f;
+                        const float *yr = p.y + (size_t)dc[k] * p.out_len;
+#pragma unroll
+                        for (int o = 0; o < kMaxOutRegs; ++o)
+                            if (o < p.out_len) e += err_term(yr[o] - outs[k][o], p.use_mse);
+                    }
+                    acc += d[k] < p.D ? e : 0.0f;
+                }
+            }
+            if (!STORE) {
+                const float total = wave_sum(acc);
+                if (lane == 0) part[par][b][w] = total;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: one thread per tree adds the tile partials in tile order ----
+        if (STORE) {
+            if ((int)threadIdx.x < nb && cls_s[par][threadIdx.x] == TREE_DEEP)
+                p.results[(size_t)(t0 + threadIdx.x) * p.D * p.out_len] = bits2f(kSentinelDeep);
+        } else if ((int)threadIdx.x < nb) {
+            const int b = threadIdx.x;
+            const int c = cls_s[par][b];
+            float f;
+            if (c == TREE_OK) {
+                const int nw = p.ntiles < W ? p.ntiles : W;
+                float s = 0.0f;
+                for (int i = 0; i < nw; ++i) s += part[par][b][i];
+                f = s / (float)p.D;
+            } else {
+                f = c == TREE_DEEP ? bits2f(kSentinelDeep) : __builtin_nanf("");
+            }
+            p.fitness[t0 + b] = f;
+        }
+        par ^= 1;
+    }
+}
+
+// General path: one wave per tree, lanes are datapoints, stack/outputs in scratch memory, dataset
+// read row-major from global memory.  only_marked != 0: evaluate only trees whose first output
+// word holds the sentinel written by the fast kernel.
+template <bool MO, bool STORE>
+__global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_marked) {
+    const int lane = threadIdx.x & 63;
+    float stk[kMaxStack + 2];
+    float outs[MO ? kGeneralOuts : 1];
+    for (int t = blockIdx.x; t < p.pop; t += gridDim.x) {
+        const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
+        if (only_marked && uni(f2bits(*mark)) != kSentinelDeep) continue;
+        const size_t row = (size_t)t * p.gp_len;
+        const float *tv = p.value + row;
+        const int16_t *tt = p.type + row;
+        int len = uni((int)p.size[row]);
+        len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
+        const int cls = uni(classify_tree(tt, tv, len, MO, p.var_len, p.out_len, kMaxStack));
+        if (cls != TREE_OK && !STORE) {
+            if (lane == 0) p.fitness[t] = __builtin_nanf("");
+            continue;
+        }
+        float acc = 0.0f;
+        for (int base = 0; base < p.D; base += kWave) {
+            const int d = base + lane;
+            const int dc = d < p.D ? d : p.D - 1;
+            float res = __builtin_nanf("");
+            if (cls == TREE_OK)
+                res = run_general<MO>(tt, tv, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, outs, stk);
+            if (STORE) {
+                if (d < p.D) {
+                    float *rr = p.results + ((size_t)t * p.D + d) * p.out_len;
+                    if (!MO) rr[0] = res;
+                    else for (int o = 0; o < p.out_len; ++o) rr[o] = cls == TREE_OK ? outs[o] : __builtin_nanf("");
+                }
+                continue;
+            }
+            float e;
+            if (!MO) {
+                e = err_term(p.y[dc] - res, p.use_mse);
+            } else {
+                e = 0.0f;
+                for (int o = 0; o < p.out_len; ++o) e += err_term(p.y[(size_t)dc * p.out_len + o] - outs[o], p.use_mse);
+            }
+            acc += d < p.D ? e : 0.0f;
+        }
+        if (!STORE) {
+            const float total = wave_sum(acc);
+            if (lane == 0) p.fitness[t] = total / (float)p.D;
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE>
+static hipError_t launch_fast(SrParams p, hipStream_t stream) {
+    auto kern = sr_fast_kernel<K, DEPTH, VL, MO, MAXW, STORE>;
+    const DeviceInfo &dev = device_info();
+    p.ntiles = (p.D + 64 * K - 1) / (64 * K);
+    const int W = p.ntiles < MAXW ? p.ntiles : MAXW;
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, W * 64, 0);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    long blocks = (long)dev.num_cus * per_cu;
+    // batch size: ~16 batches per workgroup keeps the tail short and the atomics rare
+    long batch = p.pop / (blocks * 16);
+    batch = batch < 4 ? 4 : (batch > kMaxBatch ? kMaxBatch : batch);
+    if (const char *env = getenv("EVOGP_SR_BATCH")) {
+        const int b = atoi(env);
+        batch = b < 1 ? 1 : (b > kMaxBatch ? kMaxBatch : b);
+    }
+    p.batch = (int)batch;
+    const long need = (p.pop + batch - 1) / batch;
+    if (blocks > need) blocks = need;
+    p.counter = acquire_counter(stream, &e);
+    if (!p.counter) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int K, int DEPTH, int MAXW, bool STORE>
+static hipError_t launch_fast_vl(const SrParams &p, hipStream_t stream) {
+    const bool mo = p.out_len > 1;
+    if (p.var_len <= 16)
+        return mo ? launch_fast<K, DEPTH, 16, true, MAXW, STORE>(p, stream) : launch_fast<K, DEPTH, 16, false, MAXW, STORE>(p, stream);
+    return mo ? launch_fast<K, DEPTH, 32, true, MAXW, STORE>(p, stream) : launch_fast<K, DEPTH, 32, false, MAXW, STORE>(p, stream);
+}
+
+template <bool STORE>
+static hipError_t launch_general(const SrParams &p, int only_marked, hipStream_t stream) {
+    const DeviceInfo &dev = device_info();
+    long blocks = (long)dev.num_cus * 16;
+    if (blocks > p.pop) blocks = p.pop;
+    if (p.out_len > 1) hipLaunchKernelGGL((sr_general_kernel<true, STORE>), dim3((unsigned)blocks), dim3(64), 0, stream, p, only_marked);
+    else hipLaunchKernelGGL((sr_general_kernel<false, STORE>), dim3((unsigned)blocks), dim3(64), 0, stream, p, only_marked);
+    return hipGetLastError();
+}
+
+template <bool STORE>
+static int run_population(SrParams p, hipStream_t stream) {
+    const bool fast_ok = p.var_len <= 32 && p.out_len <= kMaxOutRegs && !getenv("EVOGP_SR_FORCE_GENERAL");
+    if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
+
+    int k = EVOGP_SR_DEFAULT_K, depth = EVOGP_SR_DEFAULT_DEPTH;
+    if (const char *e = getenv("EVOGP_SR_K")) k = atoi(e);
+    if (const char *e = getenv("EVOGP_SR_DEPTH")) depth = atoi(e);
+    // K rows per lane only pays when a tile is full; tiny datasets use fewer rows per lane
+    while (k > 1 && p.D < 64 * k) k >>= 1;
+    if (p.out_len > 1 && k > 2) k = 2; // 16 output accumulators per row: keep the register budget
+    hipError_t e;
+    if (k >= 4) e = depth <= 16 ? launch_fast_vl<4, 16, 4, STORE>(p, stream) : launch_fast_vl<4, 32, 4, STORE>(p, stream);
+    else if (k == 2) e = depth <= 16 ? launch_fast_vl<2, 16, 8, STORE>(p, stream) : launch_fast_vl<2, 32, 8, STORE>(p, stream);
+    else e = depth <= 16 ? launch_fast_vl<1, 16, 16, STORE>(p, stream) : launch_fast_vl<1, 32, 16, STORE>(p, stream);
+    if (e != hipSuccess) return (int)e;
+    return (int)launch_general<STORE>(p, 1, stream);
+}
+
+} // namespace evogp
+
+using namespace evogp;
+
+extern "C" int evogp_hip_sr_fitness(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len,
+                                    unsigned out_len, int use_mse, const float *value, const int16_t *type,
+                                    const int16_t *size, const float *variables, const float *labels,
+                                    float *fitnesses, unsigned kernel_type, evogp_stream_t stream_) {
+    // argument contract of torch_wrapper.cu:250-254
+    if (pop_size == 0 || data_points == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len == 0)
+        return EVOGP_E_BADARG;
+    if (kernel_type > 4) return EVOGP_E_BADARG;
+    if (!value || !type || !size || !variables || !labels || !fitnesses) return EVOGP_E_NULLPTR;
+    if (out_len > (unsigned)kGeneralOuts) return EVOGP_E_UNSUPPORTED;
+    SrParams p{};
+    p.value = value; p.type = type; p.size = size; p.X = variables; p.y = labels; p.fitness = fitnesses;
+    p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len;
+    p.out_len = (int)out_len; p.use_mse = use_mse ? 1 : 0;
+    return run_population<false>(p, (hipStream_t)stream_);
+}
+
+extern "C" int evogp_hip_batch_evaluate(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len,
+                                        unsigned out_len, const float *value, const int16_t *type, const int16_t *size,
+                                        const float *variables, float *results, evogp_stream_t stream_) {
+    if (pop_size == 0 || data_points == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len == 0)
+        return EVOGP_E_BADARG;
+    if (!value || !type || !size || !variables || !results) return EVOGP_E_NULLPTR;
+    if (out_len > (unsigned)kGeneralOuts) return EVOGP_E_UNSUPPORTED;
+    SrParams p{};
+    p.value = value; p.type = type; p.size = size; p.X = variables; p.y = nullptr; p.results = results;
+    p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len;
+    p.out_len = (int)out_len; p.use_mse = 1;
+    return run_population<true>(p, (hipStream_t)stream_);
+}

@@ -1,0 +1,76 @@
+"""StandardPipeline — evaluate, track the best tree, evolve; stop on a fitness target, a time limit
+or a generation limit (src/evogp/pipeline/standard.py:11-106)."""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from ..algorithm import GeneticProgramming
+from ..problem import BaseProblem
+
+
+class BasePipeline:
+    def step(self):
+        raise NotImplementedError
+
+    def run(self):
+        raise NotImplementedError
+
+
+class StandardPipeline(BasePipeline):
+    def __init__(self, algorithm: GeneticProgramming, problem: BaseProblem, fitness_target: float = None,
+                 generation_limit: int = 100, time_limit: int = None, is_show_details: bool = True,
+                 valid_fitness_boundry: float = 1e8):
+        self.algorithm = algorithm
+        self.problem = problem
+        self.fitness_target = fitness_target
+        self.generation_limit = generation_limit
+        self.time_limit = time_limit
+        self.is_show_details = is_show_details
+        self.valid_fitness_boundry = valid_fitness_boundry
+        self.best_tree = None
+        self.best_fitness = float("-inf")
+        self.fitness = None
+
+    def step(self):
+        fitness = self.problem.evaluate(self.algorithm.forest)
+        fitness[torch.isnan(fitness)] = -torch.inf  # invalid trees never win (standard.py:43)
+        host = fitness.cpu()
+        best = int(torch.argmax(host))
+        if host[best] > self.best_fitness:
+            self.best_fitness = host[best]
+            self.best_tree = self.algorithm.forest[best]
+        self.algorithm.step(fitness)
+        return host
+
+    def run(self):
+        start = time.time()
+        generation = 0
+        while True:
+            tic = time.time()
+            self.fitness = self.step()
+            if self.is_show_details:
+                self.show_details(tic, generation, self.fitness)
+            if self.fitness_target is not None and self.best_fitness >= self.fitness_target:
+                print("Fitness target reached!")
+                break
+            if self.time_limit is not None and time.time() - start > self.time_limit:
+                print("Time limit reached!")
+                break
+            generation += 1
+            if generation >= self.generation_limit:
+                print("Generation limit reached!")
+                break
+        return self.best_tree
+
+    def show_details(self, tic, generation, fitness):
+        b = self.valid_fitness_boundry
+        valid = fitness[(fitness < b) & (fitness > -b)]
+        ms = (time.time() - tic) * 1000
+        if len(valid):
+            stats = (f"max: {float(valid.max()):.4f}, min: {float(valid.min()):.4f}, "
+                     f"mean: {float(valid.mean()):.4f}, std: {float(valid.std(unbiased=False)):.4f}")
+        else:
+            stats = "no valid fitness"
+        print(f"Generation: {generation}, Cost time: {ms:.2f}ms\n", f"\tfitness: valid cnt: {len(valid)}, {stats}\n")

@@ -1,0 +1,5 @@
+"""evogp_amd.problem — fitness evaluation front ends (reference: src/evogp/problem/)."""
+from .base import BaseProblem
+from .symbolic_regression import SymbolicRegression
+
+__all__ = ["BaseProblem", "SymbolicRegression"]

@@ -212,7 +212,8 @@ void evogp_oracle_mutate(int pop_size, int gp_len, const float *value_ori, const
         const float *ov = value_ori + off; const int16_t *ot = type_ori + off, *os = size_ori + off;
         const float *nv = value_new + off; const int16_t *nt = type_new + off, *ns = size_new + off;
         const int p = mutate_indices[n], S = os[0];
-        if (p < 0 || p >= S || S + (ns[0] - os[p]) > gp_len) {
+        /* ns[0] outside [1, gp_len] (a malformed donor) is undefined in the reference; defined here as copy-old */
+        if (p < 0 || p >= S || ns[0] < 1 || ns[0] > gp_len || S + (ns[0] - os[p]) > gp_len) {
             copy_tree(gp_len, ov, ot, os, value_res + off, type_res + off, size_res + off);
             continue;
         }
@@ -237,7 +238,8 @@ void evogp_oracle_crossover(int pop_size_ori, int pop_size_new, int gp_len, cons
             const size_t ro = (size_t)r * gp_len;
             rv = value_ori + ro; rt = type_ori + ro; rs = size_ori + ro;
             /* node indices outside the live trees are undefined in the reference; defined here as copy-left */
-            if (p < 0 || p >= S || q < 0 || q >= rs[0]) fallback = 1;
+            if (p < 0 || p >= S || q < 0 || q >= rs[0] || q >= gp_len) fallback = 1;
+            else if (rs[q] < 1 || q + rs[q] > gp_len) fallback = 1;
             else if (S + (rs[q] - ls[p]) > gp_len) fallback = 1; /* :279-289 */
         }
         if (fallback) { copy_tree(gp_len, lv, lt, ls, value_res + off, type_res + off, size_res + off); continue; }
