@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — tree-evaluations/s of the SR fitness hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: `tree_SR_fitness` over the
+rank's population shard x 1024 datapoints (BASELINE.json configs[1]: SymbolicRegression synthetic
+10-var, pop = 100k per GPU, 1024 datapoints, max_tree_len = 64).  Inputs (forest, dataset) are
+resident in HBM before the timed region.  The path shards over trees with no data-path collective,
+so scaling is "weak": every rank evaluates its own 100k-tree shard (tree indices offset by rank so
+the union equals the single-device forest), and `value` = trees x datapoints of ALL ranks / time.
+
+Printed by rank 0: one JSON line with the contract fields plus
+  roofline      HBM roofline of the fitness kernel (algorithmic bytes / measured launch time)
+  cpu_baseline  the CPU oracle (plain-C port of the reference algorithm, OpenMP) timed on this
+                host's cores on a bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+POP_PER_GPU = 100_000
+DATAPOINTS = 1024
+VAR_LEN = 10
+GP_LEN = 64
+
+
+def c2_inputs(rank, pop, device):
+    """SURVEY.md §8d synthetic inputs for configs[1]: forest from tree_generate(keys=[42,0],
+    max_layer_cnt=6, + - * /, consts {-1,0,1}); X ~ U(-5,5) seed 1234; y = x0*x1 + x2*x3 - x4 + 0.5*x5^2."""
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    desc = GenerateDescriptor(max_tree_len=GP_LEN, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/"],
+                              max_layer_cnt=6, const_samples=[-1, 0, 1])
+    keys = torch.tensor([42, 0], dtype=torch.uint32, device=device)
+    forest = Forest.random_generate(pop, desc, keys=keys, tree_index_offset=rank * pop)
+    rng = np.random.default_rng(1234)
+    X = rng.uniform(-5, 5, (DATAPOINTS, VAR_LEN)).astype(np.float32)
+    y = (X[:, 0] * X[:, 1] + X[:, 2] * X[:, 3] - X[:, 4] + 0.5 * X[:, 5] ** 2).astype(np.float32)[:, None]
+    return forest, torch.from_numpy(X).to(device), torch.from_numpy(y).to(device), X, y
+
+
+def cpu_baseline(forest, X, y, budget_s=12.0):
+    """Time the CPU oracle on a bounded sample (first S trees of this rank's forest x all 1024
+    datapoints); S is sized from a probe so the run takes about `budget_s` seconds."""
+    from oracle.pyoracle import Oracle
+
+    o = Oracle("port")
+    v = forest.batch_node_value.cpu().numpy(); t = forest.batch_node_type.cpu().numpy(); s = forest.batch_subtree_size.cpu().numpy()
+    probe = 2048
+    t0 = time.perf_counter(); o.sr_fitness(v[:probe], t[:probe], s[:probe], X, y, True, 0); dt = time.perf_counter() - t0
+    sample = int(min(v.shape[0], max(probe, probe * budget_s / max(dt, 1e-6))))
+    t0 = time.perf_counter(); o.sr_fitness(v[:sample], t[:sample], s[:sample], X, y, True, 0); dt = time.perf_counter() - t0
+    return {
+        "value": sample * X.shape[0] / dt,
+        "unit": "tree-evals/s",
+        "cores": int(o.threads_used),
+        "kind": "port",
+        "sample": f"first {sample} trees of the rank-0 forest x {X.shape[0]} datapoints, {dt:.1f} s, OpenMP over trees "
+                  f"(host has {os.cpu_count()} logical cpus, {len(os.sched_getaffinity(0))} usable)",
+        "node_evals_per_s": float(s[:sample, 0].astype(np.int64).sum()) * X.shape[0] / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd import _lib
+    from evogp_amd.tree import set_default_device
+
+    set_default_device(device)
+    pop = args.pop_per_gpu
+    forest, Xd, yd, X, y = c2_inputs(rank, pop, device)
+    sizes = forest.batch_subtree_size[:, 0].to(torch.int64)
+    total_nodes = int(sizes.sum())
+
+    def step():
+        return forest.SR_fitness(Xd, yd, True, "auto")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fit = step()
+    barrier()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib.evogp_hip_timer_begin(stream), "timer_begin")   # HIP events on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fit = step()
+    kernel_ms = ctypes.c_float(0)
+    _lib.check(_lib.lib.evogp_hip_timer_end(stream, ctypes.byref(kernel_ms)), "timer_end")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        nodes = torch.tensor([total_nodes], dtype=torch.int64, device=device)
+        dist.all_reduce(nodes)
+        all_nodes = int(nodes.item())
+    else:
+        all_nodes = total_nodes
+
+    # one generation of the default GP loop on this shard (fitness + selection + crossover + mutation)
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+    from evogp_amd.tree import GenerateDescriptor
+
+    mdesc = GenerateDescriptor(max_tree_len=GP_LEN, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/"],
+                               max_layer_cnt=3, const_samples=[-1, 0, 1])
+    algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
+    gen_ms = []
+    for _ in range(4):
+        torch.cuda.synchronize(); g0 = time.perf_counter()
+        f = -algo.forest.SR_fitness(Xd, yd, True, "auto")
+        f[torch.isnan(f)] = -torch.inf
+        algo.step(f)
+        torch.cuda.synchronize(); gen_ms.append((time.perf_counter() - g0) * 1000)
+
+    if rank == 0:
+        n = world
+        evals = float(pop) * DATAPOINTS * n * args.steps
+        launch_s = kernel_ms.value / 1000.0 / args.steps   # average duration of one fitness launch (rank 0)
+        alg_bytes = 6.0 * total_nodes + 2.0 * pop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * pop
+        achieved = alg_bytes / launch_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("sr_fitness_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "tree_evals_per_s",
+            "value": evals / elapsed,
+            "unit": "tree-evals/s",
+            "n_gpus": n,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1000.0,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: SymbolicRegression synthetic 10-var, pop=100k per GPU, 1024 datapoints, "
+                            "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass per step",
+                "pop_per_gpu": pop, "global_pop": pop * n, "datapoints": DATAPOINTS, "var_len": VAR_LEN,
+                "max_tree_len": GP_LEN, "mean_tree_len": total_nodes / pop, "sharding": f"trees x{n}, no data-path collective",
+            },
+            "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
+            "generation_ms": {"median": float(np.median(gen_ms[1:])), "first": gen_ms[0],
+                              "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "sr_fast_kernel (+ sr_general_kernel for marked trees)",
+                "launch_ms": launch_s * 1000.0, "algorithmic_bytes": alg_bytes,
+                "note": "stack-machine interpreter: ~0.16 algorithmic B per tree-eval at D=1024, issue-bound not HBM-bound "
+                        "(DESIGN.md); lane-node-evals/s is the meaningful utilisation figure",
+            },
+        }
+        if not args.no_cpu_baseline and n == 1:
+            out["cpu_baseline"] = cpu_baseline(forest, X, y)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libevogp_hip.so")
+# EVOGP_HIP_LIB: alternative build of the same engine (A/B benchmarking of compiler flags only)
+LIB_PATH = os.environ.get("EVOGP_HIP_LIB") or os.path.join(_HERE, "lib", "libevogp_hip.so")
 
 ABI_VERSION = 1
 

@@ -1,0 +1,93 @@
+"""GPU-side test helper: call the C ABI (include/evogp_hip.h) directly with device pointers.
+numpy in, numpy out; torch is only used to own device memory."""
+import numpy as np
+import torch
+
+from evogp_amd import _lib
+
+L = _lib.lib
+DEV = "cuda:0"
+
+
+def dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(DEV)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _out3(pop, gp_len, poison=True):
+    # poison the outputs so that "every byte is written" is actually tested
+    v = torch.full((pop, gp_len), float("nan"), dtype=torch.float32, device=DEV) if poison else torch.empty((pop, gp_len), dtype=torch.float32, device=DEV)
+    t = torch.full((pop, gp_len), -7, dtype=torch.int16, device=DEV)
+    s = torch.full((pop, gp_len), -7, dtype=torch.int16, device=DEV)
+    return v, t, s
+
+
+def _np3(v, t, s):
+    torch.cuda.synchronize()
+    return v.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy()
+
+
+def generate(pop, gp_len, var_len, out_len, out_prob, const_prob, keys, d2l, rou, cs, offset=0, expect=0):
+    k = dev(keys, np.uint32); d = dev(d2l, np.float32); r = dev(rou, np.float32); c = dev(cs, np.float32)
+    v, t, s = _out3(pop, gp_len)
+    rc = L.evogp_hip_generate(pop, gp_len, var_len, out_len, c.shape[0], out_prob, const_prob, k.data_ptr(), d.data_ptr(),
+                              r.data_ptr(), c.data_ptr(), v.data_ptr(), t.data_ptr(), s.data_ptr(), offset, _stream())
+    assert rc == expect, L.evogp_hip_error_string(rc)
+    return _np3(v, t, s)
+
+
+def mutate(value, type_, size, idx, nvalue, ntype, nsize):
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(idx, np.int32),
+         dev(nvalue, np.float32), dev(ntype, np.int16), dev(nsize, np.int16)]
+    v, t, s = _out3(pop, gp_len)
+    rc = L.evogp_hip_mutate(pop, gp_len, *[x.data_ptr() for x in a], v.data_ptr(), t.data_ptr(), s.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    return _np3(v, t, s)
+
+
+def crossover(value, type_, size, li, ri, ln, rn):
+    pop, gp_len = value.shape
+    n = len(li)
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(li, np.int32), dev(ri, np.int32),
+         dev(ln, np.int32), dev(rn, np.int32)]
+    v, t, s = _out3(n, gp_len)
+    rc = L.evogp_hip_crossover(pop, n, gp_len, *[x.data_ptr() for x in a], v.data_ptr(), t.data_ptr(), s.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    return _np3(v, t, s)
+
+
+def evaluate(value, type_, size, X, out_len):
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32)]
+    res = torch.full((pop, out_len), 12345.0, dtype=torch.float32, device=DEV)
+    rc = L.evogp_hip_evaluate(pop, gp_len, a[3].shape[1], out_len, *[x.data_ptr() for x in a], res.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    torch.cuda.synchronize()
+    return res.cpu().numpy()
+
+
+def sr_fitness(value, type_, size, X, y, use_mse=True, kernel_type=0):
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32), dev(y, np.float32)]
+    D, var_len = a[3].shape
+    fit = torch.full((pop,), 12345.0, dtype=torch.float32, device=DEV)
+    rc = L.evogp_hip_sr_fitness(pop, D, gp_len, var_len, a[4].shape[1], int(use_mse), *[x.data_ptr() for x in a],
+                                fit.data_ptr(), kernel_type, _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    torch.cuda.synchronize()
+    return fit.cpu().numpy()
+
+
+def batch_evaluate(value, type_, size, X, out_len):
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32)]
+    D, var_len = a[3].shape
+    res = torch.full((pop, D, out_len), 12345.0, dtype=torch.float32, device=DEV)
+    rc = L.evogp_hip_batch_evaluate(pop, D, gp_len, var_len, out_len, *[x.data_ptr() for x in a], res.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    torch.cuda.synchronize()
+    return res.cpu().numpy()

@@ -1,0 +1,68 @@
+"""Shared test helpers: standard descriptors, random index batteries, comparison utilities."""
+import numpy as np
+
+from oracle.pyoracle import depth2leaf, live_mask, roulette_uniform  # noqa: F401
+
+ARITH = [1, 2, 3, 4]                 # + - * /
+PAPER7 = [1, 2, 3, 4, 14, 15, 16]    # + - * / sin cos tan (example/uci_sr.py:50)
+ALLF = list(range(29))
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def fbits(a):
+    """Bit patterns of float32 data with every NaN mapped to one canonical pattern (the sign and
+    payload of a NaN depend on the compiler's choice of operand order and carry no meaning)."""
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).copy()
+    u[np.isnan(a)] = 0x7FC00000
+    return u
+
+
+def assert_forest_equal(a, b, what="forest", live_only=False):
+    """Bit-exact comparison of (value, type, size) triples; live_only compares [0, len) only
+    (the reference leaves the tail uninitialised)."""
+    assert np.array_equal(a[2][:, 0], b[2][:, 0]), f"{what}: tree lengths differ"
+    m = live_mask(a[2]) if live_only else np.ones_like(a[2], dtype=bool)
+    for name, x, y in zip(("value", "type", "size"), a, b):
+        bx, by = bits(x), bits(y)
+        if not np.array_equal(bx[m], by[m]):
+            bad = np.argwhere((bx != by) & m)[0]
+            raise AssertionError(f"{what}: {name} differs at tree {bad[0]} node {bad[1]}: {x[tuple(bad)]} vs {y[tuple(bad)]}")
+
+
+def assert_close_classes(got, want, rtol, atol=0.0, what="values"):
+    """Same NaN / +inf / -inf classes, and rtol/atol agreement on the finite values."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN sets differ ({np.isnan(got).sum()} vs {np.isnan(want).sum()})"
+    assert np.array_equal(np.isposinf(got), np.isposinf(want)), f"{what}: +inf sets differ"
+    assert np.array_equal(np.isneginf(got), np.isneginf(want)), f"{what}: -inf sets differ"
+    fin = np.isfinite(want)
+    err = np.abs(got[fin] - want[fin])
+    tol = atol + rtol * np.abs(want[fin])
+    if not (err <= tol).all():
+        i = np.argmax(err - tol)
+        raise AssertionError(f"{what}: max violation got {got[fin][i]!r} want {want[fin][i]!r} (rtol {rtol})")
+
+
+def c2_dataset(D=1024, var_len=10, seed=1234):
+    """X ~ U(-5,5), y = x0*x1 + x2*x3 - x4 + 0.5*x5^2."""
+    r = np.random.default_rng(seed)
+    X = r.uniform(-5, 5, (D, var_len)).astype(np.float32)
+    y = (X[:, 0] * X[:, 1] + X[:, 2] * X[:, 3] - X[:, 4] + 0.5 * X[:, 5] ** 2).astype(np.float32)[:, None]
+    return X, y
+
+
+def random_crossover_indices(rng, sizes, n, invalid_frac=0.02):
+    pop = len(sizes)
+    li = rng.integers(0, pop, n).astype(np.int32)
+    ri = rng.integers(0, pop, n).astype(np.int32)
+    bad = rng.random(n) < invalid_frac
+    ri[bad] = rng.choice([-1, -7, pop, pop + 5], bad.sum())
+    ln = (rng.integers(0, 2**31 - 1, n) % sizes[li]).astype(np.int32)
+    rn = (rng.integers(0, 2**31 - 1, n) % sizes[np.clip(ri, 0, pop - 1)]).astype(np.int32)
+    return li, ri, ln, rn

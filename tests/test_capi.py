@@ -1,0 +1,61 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/evogp_hip.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "evogp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(evogp_hip_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_five_reference_entry_points():
+    syms = declared_symbols()
+    for name in ("generate", "mutate", "crossover", "evaluate", "sr_fitness"):
+        assert f"evogp_hip_{name}" in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from evogp_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for sym in declared_symbols():
+        assert hasattr(lib, sym), f"libevogp_hip.so does not export {sym}"
+    assert set(_lib.PROTOTYPES) | {"evogp_hip_error_string"} == set(declared_symbols())
+    assert lib.evogp_hip_abi_version() == _lib.ABI_VERSION
+
+
+def test_error_strings_and_argument_errors_without_gpu():
+    from evogp_amd import _lib
+
+    assert b"success" in _lib.lib.evogp_hip_error_string(0)
+    # argument validation happens on the host before any launch: callable without a GPU
+    rc = _lib.lib.evogp_hip_sr_fitness(0, 8, 32, 3, 1, 1, None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"out of range" in _lib.lib.evogp_hip_error_string(rc)
+    rc = _lib.lib.evogp_hip_generate(4, 2000, 3, 1, 3, 0.5, 0.5, None, None, None, None, None, None, None, 0, None)
+    assert rc == -1
+    rc = _lib.lib.evogp_hip_generate(4, 32, 3, 1, 3, 0.5, 0.5, None, None, None, None, None, None, None, 0, None)
+    assert rc == -2
+    rc = _lib.lib.evogp_hip_crossover(4, 4, 0, None, None, None, None, None, None, None, None, None, None, None)
+    assert rc == -1
+
+
+def test_ops_are_registered_with_reference_schemas():
+    import torch
+
+    import evogp_amd  # noqa: F401
+
+    s = str(torch.ops.evogp_cuda.tree_SR_fitness.default._schema)
+    assert "int i1, int i2, int i3, int i4, int i5, bool b1" in s and "int i6" in s
+    for op in ("tree_generate", "tree_mutate", "tree_crossover", "tree_evaluate", "tree_SR_fitness"):
+        assert hasattr(torch.ops.evogp_cuda, op)
+    # no CPU implementation and no fallback: CPU tensors are rejected, not silently computed
+    import pytest
+
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.evogp_cuda.tree_evaluate(1, 8, 1, 1, torch.zeros(1, 8), torch.zeros(1, 8, dtype=torch.int16),
+                                           torch.zeros(1, 8, dtype=torch.int16), torch.zeros(1, 1))

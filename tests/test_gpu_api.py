@@ -1,0 +1,166 @@
+"""GPU: the reference's Python surface on top of the HIP engine — torch.ops.evogp_cuda.*, Forest,
+GenerateDescriptor, Default{Selection,Crossover,Mutation}, GeneticProgramming, SymbolicRegression,
+StandardPipeline — exercised the way the reference's own scripts do (test/test_bind_success.py,
+test/fix_bug.py, example/basic.py, src/evogp/sr_test.py)."""
+import pickle
+
+import numpy as np
+import pytest
+
+from helpers import assert_close_classes, bits, c2_dataset, depth2leaf, roulette_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available()
+    import evogp_amd  # noqa: F401
+
+    return torch
+
+
+def _desc_tensors(torch, mlc=3):
+    keys = torch.tensor([42, 0], dtype=torch.uint32, device="cuda")
+    d2l = torch.tensor([0.1] * (mlc - 1) + [1.0] * (10 - (mlc - 1)), dtype=torch.float32, device="cuda")
+    rou = torch.tensor([0.0, 0.25, 0.5, 0.75, 1.0] + [1.0] * 24, dtype=torch.float32, device="cuda")
+    cs = torch.tensor([-1.0, 0.0, 1.0], dtype=torch.float32, device="cuda")
+    return keys, d2l, rou, cs
+
+
+def test_bind_success_script_flow(torch_mod, oracle):
+    """test/test_bind_success.py: generate -> crossover -> evaluate -> SR fitness through torch.ops."""
+    torch = torch_mod
+    keys, d2l, rou, cs = _desc_tensors(torch)
+    v, t, s = torch.ops.evogp_cuda.tree_generate(2, 64, 2, 1, 3, 0.3, 0.5, keys, d2l, rou, cs)
+    assert v.dtype == torch.float32 and t.dtype == torch.int16 and s.dtype == torch.int16 and v.shape == (2, 64)
+    assert t[0, :7].tolist() == [3, 3, 0, 1, 3, 0, 1] and s[1, :7].tolist() == [7, 3, 1, 1, 3, 1, 1]  # Appendix B1
+    res = torch.ops.evogp_cuda.tree_evaluate(2, 64, 2, 1, v, t, s, torch.tensor([[1.0, 2.0], [3.0, 4.0]], device="cuda"))
+    assert res.ravel().tolist() == [3.0, 1.0]
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32, device="cuda")
+    cv, ct, cs_ = torch.ops.evogp_cuda.tree_crossover(2, 1, 64, v, t, s, i32([0]), i32([1]), i32([2]), i32([4]))
+    assert cs_[0, :9].tolist() == [9, 5, 3, 1, 1, 1, 3, 1, 1]
+    v1, t1, s1 = torch.ops.evogp_cuda.tree_generate(2, 64, 1, 1, 3, 0.3, 0.5, keys, d2l, rou, cs)
+    fit = torch.ops.evogp_cuda.tree_SR_fitness(2, 2, 64, 1, 1, True, v1, t1, s1, torch.tensor([[1.0], [2.0]], device="cuda"),
+                                               torch.tensor([[1.0], [3.0]], device="cuda"), 0)
+    assert fit.tolist() == [0.5, 2.0]  # Appendix B2
+    mv, mt, ms = torch.ops.evogp_cuda.tree_mutate(2, 64, v, t, s, i32([1, 0]), v.flip(0).contiguous(), t.flip(0).contiguous(), s.flip(0).contiguous())
+    assert ms[1, 0].item() == 7 and ms[0, 0].item() == 11
+
+
+def test_argument_errors_are_runtime_errors(torch_mod):
+    torch = torch_mod
+    keys, d2l, rou, cs = _desc_tensors(torch)
+    with pytest.raises(RuntimeError, match="gp_len must be in range"):
+        torch.ops.evogp_cuda.tree_generate(2, 2000, 2, 1, 3, 0.3, 0.5, keys, d2l, rou, cs)
+    with pytest.raises(RuntimeError, match="pop_size must larger than 0"):
+        torch.ops.evogp_cuda.tree_generate(0, 64, 2, 1, 3, 0.3, 0.5, keys, d2l, rou, cs)
+    with pytest.raises(RuntimeError, match="roulette_funcs must have shape"):
+        torch.ops.evogp_cuda.tree_generate(2, 64, 2, 1, 3, 0.3, 0.5, keys, d2l, rou[:24].contiguous(), cs)
+    with pytest.raises(RuntimeError, match="out_prob must be in range"):
+        torch.ops.evogp_cuda.tree_generate(2, 64, 2, 1, 3, 1.3, 0.5, keys, d2l, rou, cs)
+    v, t, s = torch.ops.evogp_cuda.tree_generate(4, 64, 2, 1, 3, 0.3, 0.5, keys, d2l, rou, cs)
+    with pytest.raises(RuntimeError, match="contiguous CUDA tensor"):
+        torch.ops.evogp_cuda.tree_evaluate(4, 64, 2, 1, v, t, s, torch.zeros(2, 4, device="cuda").t())
+    with pytest.raises(RuntimeError, match="variables must have shape"):
+        torch.ops.evogp_cuda.tree_evaluate(4, 64, 2, 1, v, t, s, torch.zeros(3, 2, device="cuda"))
+
+
+def test_fix_bug_tree_known_answer(torch_mod):
+    """test/fix_bug.py: (x0-x2)*(x0-x2) on four XOR rows -> MSE 0.5 in both execution modes."""
+    torch = torch_mod
+    from evogp_amd.tree import Tree
+
+    tree = Tree(3, 1,
+                node_type=torch.tensor([3, 3, 0, 0, 3, 0, 0, 0], dtype=torch.int16, device="cuda"),
+                node_value=torch.tensor([3., 2., 0., 2., 2., 0., 2., 0.], dtype=torch.float32, device="cuda"),
+                subtree_size=torch.tensor([7, 3, 1, 1, 3, 1, 1, 0], dtype=torch.int16, device="cuda"))
+    X = torch.tensor([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1]], dtype=torch.float, device="cuda")
+    y = torch.tensor([[0], [1], [1], [0]], dtype=torch.float, device="cuda")
+    assert tree.SR_fitness(X, y, execute_mode="hybrid parallel").item() == 0.5
+    assert tree.SR_fitness(X, y, execute_mode="data parallel").item() == 0.5
+    assert tree.forward(X).ravel().tolist() == [0.0, 1.0, 0.0, 1.0]
+    assert tree.forward(X[1]).tolist() == [1.0]
+    assert "x0" in str(tree) and "x2" in str(tree)
+
+
+def test_forest_api_matches_oracle(torch_mod, oracle):
+    torch = torch_mod
+    from evogp_amd.tree import Forest, GenerateDescriptor, Tree
+
+    desc = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/"],
+                              max_layer_cnt=6, const_samples=[-1, 0, 1])
+    keys = torch.tensor([42, 0], dtype=torch.uint32, device="cuda")
+    forest = Forest.random_generate(2000, desc, keys=keys)
+    want = oracle.generate(2000, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform([1, 2, 3, 4]), [-1, 0, 1])
+    assert np.array_equal(forest.batch_subtree_size.cpu().numpy(), want[2])
+    assert np.array_equal(bits(forest.batch_node_value.cpu().numpy()), bits(want[0]))
+    X, y = c2_dataset()
+    fit = forest.SR_fitness(torch.from_numpy(X), torch.from_numpy(y))
+    assert_close_classes(fit.cpu().numpy(), oracle.sr_fitness(*want, X, y), 1e-5, what="Forest.SR_fitness")
+    # forward (one row per tree) and batch_forward (shared rows) agree with each other and the oracle
+    xb = torch.from_numpy(X[:5]).cuda()
+    bf = forest.batch_forward(xb)
+    assert bf.shape == (2000, 5, 1)
+    fw = forest.forward(xb[2:3].repeat(2000, 1))
+    assert torch.equal(torch.nan_to_num(bf[:, 2, :], nan=7.0), torch.nan_to_num(fw, nan=7.0))
+    # container protocol
+    assert isinstance(forest[3], Tree) and len(forest[10:20]) == 10 and len(forest + forest[0]) == 2001
+    mask = torch.zeros(2000, dtype=torch.bool); mask[::7] = True
+    assert len(forest[mask]) == int(mask.sum())
+    again = pickle.loads(pickle.dumps(forest[:50]))
+    assert torch.equal(again.batch_node_type, forest.batch_node_type[:50])
+    z = Forest.zero_generate(4, 16, 3, 1)
+    assert z.forward(torch.ones(4, 3)).ravel().tolist() == [0.0] * 4
+
+
+def test_basic_example_pipeline_runs_and_improves(torch_mod):
+    """example/basic.py scaled to a few generations: XOR-3d SR with the default operator set."""
+    torch = torch_mod
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+    from evogp_amd.pipeline import StandardPipeline
+    from evogp_amd.problem import SymbolicRegression
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    torch.manual_seed(0)
+    X = torch.tensor([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=torch.float, device="cuda")
+    y = (X.sum(1) % 2)[:, None]
+    problem = SymbolicRegression(datapoints=X, labels=y)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=problem.problem_dim, output_len=problem.solution_dim,
+                              using_funcs=["+", "-", "*", "/"], max_layer_cnt=5, const_samples=[-1, 0, 1])
+    algo = GeneticProgramming(initial_forest=Forest.random_generate(pop_size=5000, descriptor=desc),
+                              crossover=DefaultCrossover(), mutation=DefaultMutation(0.2, desc.update(max_layer_cnt=3)),
+                              selection=DefaultSelection(survival_rate=0.3, elite_rate=0.01), enable_pareto_front=True)
+    pipe = StandardPipeline(algo, problem, generation_limit=15, is_show_details=False)
+    first = float(torch.nan_to_num(problem.evaluate(algo.forest), nan=-1e9).max())
+    best = pipe.run()
+    assert algo.forest.pop_size == 5000
+    assert float(pipe.best_fitness) >= first  # elitism: never worse
+    assert float(pipe.best_fitness) > -0.5    # better than any constant the leaf set offers (0, 1, -1)
+    pred = best.forward(X)
+    assert pred.shape == (8, 1)
+    # every tree of the final population is structurally valid
+    from oracle.pyoracle import Oracle
+    o = Oracle("port")
+    tt, ss = algo.forest.batch_node_type.cpu().numpy(), algo.forest.batch_subtree_size.cpu().numpy()
+    assert all(o.validate_tree(tt[i], ss[i]) == 0 for i in range(0, 5000, 13))
+
+
+def test_sr_installation_scenario(torch_mod):
+    """src/evogp/sr_test.py shape: pop 1000, 1000 datapoints, func-generated data, torch and kernel modes agree."""
+    torch = torch_mod
+    from evogp_amd.problem import SymbolicRegression
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    torch.manual_seed(0)
+    prob = SymbolicRegression(func=lambda x: (x[0] + x[1]) ** 2, num_inputs=2, num_data=1000, lower_bounds=-5, upper_bounds=5)
+    assert prob.datapoints.shape == (1000, 2) and prob.labels.shape == (1000, 1)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=2, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5,
+                              const_range=(-1, 1), sample_cnt=8)
+    forest = Forest.random_generate(1000, desc)
+    a = prob.evaluate(forest)
+    prob.execute_mode = "torch"
+    b = prob.evaluate(forest)
+    assert_close_classes(a.cpu().numpy(), b.cpu().numpy(), 1e-4, what="kernel vs torch mode")

@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP engine, called THROUGH THE C ABI, against the CPU oracle and the
+committed golden vectors.
+
+Bars (BASELINE.json north_star): tree encodings from generate / crossover / mutate are BIT-EXACT;
+SR fitness and evaluation agree within 1e-5 relative (fp32) on the arithmetic function set —
+in fact bit-exact per datapoint there (IEEE + - * / on both sides; only the order of the final
+summation differs) — and within the transcendental-library tolerance stated below for the
+sin/cos/exp/pow families (device OCML vs host glibc: a few ulp per call, amplified by the tree).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (ALLF, ARITH, PAPER7, assert_close_classes, assert_forest_equal, bits, c2_dataset, depth2leaf, fbits,
+                     random_crossover_indices, roulette_uniform)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+BATTERIES = sorted(glob.glob(os.path.join(GOLD, "battery_*.npz")))
+CS3 = [-1.0, 0.0, 1.0]
+
+RTOL_ARITH = 1e-5   # north_star bar
+RTOL_TRANS = 2e-3   # trees of transcendental nodes: ulp-level libm differences amplified by the tree
+ATOL_TRANS = 1e-4
+
+
+@pytest.fixture(scope="module")
+def g():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import gpu_capi
+
+    return gpu_capi
+
+
+# ---- generate: bit-exact ---------------------------------------------------------------------
+@pytest.mark.parametrize("funcs,out_len,var_len,L,mlc", [
+    (ARITH, 1, 10, 64, 6), (ARITH, 1, 3, 32, 4), (PAPER7, 1, 5, 64, 6), (ALLF, 1, 4, 128, 5),
+    (ARITH, 3, 6, 64, 6), (ALLF, 4, 3, 128, 5), (ARITH, 1, 2, 1024, 9), ([0], 2, 3, 1024, 6)])
+def test_generate_bit_exact(g, oracle, funcs, out_len, var_len, L, mlc):
+    rou, d2l = roulette_uniform(funcs), depth2leaf(mlc)
+    cs = np.array([-1, 0, 1, 0.5, 2], np.float32)
+    for pop, keys in ((1, [1, 2]), (63, [42, 0]), (1000, [123456, 654321]), (4097, [2**32 - 1, 7])):
+        want = oracle.generate(pop, L, var_len, out_len, 0.37, 0.61, keys, d2l, rou, cs)
+        got = g.generate(pop, L, var_len, out_len, 0.37, 0.61, keys, d2l, rou, cs)
+        assert_forest_equal(got, want, f"generate pop={pop}")  # full rows: tails are zero on both sides
+
+
+def test_generate_tree_index_offset_makes_shards_identical(g, oracle):
+    rou, d2l = roulette_uniform(ARITH), depth2leaf(6)
+    full = g.generate(1000, 64, 10, 1, 0.5, 0.5, [42, 0], d2l, rou, CS3)
+    parts = [g.generate(250, 64, 10, 1, 0.5, 0.5, [42, 0], d2l, rou, CS3, offset=250 * r) for r in range(4)]
+    assert_forest_equal(tuple(np.concatenate([p[i] for p in parts]) for i in range(3)), full, "sharded generate")
+    assert_forest_equal(full, oracle.generate(1000, 64, 10, 1, 0.5, 0.5, [42, 0], d2l, rou, CS3), "vs oracle")
+
+
+def test_generate_extreme_probabilities(g, oracle):
+    rou = roulette_uniform(ARITH)
+    for d2l in (np.array([0.0] * 5 + [1.0] * 5, np.float32), np.array([1.0] * 10, np.float32)):
+        for cp in (0.0, 1.0):
+            want = oracle.generate(300, 64, 3, 1, 0.0, cp, [8, 9], d2l, rou, CS3)
+            got = g.generate(300, 64, 3, 1, 0.0, cp, [8, 9], d2l, rou, CS3)
+            assert_forest_equal(got, want, "generate extremes")
+
+
+# ---- golden batteries (reference outputs) -------------------------------------------------------
+@pytest.mark.parametrize("path", BATTERIES, ids=[os.path.basename(p)[8:-4] for p in BATTERIES])
+def test_golden_battery(g, path):
+    z = np.load(path)
+    out_len, var_len, L = int(z["out_len"]), int(z["var_len"]), int(z["gp_len"])
+    pop = z["value"].shape[0]
+    trans = any(int(f) not in (1, 2, 3, 4) for f in z["funcs"])
+    forest = g.generate(pop, L, var_len, out_len, 0.5, 0.5, z["keys"], z["depth2leaf"], z["roulette"], z["consts"])
+    assert_forest_equal(forest, (z["value"], z["type"], z["size"]), "generate", live_only=True)
+    cr = g.crossover(*forest, z["left_idx"], z["right_idx"], z["left_node"], z["right_node"])
+    assert_forest_equal(cr, (z["cross_value"], z["cross_type"], z["cross_size"]), "crossover", live_only=True)
+    mu = g.mutate(*forest, z["mut_idx"], z["new_value"], z["new_type"], z["new_size"])
+    assert_forest_equal(mu, (z["mut_value"], z["mut_type"], z["mut_size"]), "mutate", live_only=True)
+    rt, at = (RTOL_TRANS, ATOL_TRANS) if trans else (RTOL_ARITH, 0.0)
+    ev = g.evaluate(*forest, z["eval_x"], out_len)
+    if trans:
+        _assert_mostly_close(ev, z["eval_out"], rt, at, "evaluate")
+        _assert_mostly_close(g.sr_fitness(*forest, z["sr_x"], z["sr_y"], True), z["sr_mse"], rt, at, "sr mse")
+        _assert_mostly_close(g.sr_fitness(*forest, z["sr_x"], z["sr_y"], False), z["sr_mae"], rt, at, "sr mae")
+    else:
+        assert np.array_equal(fbits(ev), fbits(z["eval_out"])), "arithmetic evaluation must be bit-exact"
+        assert_close_classes(g.sr_fitness(*forest, z["sr_x"], z["sr_y"], True), z["sr_mse"], rt, what="sr mse")
+        assert_close_classes(g.sr_fitness(*forest, z["sr_x"], z["sr_y"], False), z["sr_mae"], rt, what="sr mae")
+
+
+def _assert_mostly_close(got, want, rtol, atol, what, allowed_bad=0.02):
+    """Transcendental sets: trees such as tan(tan(x)) or a/(sin(x)-sin(x)) are ill-conditioned, so
+    two IEEE-correct libms legitimately disagree on a few of them.  Require the
+    same result on >= 98 % of the entries and the same NaN class wherever the oracle is finite
+    and well away from overflow."""
+    got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
+    fin = np.isfinite(want) & np.isfinite(got)
+    ok = np.abs(got[fin] - want[fin]) <= atol + rtol * np.abs(want[fin])
+    same_class = (np.isnan(got) == np.isnan(want)) & (np.isposinf(got) == np.isposinf(want)) & (np.isneginf(got) == np.isneginf(want))
+    bad = (~same_class).sum() + (~ok).sum()
+    assert bad <= allowed_bad * got.size, f"{what}: {bad} of {got.size} entries disagree"
+
+
+# ---- crossover / mutate: bit-exact on fuzzed inputs ----------------------------------------------
+@pytest.mark.parametrize("L,mlc,funcs", [(64, 6, ARITH), (32, 4, ARITH), (128, 5, ALLF), (1024, 9, ARITH), (200, 5, [0, 1, 14])])
+def test_crossover_mutate_bit_exact(g, oracle, rng, L, mlc, funcs):
+    rou = roulette_uniform(funcs)
+    pop = 3000
+    forest = oracle.generate(pop, L, 5, 1, 0.5, 0.5, [17, 4], depth2leaf(mlc), rou, CS3)
+    sizes = forest[2][:, 0].astype(np.int64)
+    idx = random_crossover_indices(rng, sizes, 7000)
+    assert_forest_equal(g.crossover(*forest, *idx), oracle.crossover(*forest, *idx), "crossover")
+    new = oracle.generate(pop, L, 5, 1, 0.5, 0.5, [4, 17], depth2leaf(max(2, mlc - 2)), rou, CS3)
+    mi = (rng.integers(0, 1024, pop) % sizes).astype(np.int32)
+    mi[:6] = [-1, 100000, 0, -5, L, L - 1]
+    assert_forest_equal(g.mutate(*forest, mi, *new), oracle.mutate(*forest, mi, *new), "mutate")
+    # second generation: operate on evolved trees (longer, results hit the length cap)
+    child = oracle.crossover(*forest, *idx)
+    csz = child[2][:, 0].astype(np.int64)
+    idx2 = random_crossover_indices(rng, csz, 5000)
+    got, want = g.crossover(*child, *idx2), oracle.crossover(*child, *idx2)
+    assert_forest_equal(got, want, "crossover gen 2")
+    for n in range(0, 5000, 97):
+        assert oracle.validate_tree(got[1][n], got[2][n]) == 0
+
+
+def test_crossover_every_position_of_one_pair(g, oracle):
+    """Exhaustive: every (left position, right position) pair of two 15-node trees, including a
+    ternary parent whose MIDDLE child is replaced (the reference reads an uncopied size there,
+    mutation.cu:68-75 — SURVEY.md §7.3-5a)."""
+    rou = roulette_uniform([0, 1, 14])
+    forest = oracle.generate(64, 40, 3, 1, 0.5, 0.5, [3, 1], depth2leaf(4, 0.0), rou, CS3)
+    sizes = forest[2][:, 0].astype(np.int64)
+    a, b = int(np.argmax(sizes)), int(np.argsort(sizes)[-2])
+    pairs = [(p, q) for p in range(sizes[a]) for q in range(sizes[b])]
+    li = np.full(len(pairs), a, np.int32); ri = np.full(len(pairs), b, np.int32)
+    ln = np.array([p for p, _ in pairs], np.int32); rn = np.array([q for _, q in pairs], np.int32)
+    assert_forest_equal(g.crossover(*forest, li, ri, ln, rn), oracle.crossover(*forest, li, ri, ln, rn), "exhaustive")
+
+
+# ---- evaluation ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("out_len", [1, 3])
+def test_evaluate_arith_bit_exact(g, oracle, rng, out_len):
+    forest = oracle.generate(5000, 64, 17, out_len, 0.5, 0.5, [1, 2], depth2leaf(6), roulette_uniform(ARITH), CS3)
+    X = rng.normal(0, 1, (5000, 17)).astype(np.float32)
+    assert np.array_equal(fbits(g.evaluate(*forest, X, out_len)), fbits(oracle.evaluate(*forest, X, out_len)))
+
+
+def test_evaluate_each_function_alone(g, oracle, rng):
+    """One function at a time (plus + to build trees): tolerances per family."""
+    for f in range(29):
+        funcs = [f] if f == 0 or f >= 14 else [f]
+        forest = oracle.generate(400, 40, 3, 1, 0.5, 0.5, [f, 99], depth2leaf(3, 0.1), roulette_uniform(funcs + [1]), [-1.5, 0.0, 0.5, 2.0])
+        X = rng.uniform(-2, 2, (400, 3)).astype(np.float32)
+        got, want = g.evaluate(*forest, X, 1), oracle.evaluate(*forest, X, 1)
+        exact = f in (0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 23, 24, 25, 26, 27, 28)  # IEEE-exact ops (incl. / and sqrt)
+        if exact:
+            assert np.array_equal(fbits(got), fbits(want)), f"function {f} must be bit-exact"
+        else:
+            _assert_mostly_close(got, want, 1e-4, 1e-5, f"function {f}", allowed_bad=0.01)
+
+
+def test_deep_and_long_trees_take_the_general_path(g, oracle, rng):
+    """Left-deep chains need an operand stack of (L+1)/2 > 32 entries: register path -> scratch path."""
+    L = 1024
+    for n_nodes in (31, 63, 65, 129, 1023):
+        k = (n_nodes - 1) // 2
+        # prefix of a left-deep tree: k ADD/SUB nodes, then k+1 leaves
+        v = np.zeros((3, L), np.float32); t = np.zeros((3, L), np.int16); s = np.zeros((3, L), np.int16)
+        for r in range(3):
+            v[r, :k] = 1 + (np.arange(k) + r) % 3; t[r, :k] = 3
+            s[r, :k] = n_nodes - 2 * np.arange(k)
+            leaves = np.arange(k, n_nodes)
+            t[r, leaves] = np.where(leaves % 2 == 0, 0, 1); v[r, leaves] = np.where(leaves % 2 == 0, leaves % 4, 0.5 + r)
+            s[r, leaves] = 1
+            assert oracle.validate_tree(t[r], s[r]) == 0
+        X = rng.uniform(-1, 1, (3, 4)).astype(np.float32)
+        assert np.array_equal(fbits(g.evaluate(v, t, s, X, 1)), fbits(oracle.evaluate(v, t, s, X, 1))), n_nodes
+        Xd = rng.uniform(-1, 1, (130, 4)).astype(np.float32); yd = rng.uniform(-1, 1, (130, 1)).astype(np.float32)
+        assert_close_classes(g.sr_fitness(v, t, s, Xd, yd), oracle.sr_fitness(v, t, s, Xd, yd), RTOL_ARITH, what=f"deep {n_nodes}")
+        assert np.array_equal(fbits(g.batch_evaluate(v, t, s, Xd, 1)), fbits(oracle.batch_evaluate(v, t, s, Xd, 1)))
+
+
+def test_malformed_trees_yield_nan(g):
+    L = 16
+    v = np.zeros((4, L), np.float32); t = np.zeros((4, L), np.int16); s = np.zeros((4, L), np.int16)
+    t[0, :2] = [3, 0]; s[0, :2] = [2, 1]; v[0, 0] = 1          # ADD with one operand: stack underflow
+    t[1, :2] = [0, 0]; s[1, 0] = 2                             # two leaves: final height 2
+    s[2, 0] = 0                                                # empty tree
+    t[3, :3] = [3, 0, 1]; s[3, :3] = [3, 1, 1]; v[3, :3] = [1, 0, 2]  # valid: x0 + 2
+    X = np.ones((5, 1), np.float32); y = np.zeros((5, 1), np.float32)
+    fit = g.sr_fitness(v, t, s, X, y)
+    assert np.isnan(fit[:3]).all() and fit[3] == 9.0
+    ev = g.evaluate(v, t, s, np.ones((4, 1), np.float32), 1)
+    assert np.isnan(ev[:3]).all() and ev[3, 0] == 3.0
+
+
+# ---- SR fitness ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [1, 8, 63, 64, 65, 256, 1000, 1024, 1025, 2500, 5000])
+def test_sr_fitness_ragged_datapoint_counts(g, oracle, rng, D):
+    forest = oracle.generate(777, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform(ARITH), CS3)
+    X = rng.uniform(-5, 5, (D, 10)).astype(np.float32); y = rng.uniform(-5, 5, (D, 1)).astype(np.float32)
+    for mse in (True, False):
+        assert_close_classes(g.sr_fitness(*forest, X, y, mse), oracle.sr_fitness(*forest, X, y, mse), RTOL_ARITH, what=f"D={D} mse={mse}")
+
+
+@pytest.mark.parametrize("var_len,out_len", [(1, 1), (16, 1), (17, 1), (32, 2), (33, 1), (64, 10), (5, 16), (5, 17)])
+def test_sr_fitness_shapes(g, oracle, rng, var_len, out_len):
+    forest = oracle.generate(500, 64, var_len, out_len, 0.5, 0.5, [5, 5], depth2leaf(6), roulette_uniform(ARITH), CS3)
+    X = rng.uniform(-2, 2, (300, var_len)).astype(np.float32); y = rng.uniform(-2, 2, (300, out_len)).astype(np.float32)
+    assert_close_classes(g.sr_fitness(*forest, X, y), oracle.sr_fitness(*forest, X, y), RTOL_ARITH, what=f"var={var_len} out={out_len}")
+    be = g.batch_evaluate(*forest, X[:70], out_len)
+    assert np.array_equal(fbits(be), fbits(oracle.batch_evaluate(*forest, X[:70], out_len)))
+
+
+def test_sr_fitness_c1_xor_config(g, oracle):
+    """BASELINE configs[0]: XOR-3d, pop 5000, max_tree_len 32, 8 datapoints."""
+    forest = oracle.generate(5000, 32, 3, 1, 0.5, 0.5, [42, 0], depth2leaf(4), roulette_uniform(ARITH), CS3)
+    X = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.float32)
+    y = (X.sum(1) % 2).astype(np.float32)[:, None]
+    got = g.sr_fitness(*forest, X, y)
+    assert_close_classes(got, oracle.sr_fitness(*forest, X, y), RTOL_ARITH, what="C1")
+    assert int(np.isnan(got).sum()) == 2430
+
+
+def test_sr_fitness_c2_config_subset_and_kernel_types(g, oracle):
+    """BASELINE configs[1] shape (10 variables, 1024 datapoints, L = 64) on a 20k-tree subset, and every
+    kernel_type code returns the same bits."""
+    forest = oracle.generate(20000, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform(ARITH), CS3)
+    X, y = c2_dataset()
+    want = oracle.sr_fitness(*forest, X, y)
+    got = g.sr_fitness(*forest, X, y, True, 0)
+    assert_close_classes(got, want, RTOL_ARITH, what="C2")
+    for kt in (1, 2, 3, 4):
+        assert np.array_equal(bits(g.sr_fitness(*forest, X, y, True, kt)), bits(got))
+    assert np.array_equal(bits(g.sr_fitness(*forest, X, y, True, 0)), bits(got)), "run-to-run reproducible"
+
+
+def test_sr_fitness_paper_function_set(g, oracle):
+    forest = oracle.generate(4000, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform(PAPER7), CS3)
+    X, y = c2_dataset()
+    _assert_mostly_close(g.sr_fitness(*forest, X, y), oracle.sr_fitness(*forest, X, y), RTOL_TRANS, ATOL_TRANS, "paper7")
+
+
+def test_full_size_properties(g, oracle):
+    """BASELINE full size (pop 100k x 1024 datapoints): size-independent checks —
+    (1) fitness of a forest equals fitness of its two halves concatenated (row independence),
+    (2) evaluate-then-reduce equals the fused fitness on a sampled subset,
+    (3) linearity: fitness against labels y equals mean((tree - y)^2) from batch_evaluate."""
+    rou, d2l = roulette_uniform(ARITH), depth2leaf(6)
+    pop = 100_000
+    forest = g.generate(pop, 64, 10, 1, 0.5, 0.5, [42, 0], d2l, rou, CS3)
+    assert abs(forest[2][:, 0].mean() - 26.26) < 0.2  # measured mean length 26.26
+    X, y = c2_dataset()
+    full = g.sr_fitness(*forest, X, y)
+    h = pop // 2
+    halves = np.concatenate([g.sr_fitness(*(a[:h] for a in forest), X, y), g.sr_fitness(*(a[h:] for a in forest), X, y)])
+    assert np.array_equal(bits(full), bits(halves))
+    pick = np.arange(0, pop, 997)
+    sub = tuple(a[pick] for a in forest)
+    assert_close_classes(full[pick], oracle.sr_fitness(*sub, X, y), RTOL_ARITH, what="sample vs oracle")
+    pred = g.batch_evaluate(*sub, X, 1)[:, :, 0]
+    with np.errstate(all="ignore"):
+        d = pred - y[:, 0][None, :]                    # fp32, like the kernel
+        ref = (d * d).astype(np.float64).mean(1)       # squares in fp32 (same overflow), sum in fp64
+    assert_close_classes(full[pick], ref.astype(np.float32), 1e-4, what="fused vs batch_evaluate")
