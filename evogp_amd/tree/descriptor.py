@@ -20,6 +20,8 @@ from .utils import FUNCS_NAMES, MAX_FULL_DEPTH, MAX_STACK, Func, check_tensor, d
 def check_tree_length(max_tree_len, using_funcs, max_layer_cnt, layer_leaf_prob) -> Tensor:
     """Assert that a full tree of ``max_layer_cnt`` layers with the largest arity in use fits in
     ``max_tree_len`` nodes, and build ``depth2leaf_probs`` (descriptor.py:8-39)."""
+    for name in using_funcs:
+        assert name in FUNCS_NAMES, f"Unknown function name: {name}, total functions are {FUNCS_NAMES}"
     max_arity = max(func_arity(FUNCS_NAMES.index(name)) for name in using_funcs)
     if max_arity > 1:
         full_len = int((max_arity**max_layer_cnt - 1) / (max_arity - 1))

@@ -1,0 +1,150 @@
+"""CPU: host-side logic of the reference API surface (descriptor tensors, selection / crossover /
+mutation index arithmetic, Forest container protocol, pipeline loop) on CPU tensors with the
+test-only oracle-backed ops."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import cpu_ops  # noqa: E402
+
+cpu_ops.register()
+from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming  # noqa: E402
+from evogp_amd.pipeline import StandardPipeline  # noqa: E402
+from evogp_amd.problem import SymbolicRegression  # noqa: E402
+from evogp_amd.tree import MAX_STACK, Forest, GenerateDescriptor, NType, Tree, randint, set_default_device  # noqa: E402
+
+set_default_device("cpu")
+
+
+def desc(**kw):
+    base = dict(max_tree_len=64, input_len=3, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5, const_samples=[-1, 0, 1])
+    base.update(kw)
+    return GenerateDescriptor(**base)
+
+
+def test_descriptor_tensors():
+    d = desc()
+    assert d.depth2leaf_probs.tolist() == pytest.approx([0.2] * 4 + [1.0] * 6)
+    assert d.roulette_funcs.tolist() == [0.0, 0.25, 0.5, 0.75] + [1.0] * 25
+    assert d.roulette_bfuncs.tolist() == d.roulette_funcs.tolist() and d.roulette_ufuncs.sum() == 0
+    assert d.const_samples.tolist() == [-1.0, 0.0, 1.0]
+    d2 = d.update(max_layer_cnt=3, layer_leaf_prob=0.5)
+    assert d2.depth2leaf_probs.tolist() == pytest.approx([0.5] * 2 + [1.0] * 8) and d2.max_tree_len == 64
+    w = desc(using_funcs={"+": 3.0, "sin": 1.0})
+    assert w.roulette_funcs[1].item() == pytest.approx(0.75) and w.roulette_funcs[28].item() == pytest.approx(1.0)
+    r = desc(const_samples=None, const_range=(2.0, 3.0), sample_cnt=10)
+    assert r.const_samples.shape == (10,) and (r.const_samples >= 2).all() and (r.const_samples <= 3).all()
+
+
+def test_descriptor_validation():
+    with pytest.raises(AssertionError, match="too small"):
+        desc(max_tree_len=16, max_layer_cnt=5)            # full binary tree of 5 layers needs 31 nodes
+    with pytest.raises(AssertionError, match="too small"):
+        desc(using_funcs=["if", "+"], max_tree_len=64, max_layer_cnt=5)  # ternary: 121 nodes
+    with pytest.raises(AssertionError, match="too large"):
+        desc(max_tree_len=MAX_STACK + 1)
+    with pytest.raises(AssertionError, match="Unknown function"):
+        desc(using_funcs=["+", "frobnicate"])
+    with pytest.raises(AssertionError):
+        desc(const_prob=1.5)
+
+
+def test_forest_container_protocol():
+    f = Forest.random_generate(40, desc(), keys=torch.tensor([3, 4]))
+    assert len(f) == 40 and f.max_tree_len == 64 and isinstance(f[0], Tree)
+    assert len(f[5:15]) == 10 and len(f[torch.tensor([1, 3, 5])]) == 3 and len(f[np.array([0, 1])]) == 2
+    g = f + f[:3] + f[0]
+    assert len(g) == 44
+    f2 = Forest.zero_generate(40, 64, 3, 1)
+    f2[10:20] = f[0:10]
+    assert torch.equal(f2.batch_node_type[10:20], f.batch_node_type[:10])
+    f2[0] = f[39]
+    assert torch.equal(f2.batch_subtree_size[0], f.batch_subtree_size[39])
+    assert sum(1 for _ in f) == 40
+    h = pickle.loads(pickle.dumps(f))
+    assert torch.equal(h.batch_node_value.view(torch.int32), f.batch_node_value.view(torch.int32)) and h.input_len == 3
+    with pytest.raises(Exception):
+        f["x"]
+    assert Forest.zero_generate(2, 8, 1, 1).batch_node_type[:, 0].tolist() == [NType.CONST] * 2
+    assert (randint((1000,), 3, 9) >= 3).all() and (randint((1000,), 3, 9) < 9).all()
+
+
+def test_default_selection_counts_and_order():
+    f = Forest.zero_generate(10, 8, 1, 1)
+    fit = torch.tensor([0.1, 0.9, 0.5, 0.9, -1.0, 0.3, 0.2, 0.8, 0.0, 0.4])
+    elite, surv = DefaultSelection(survival_rate=0.3, elite_cnt=2)(f, fit)
+    assert elite.dtype == torch.int32 and elite.tolist() == [1, 3] and surv.tolist() == [1, 3, 7]  # stable on the tie
+    elite, surv = DefaultSelection(survival_rate=0.5, elite_rate=0.1)(f, fit)
+    assert elite.tolist() == [1] and len(surv) == 5
+    assert DefaultSelection(0.3)(f, fit)[0].numel() == 0
+    with pytest.raises(AssertionError):
+        DefaultSelection(0.3, elite_cnt=1, elite_rate=0.1)
+
+
+def test_crossover_mutation_keep_population_valid_and_sized():
+    from oracle.pyoracle import Oracle
+
+    o = Oracle("port")
+    torch.manual_seed(1)
+    d = desc()
+    f = Forest.random_generate(300, d, keys=torch.tensor([8, 8]))
+    fit = torch.randn(300)
+    algo = GeneticProgramming(f, DefaultCrossover(), DefaultMutation(0.3, d.update(max_layer_cnt=3)), DefaultSelection(0.3, elite_rate=0.02),
+                              enable_pareto_front=True)
+    elites = f[torch.sort(fit, descending=True, stable=True).indices[:6]]
+    nxt = algo.step(fit)
+    assert nxt.pop_size == 300
+    assert torch.equal(nxt.batch_node_type[:6], elites.batch_node_type)  # elites first, unchanged
+    t, s = nxt.batch_node_type.numpy(), nxt.batch_subtree_size.numpy()
+    assert all(o.validate_tree(t[i], s[i]) == 0 for i in range(300))
+    assert (s[:, 0] <= 64).all() and np.isfinite(algo.pareto_front.fitness.numpy()).any()
+    assert DefaultMutation(0.0, d)(nxt) is nxt  # nothing selected: the forest comes back untouched
+
+
+def test_pipeline_xor_improves_on_cpu_ops(capsys):
+    torch.manual_seed(0)
+    X = torch.tensor([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=torch.float32)
+    y = (X.sum(1) % 2)[:, None]
+    prob = SymbolicRegression(datapoints=X, labels=y)
+    assert prob.problem_dim == 3 and prob.solution_dim == 1
+    d = desc()
+    algo = GeneticProgramming(Forest.random_generate(400, d), DefaultCrossover(), DefaultMutation(0.2, d.update(max_layer_cnt=3)),
+                              DefaultSelection(0.3, elite_rate=0.01))
+    pipe = StandardPipeline(algo, prob, generation_limit=8, is_show_details=True)
+    best = pipe.run()
+    assert "Generation: 7" in capsys.readouterr().out
+    assert isinstance(best, Tree) and float(pipe.best_fitness) > -0.5
+    assert best.forward(X).shape == (8, 1) and pipe.fitness.shape == (400,)
+    early = StandardPipeline(algo, prob, fitness_target=-10.0, is_show_details=False)
+    early.run()
+    assert float(early.best_fitness) >= -10.0
+
+
+def test_sr_problem_modes_agree_and_generate_data():
+    torch.manual_seed(0)
+    prob = SymbolicRegression(func=lambda x: x[0] * x[1] - x[2], num_inputs=3, num_data=50, lower_bounds=-2, upper_bounds=2)
+    assert prob.datapoints.shape == (50, 3) and prob.labels.shape == (50, 1)
+    assert torch.allclose(prob.labels[:, 0], prob.datapoints[:, 0] * prob.datapoints[:, 1] - prob.datapoints[:, 2])
+    f = Forest.random_generate(100, desc(), keys=torch.tensor([5, 6]))
+    a = prob.evaluate(f)
+    prob.execute_mode = "torch"
+    b = prob.evaluate(f)
+    ok = torch.isfinite(a) & torch.isfinite(b)
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.allclose(a[ok], b[ok], rtol=1e-4)
+    with pytest.raises(AssertionError):
+        SymbolicRegression(datapoints=prob.datapoints, labels=prob.labels, execute_mode="fast please")
+
+
+def test_tree_views_and_printing():
+    t = Tree(3, 1, node_value=torch.tensor([3., 2., 0., 2., 2., 0., 2., 0.]), node_type=torch.tensor([3, 3, 0, 0, 3, 0, 0, 0], dtype=torch.int16),
+             subtree_size=torch.tensor([7, 3, 1, 1, 3, 1, 1, 0], dtype=torch.int16))
+    assert t.to_infix() == "((x0 - x2) * (x0 - x2))"
+    assert str(t.to_sympy_expr()) in ("(x0 - x2)**2",)
+    assert t.SR_fitness(torch.tensor([[0., 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1]]), torch.tensor([[0.], [1], [1], [0]])).item() == 0.5
+    assert t.forward(torch.tensor([1.0, 0.0, 3.0])).tolist() == [4.0]
+    assert t.to_forest().pop_size == 1

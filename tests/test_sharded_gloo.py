@@ -1,0 +1,86 @@
+"""CPU, world_size = 2 on the gloo backend: the sharded generation step (evogp_amd/parallel.py)
+produces the same population as the single-process run — the N > 1 path of bench.py / multi-GPU
+pipelines, exercised without a GPU (tree ops are served by the test-only oracle-backed CPU ops)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POP, L, GENS = 600, 32, 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(rank, world, port, outdir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_ops
+    cpu_ops.register()
+    from evogp_amd.parallel import ShardedGeneticProgramming
+    from evogp_amd.tree import Forest, GenerateDescriptor, set_default_device
+
+    set_default_device("cpu")
+    desc = GenerateDescriptor(max_tree_len=L, input_len=3, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=4,
+                              const_samples=[-1, 0, 1])
+    n_local = POP // world
+    keys = torch.tensor([42, 0], dtype=torch.int64)
+    local = Forest.random_generate(n_local, desc, keys=keys, tree_index_offset=rank * n_local)
+    X = torch.tensor([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=torch.float32)
+    y = (X.sum(1) % 2)[:, None]
+    gp = ShardedGeneticProgramming(local, 0.2, desc.update(max_layer_cnt=3), seed=123)
+    for _ in range(GENS):
+        fit = -gp.forest.SR_fitness(X, y)
+        fit[torch.isnan(fit)] = -torch.inf
+        gp.step(fit)
+    f = gp.forest
+    np.savez(os.path.join(outdir, f"w{world}_r{rank}.npz"), v=f.batch_node_value.numpy(), t=f.batch_node_type.numpy(),
+             s=f.batch_subtree_size.numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank(tmp_path):
+    out = str(tmp_path)
+    _run(0, 1, _free_port(), out)
+    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    parts = [np.load(os.path.join(out, f"w2_r{r}.npz")) for r in range(2)]
+    for k in ("v", "t", "s"):
+        both = np.concatenate([p[k] for p in parts])
+        a = one[k].view(np.uint32) if k == "v" else one[k]
+        b = both.view(np.uint32) if k == "v" else both
+        assert np.array_equal(a, b), f"sharded population differs in {k}"
+    # the population actually evolved and stayed valid
+    from oracle.pyoracle import Oracle
+    o = Oracle("port")
+    assert all(o.validate_tree(one["t"][i], one["s"][i]) == 0 for i in range(POP))
+
+
+def test_pack_unpack_roundtrip():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops
+    cpu_ops.register()
+    from evogp_amd.parallel import _pack, _unpack
+    from evogp_amd.tree import Forest, GenerateDescriptor, set_default_device
+
+    set_default_device("cpu")
+    desc = GenerateDescriptor(max_tree_len=L, input_len=3, output_len=2, using_funcs=["+", "*", "sin"], max_layer_cnt=4,
+                              const_samples=[-1, 0, 1])
+    f = Forest.random_generate(50, desc, keys=torch.tensor([1, 2]))
+    fit = torch.randn(50)
+    g, fit2 = _unpack(_pack(f, fit), L, 3, 2)
+    assert torch.equal(fit, fit2) and torch.equal(f.batch_node_type, g.batch_node_type)
+    assert torch.equal(f.batch_node_value.view(torch.int32), g.batch_node_value.view(torch.int32))
+    assert torch.equal(f.batch_subtree_size, g.batch_subtree_size)
