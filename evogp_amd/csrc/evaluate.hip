@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void eval_fast_kernel(EvalParams p) {
                 opv = dn.op; payv = dn.pay;
             }
             const int n = len - base < kWave ? len - base : kWave;
-            run_chunk<MO, 1, kEvalDepth, VL>(opv, payv, n, st, vars, outs);
+            run_chunk<MO, false, 1, kEvalDepth, VL>(opv, payv, n, st, vars, outs);
         }
         if (!MO) {
             if (lane == 0) res[0] = st.tos[0];

@@ -25,7 +25,16 @@ namespace evogp {
 
 typedef float v32f __attribute__((ext_vector_type(32)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v12f __attribute__((ext_vector_type(12)));
+typedef float v10f __attribute__((ext_vector_type(10)));
+typedef float v9f __attribute__((ext_vector_type(9)));
+// Register-tuple widths with a uniform dynamic index: 9..12, 16 and 32 dwords are lowered to
+// s_set_gpr_idx_on + v_mov (vectors of <= 8 elements are expanded into compare/select chains by the
+// back end, which is slower), so 9 is the smallest width used.
 template <int N> struct VecOf;
+template <> struct VecOf<9> { using type = v9f; };
+template <> struct VecOf<10> { using type = v10f; };
+template <> struct VecOf<12> { using type = v12f; };
 template <> struct VecOf<16> { using type = v16f; };
 template <> struct VecOf<32> { using type = v32f; };
 
@@ -47,7 +56,15 @@ struct Decoded {
     uint32_t op;   // handler id
     uint32_t pay;  // CONST: value bits; VAR: variable index; function: output index or kNoOut
     int delta;     // change of stack height: 1 - arity
+    bool heavy;    // transcendental / pow: only the FULL interpreter build carries these handlers
 };
+
+// Functions with long library expansions (range reduction, pow).  The LEAN interpreter build leaves
+// them out so that its register budget and code size stay small; trees using them are routed to the
+// FULL build.
+__device__ inline bool is_heavy_func(uint32_t f) {
+    return (f >= (uint32_t)F_SIN && f <= (uint32_t)F_EXP) || f == (uint32_t)F_POW || f == (uint32_t)F_LOOSE_POW;
+}
 
 // Pre-decode one node (forward.cu:86-115 for the type/value unpacking).  `multi` selects the
 // multi-output conventions (type masked, OUT flag honoured); in single-output mode the raw type
@@ -57,6 +74,7 @@ __device__ inline Decoded decode_node(int type, float value, bool multi, int var
     bool is_out = false;
     if (multi) { is_out = (type & T_OUT) != 0; type &= T_MASK; }
     d.pay = kNoOut;
+    d.heavy = false;
     if (type == T_CONST) { d.op = H_CONST; d.pay = f2bits(value); d.delta = 1; return d; }
     if (type == T_VAR) {
         int v = (int)value;
@@ -72,11 +90,13 @@ __device__ inline Decoded decode_node(int type, float value, bool multi, int var
     }
     if (type == T_UFUNC) {
         d.op = (f >= (uint32_t)F_SIN && f <= (uint32_t)F_LOOSE_SQRT) ? H_UN + (f - F_SIN) : H_UN_ZERO;
+        d.heavy = d.op != H_UN_ZERO && is_heavy_func(f);
         d.delta = 0;
     } else if (type == T_BFUNC) {
         if (f >= (uint32_t)F_ADD && f <= (uint32_t)F_DIV) d.op = H_ADD + (f - F_ADD);
         else if (f >= (uint32_t)F_LOOSE_DIV && f <= (uint32_t)F_GE) d.op = H_BIN_OTHER + (f - F_LOOSE_DIV);
         else d.op = H_BIN_ZERO;
+        d.heavy = d.op != H_BIN_ZERO && is_heavy_func(f);
         d.delta = -1;
     } else {
         d.op = H_IF; d.delta = -2;
@@ -85,40 +105,52 @@ __device__ inline Decoded decode_node(int type, float value, bool multi, int var
 }
 
 // ---- node arithmetic (forward.cu:125-224) ------------------------------------------------------
+// LEAN builds omit the heavy functions (their trees never reach a LEAN interpreter).
+template <bool LEAN>
 __device__ inline float op_unary(uint32_t h, float a) {
     switch (h) {
-    case H_UN + (F_SIN - F_SIN): return sinf(a);
-    case H_UN + (F_COS - F_SIN): return cosf(a);
-    case H_UN + (F_TAN - F_SIN): return tanf(a);
-    case H_UN + (F_SINH - F_SIN): return sinhf(a);
-    case H_UN + (F_COSH - F_SIN): return coshf(a);
-    case H_UN + (F_TANH - F_SIN): return tanhf(a);
-    case H_UN + (F_LOG - F_SIN): return logf(a);
-    case H_UN + (F_LOOSE_LOG - F_SIN): return a == 0.0f ? -kMaxVal : logf(fabsf(a));
-    case H_UN + (F_EXP - F_SIN): return expf(a);
     case H_UN + (F_INV - F_SIN): return a == 0.0f ? __builtin_nanf("") : 1.0f / a;
     case H_UN + (F_LOOSE_INV - F_SIN): { const float d = fabsf(a) <= kDelta ? copysignf(kDelta, a) : a; return 1.0f / d; }
     case H_UN + (F_NEG - F_SIN): return -a;
     case H_UN + (F_ABS - F_SIN): return fabsf(a);
     case H_UN + (F_SQRT - F_SIN): return sqrtf(a);
     case H_UN + (F_LOOSE_SQRT - F_SIN): return sqrtf(fabsf(a));
-    default: return 0.0f; // unknown ids leave the zero-initialised result (forward.cu:117)
+    default: break;
     }
+    if (!LEAN) {
+        switch (h) {
+        case H_UN + (F_SIN - F_SIN): return sinf(a);
+        case H_UN + (F_COS - F_SIN): return cosf(a);
+        case H_UN + (F_TAN - F_SIN): return tanf(a);
+        case H_UN + (F_SINH - F_SIN): return sinhf(a);
+        case H_UN + (F_COSH - F_SIN): return coshf(a);
+        case H_UN + (F_TANH - F_SIN): return tanhf(a);
+        case H_UN + (F_LOG - F_SIN): return logf(a);
+        case H_UN + (F_LOOSE_LOG - F_SIN): return a == 0.0f ? -kMaxVal : logf(fabsf(a));
+        case H_UN + (F_EXP - F_SIN): return expf(a);
+        default: break;
+        }
+    }
+    return 0.0f; // unknown ids leave the zero-initialised result (forward.cu:117)
 }
 
+template <bool LEAN>
 __device__ inline float op_binary_other(uint32_t h, float a, float b) {
     switch (h) {
     case H_BIN_OTHER + (F_LOOSE_DIV - F_LOOSE_DIV): { const float d = fabsf(b) <= kDelta ? copysignf(kDelta, b) : b; return a / d; }
-    case H_BIN_OTHER + (F_POW - F_LOOSE_DIV): return powf(a, b);
-    case H_BIN_OTHER + (F_LOOSE_POW - F_LOOSE_DIV): return (a == 0.0f && b == 0.0f) ? 0.0f : powf(fabsf(a), b);
     case H_BIN_OTHER + (F_MAX - F_LOOSE_DIV): return a >= b ? a : b;
     case H_BIN_OTHER + (F_MIN - F_LOOSE_DIV): return a <= b ? a : b;
     case H_BIN_OTHER + (F_LT - F_LOOSE_DIV): return a < b ? 1.0f : -1.0f;
     case H_BIN_OTHER + (F_GT - F_LOOSE_DIV): return a > b ? 1.0f : -1.0f;
     case H_BIN_OTHER + (F_LE - F_LOOSE_DIV): return a <= b ? 1.0f : -1.0f;
     case H_BIN_OTHER + (F_GE - F_LOOSE_DIV): return a >= b ? 1.0f : -1.0f;
-    default: return 0.0f;
+    default: break;
     }
+    if (!LEAN) {
+        if (h == H_BIN_OTHER + (F_POW - F_LOOSE_DIV)) return powf(a, b);
+        if (h == H_BIN_OTHER + (F_LOOSE_POW - F_LOOSE_DIV)) return (a == 0.0f && b == 0.0f) ? 0.0f : powf(fabsf(a), b);
+    }
+    return 0.0f;
 }
 
 // Operand stack in registers for K input rows per lane.  Height h counts the elements; the top
@@ -133,14 +165,20 @@ struct RegStack {
 
 // Execute `n` pre-decoded instructions held one per lane in (opv, payv), lanes 0..n-1 in
 // execution order.  vars[k] holds input row k of this lane; outs[k] the multi-output accumulators.
-template <bool MO, int K, int DEPTH, int VL>
+// The opcode of the NEXT instruction is fetched (v_readlane) before the current one is dispatched,
+// so the VALU->SGPR latency of the fetch overlaps the handler; the payload is only fetched by the
+// handlers that use it.
+template <bool MO, bool LEAN, int K, int DEPTH, int VL>
 __device__ inline void run_chunk(uint32_t opv, uint32_t payv, int n, RegStack<K, DEPTH> &st,
                                  const typename VecOf<VL>::type (&vars)[K], v16f (&outs)[K]) {
+    uint32_t next_op = (uint32_t)__builtin_amdgcn_readlane((int)opv, 0);
     for (int j = 0; j < n; ++j) {
-        const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)opv, j);
-        const uint32_t pay = (uint32_t)__builtin_amdgcn_readlane((int)payv, j);
+        const uint32_t op = next_op;
+        next_op = (uint32_t)__builtin_amdgcn_readlane((int)opv, (j + 1) & 63);
         if (op < H_ADD) { // leaf: push
+            const uint32_t pay = (uint32_t)__builtin_amdgcn_readlane((int)payv, j);
             const int h = st.h;
+            st.h = h + 1;
 #pragma unroll
             for (int k = 0; k < K; ++k) st.s[k][h] = st.tos[k];
             if (op == H_CONST) {
@@ -150,93 +188,112 @@ __device__ inline void run_chunk(uint32_t opv, uint32_t payv, int n, RegStack<K,
 #pragma unroll
                 for (int k = 0; k < K; ++k) st.tos[k] = vars[k][pay];
             }
-            st.h = h + 1;
-            continue;
-        }
-        float r[K], last[K];
-        if (op < H_UN) { // binary: a = top (left operand), b = next (right operand)
+        } else if (op < H_UN) { // binary: a = top (left operand), b = next (right operand)
             const int h = st.h - 1;
+            st.h = h;
             float b[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) b[k] = st.s[k][h];
-            st.h = h;
-            if (op < H_MUL) {
+            if (MO) {
+                const uint32_t pay = (uint32_t)__builtin_amdgcn_readlane((int)payv, j);
+                if (pay != kNoOut) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float a = st.tos[k];
+                        const float r = op == H_ADD ? a + b[k] : op == H_SUB ? a - b[k] : op == H_MUL ? a * b[k]
+                                        : op == H_DIV ? (b[k] == 0.0f ? __builtin_nanf("") : a / b[k])
+                                                      : op_binary_other<LEAN>(op, a, b[k]);
+                        outs[k][pay] += r;
+                    }
+                }
+                // every function node hands its LAST popped operand to its parent (forward.cu:237-243)
+#pragma unroll
+                for (int k = 0; k < K; ++k) st.tos[k] = b[k];
+            } else if (op < H_MUL) {
                 if (op == H_ADD) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) r[k] = st.tos[k] + b[k];
+                    for (int k = 0; k < K; ++k) st.tos[k] = st.tos[k] + b[k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) r[k] = st.tos[k] - b[k];
+                    for (int k = 0; k < K; ++k) st.tos[k] = st.tos[k] - b[k];
                 }
             } else if (op < H_BIN_OTHER) {
                 if (op == H_MUL) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) r[k] = st.tos[k] * b[k];
+                    for (int k = 0; k < K; ++k) st.tos[k] = st.tos[k] * b[k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) r[k] = b[k] == 0.0f ? __builtin_nanf("") : st.tos[k] / b[k];
+                    for (int k = 0; k < K; ++k) st.tos[k] = b[k] == 0.0f ? __builtin_nanf("") : st.tos[k] / b[k];
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < K; ++k) r[k] = op_binary_other(op, st.tos[k], b[k]);
+                for (int k = 0; k < K; ++k) st.tos[k] = op_binary_other<LEAN>(op, st.tos[k], b[k]);
             }
-#pragma unroll
-            for (int k = 0; k < K; ++k) last[k] = b[k];
         } else if (op < H_IF) { // unary
+            if (MO) {
+                const uint32_t pay = (uint32_t)__builtin_amdgcn_readlane((int)payv, j);
+                if (pay != kNoOut) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) { last[k] = st.tos[k]; r[k] = op_unary(op, st.tos[k]); }
+                    for (int k = 0; k < K; ++k) outs[k][pay] += op_unary<LEAN>(op, st.tos[k]);
+                }
+                // tos stays: the operand itself is handed to the parent
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) st.tos[k] = op_unary<LEAN>(op, st.tos[k]);
+            }
         } else { // ternary IF: cond = top, then = next, else = third
             const int h = st.h - 2;
+            st.h = h;
+            uint32_t pay = kNoOut;
+            if (MO) pay = (uint32_t)__builtin_amdgcn_readlane((int)payv, j);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float b = st.s[k][h + 1], c = st.s[k][h];
-                r[k] = st.tos[k] > 0.0f ? b : c;
-                last[k] = c;
+                const float r = st.tos[k] > 0.0f ? b : c;
+                if (MO) {
+                    if (pay != kNoOut) outs[k][pay] += r;
+                    st.tos[k] = c;
+                } else {
+                    st.tos[k] = r;
+                }
             }
-            st.h = h;
         }
-        if (MO) {
-            // every function node hands its LAST popped operand to its parent; OUT nodes add their
-            // value to an output accumulator (forward.cu:237-243)
-            if (pay != kNoOut) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) outs[k][pay] += r[k];
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) r[k] = last[k];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) st.tos[k] = r[k];
     }
 }
 
 // Result of the structural pre-pass over one tree.
-enum TreeClass : int { TREE_OK = 0, TREE_DEEP = 1, TREE_BAD = 2 };
+enum TreeClass : int { TREE_OK = 0, TREE_DEEP = 1, TREE_BAD = 2, TREE_HEAVY = 3, TREE_SKIP = 4 };
 
 // Classify a tree: walk it in chunks of 64 nodes in execution (reverse prefix) order, prefix-sum
 // the stack-height deltas, and check 1 <= height everywhere, final height == 1, and the maximum
 // height against the register stack.  type/value point at the tree's row; len is already clamped.
-// Returns TreeClass; *height_out receives the maximum operand-stack height.
+// Returns TREE_BAD (malformed), TREE_HEAVY (uses a function the LEAN build lacks; only when
+// `lean`), TREE_DEEP (operand stack > max_height) or TREE_OK.
 __device__ inline int classify_tree(const int16_t *__restrict__ type, const float *__restrict__ value, int len,
-                                    bool multi, int var_len, int out_len, int max_height, int *height_out = nullptr) {
+                                    bool multi, int var_len, int out_len, int max_height, bool lean = false) {
     if (len <= 0) return TREE_BAD;
     const int lane = threadIdx.x & 63;
     int carry = 0, hmax = 0, hmin = 1;
+    bool heavy = false;
     for (int base = 0; base < len; base += kWave) {
         const int r = base + lane;
         int delta = 0;
         if (r < len) {
             const int i = len - 1 - r;
-            delta = decode_node(type[i], value[i], multi, var_len, out_len).delta;
+            const Decoded d = decode_node(type[i], value[i], multi, var_len, out_len);
+            delta = d.delta;
+            heavy |= d.heavy;
         }
         const int hh = carry + wave_scan_incl(delta);
         const int hv = r < len ? hh : 1;
-        hmax = max(hmax, wave_max(hv));
-        hmin = min(hmin, -wave_max(-hv));
+        hmax = max(hmax, hv);
+        hmin = min(hmin, hv);
         carry = __shfl(hh, 63, 64);
     }
-    if (height_out) *height_out = hmax;
+    hmax = wave_max(hmax);
+    hmin = -wave_max(-hmin);
     if (hmin < 1 || carry != 1) return TREE_BAD;
+    if (lean && __any(heavy)) return TREE_HEAVY;
     return hmax > max_height ? TREE_DEEP : TREE_OK;
 }
 
@@ -266,11 +323,11 @@ __device__ inline float run_general(const int16_t *__restrict__ type, const floa
             else if (op == H_SUB) r = a - b;
             else if (op == H_MUL) r = a * b;
             else if (op == H_DIV) r = b == 0.0f ? __builtin_nanf("") : a / b;
-            else r = op_binary_other(op, a, b);
+            else r = op_binary_other<false>(op, a, b);
             last = b;
         } else if (op < H_IF) {
             const float a = stk[--h];
-            r = op_unary(op, a);
+            r = op_unary<false>(op, a);
             last = a;
         } else {
             const float a = stk[h - 1], b = stk[h - 2], c = stk[h - 3];

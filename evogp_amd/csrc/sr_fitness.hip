@@ -37,7 +37,8 @@
 
 namespace evogp {
 
-constexpr uint32_t kSentinelDeep = 0x7FC0DEEDu; // quiet-NaN payload: "evaluate me in the general kernel"
+constexpr uint32_t kSentinelDeep = 0x7FC0DEEDu;  // quiet-NaN payload: "evaluate me in the general kernel"
+constexpr uint32_t kSentinelHeavy = 0x7FC0FEEDu; // quiet-NaN payload: "evaluate me in the FULL register kernel"
 constexpr int kMaxBatch = 64;                    // trees per batch (LDS partial-sum slots)
 constexpr int kMaxWaves = 16;
 
@@ -54,14 +55,20 @@ struct SrParams {
     int use_mse;
     int batch;       // trees per batch, <= kMaxBatch
     int ntiles;      // ceil(D / (64*K))
+    int only_marked; // != 0: only trees whose output word holds kSentinelHeavy are evaluated
 };
 
 __device__ inline float err_term(float diff, int use_mse) { return use_mse ? diff * diff : fabsf(diff); }
 
 // K rows per lane, DEPTH-entry register stack, VL variable registers, MO = multi-output,
 // MAXW = waves per workgroup the launch bound allows.
-template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE>
-__global__ __launch_bounds__(MAXW * 64) void sr_fast_kernel(SrParams p) {
+// The LEAN build is held to 128 VGPRs (4 resident waves per SIMD): the interpreter is latency bound,
+// throughput scales with K x resident waves.
+#ifndef EVOGP_LEAN_WAVES
+#define EVOGP_LEAN_WAVES 4
+#endif
+template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE, bool LEAN>
+__global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEAN_WAVES : 1) void sr_fast_kernel(SrParams p) {
     __shared__ float part[2][kMaxBatch][kMaxWaves]; // per-tree partial sums, double-buffered by batch parity
     __shared__ int cls_s[2][kMaxBatch];
     __shared__ int next_s[2];
@@ -105,7 +112,10 @@ __global__ __launch_bounds__(MAXW * 64) void sr_fast_kernel(SrParams p) {
             const size_t row = (size_t)(t0 + b) * p.gp_len;
             int len = uni((int)p.size[row]);
             len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
-            const int c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH);
+            int c;
+            const float *mark = STORE ? p.results + (size_t)(t0 + b) * p.D * p.out_len : p.fitness + (t0 + b);
+            if (p.only_marked && uni(f2bits(*mark)) != kSentinelHeavy) c = TREE_SKIP;
+            else c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH, LEAN);
             if (lane == 0) cls_s[par][b] = c;
         }
         __syncthreads();
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(MAXW * 64) void sr_fast_kernel(SrParams p) {
                         opv = dn.op; payv = dn.pay;
                     }
                     const int n = len - base < kWave ? len - base : kWave;
-                    run_chunk<MO, K, DEPTH, VL>(opv, payv, n, st, vars, outs);
+                    run_chunk<MO, LEAN, K, DEPTH, VL>(opv, payv, n, st, vars, outs);
                 }
                 if (STORE) {
 #pragma unroll
@@ -196,9 +206,12 @@ __global__ __launch_bounds__(MAXW * 64) void sr_fast_kernel(SrParams p) {
 
         // ---- phase 3: one thread per tree adds the tile partials in tile order ----
         if (STORE) {
-            if ((int)threadIdx.x < nb && cls_s[par][threadIdx.x] == TREE_DEEP)
-                p.results[(size_t)(t0 + threadIdx.x) * p.D * p.out_len] = bits2f(kSentinelDeep);
-        } else if ((int)threadIdx.x < nb) {
+            if ((int)threadIdx.x < nb) {
+                const int c = cls_s[par][threadIdx.x];
+                if (c == TREE_DEEP || c == TREE_HEAVY)
+                    p.results[(size_t)(t0 + threadIdx.x) * p.D * p.out_len] = bits2f(c == TREE_DEEP ? kSentinelDeep : kSentinelHeavy);
+            }
+        } else if ((int)threadIdx.x < nb && cls_s[par][threadIdx.x] != TREE_SKIP) {
             const int b = threadIdx.x;
             const int c = cls_s[par][b];
             float f;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(MAXW * 64) void sr_fast_kernel(SrParams p) {
                 for (int i = 0; i < nw; ++i) s += part[par][b][i];
                 f = s / (float)p.D;
             } else {
-                f = c == TREE_DEEP ? bits2f(kSentinelDeep) : __builtin_nanf("");
+                f = c == TREE_DEEP ? bits2f(kSentinelDeep) : c == TREE_HEAVY ? bits2f(kSentinelHeavy) : __builtin_nanf("");
             }
             p.fitness[t0 + b] = f;
         }
@@ -269,16 +282,21 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
 }
 
 // ---- host side -----------------------------------------------------------------------------------
-template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE>
-static hipError_t launch_fast(SrParams p, hipStream_t stream) {
-    auto kern = sr_fast_kernel<K, DEPTH, VL, MO, MAXW, STORE>;
+template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE, bool LEAN>
+static hipError_t launch_fast(SrParams p, int only_marked, hipStream_t stream) {
+    auto kern = sr_fast_kernel<K, DEPTH, VL, MO, MAXW, STORE, LEAN>;
     const DeviceInfo &dev = device_info();
     p.ntiles = (p.D + 64 * K - 1) / (64 * K);
+    p.only_marked = only_marked;
     const int W = p.ntiles < MAXW ? p.ntiles : MAXW;
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, W * 64, 0);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    static int per_cu_cache[kMaxWaves + 1] = {0}; // occupancy per block size of THIS instantiation
+    int per_cu = per_cu_cache[W];
+    if (per_cu == 0) {
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, W * 64, 0);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        per_cu_cache[W] = per_cu;
+    }
     long blocks = (long)dev.num_cus * per_cu;
     // batch size: ~16 batches per workgroup keeps the tail short and the atomics rare
     long batch = p.pop / (blocks * 16);
@@ -290,18 +308,19 @@ static hipError_t launch_fast(SrParams p, hipStream_t stream) {
     p.batch = (int)batch;
     const long need = (p.pop + batch - 1) / batch;
     if (blocks > need) blocks = need;
+    hipError_t e;
     p.counter = acquire_counter(stream, &e);
     if (!p.counter) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), 0, stream, p);
     return hipGetLastError();
 }
 
-template <int K, int DEPTH, int MAXW, bool STORE>
-static hipError_t launch_fast_vl(const SrParams &p, hipStream_t stream) {
-    const bool mo = p.out_len > 1;
-    if (p.var_len <= 16)
-        return mo ? launch_fast<K, DEPTH, 16, true, MAXW, STORE>(p, stream) : launch_fast<K, DEPTH, 16, false, MAXW, STORE>(p, stream);
-    return mo ? launch_fast<K, DEPTH, 32, true, MAXW, STORE>(p, stream) : launch_fast<K, DEPTH, 32, false, MAXW, STORE>(p, stream);
+// LEAN pass over every tree, then the FULL build over the trees the lean pass marked heavy.
+template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE>
+static hipError_t launch_pair(const SrParams &p, hipStream_t stream) {
+    hipError_t e = launch_fast<K, DEPTH, VL, MO, MAXW, STORE, true>(p, 0, stream);
+    if (e != hipSuccess) return e;
+    return launch_fast<K, DEPTH, VL, MO, MAXW, STORE, false>(p, 1, stream);
 }
 
 template <bool STORE>
@@ -314,21 +333,29 @@ static hipError_t launch_general(const SrParams &p, int only_marked, hipStream_t
     return hipGetLastError();
 }
 
+// Configurations (chosen from the sweep in profiles/: throughput ~ K x resident waves):
+//   single output, D >= 256 : K = 4 rows per lane, 16-entry stack, variable registers sized to var_len
+//   multi output,  D >= 128 : K = 2 (16 output accumulators per row live in registers as well)
+//   small datasets          : K = 1, 32-entry stack
 template <bool STORE>
-static int run_population(SrParams p, hipStream_t stream) {
+static int run_population(const SrParams &p, hipStream_t stream) {
     const bool fast_ok = p.var_len <= 32 && p.out_len <= kMaxOutRegs && !getenv("EVOGP_SR_FORCE_GENERAL");
     if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
-
-    int k = EVOGP_SR_DEFAULT_K, depth = EVOGP_SR_DEFAULT_DEPTH;
-    if (const char *e = getenv("EVOGP_SR_K")) k = atoi(e);
-    if (const char *e = getenv("EVOGP_SR_DEPTH")) depth = atoi(e);
-    // K rows per lane only pays when a tile is full; tiny datasets use fewer rows per lane
-    while (k > 1 && p.D < 64 * k) k >>= 1;
-    if (p.out_len > 1 && k > 2) k = 2; // 16 output accumulators per row: keep the register budget
+    const bool mo = p.out_len > 1;
     hipError_t e;
-    if (k >= 4) e = depth <= 16 ? launch_fast_vl<4, 16, 4, STORE>(p, stream) : launch_fast_vl<4, 32, 4, STORE>(p, stream);
-    else if (k == 2) e = depth <= 16 ? launch_fast_vl<2, 16, 8, STORE>(p, stream) : launch_fast_vl<2, 32, 8, STORE>(p, stream);
-    else e = depth <= 16 ? launch_fast_vl<1, 16, 16, STORE>(p, stream) : launch_fast_vl<1, 32, 16, STORE>(p, stream);
+    if (!mo && p.D >= 256) {
+        if (p.var_len <= 9) e = launch_pair<4, 16, 9, false, 4, STORE>(p, stream);
+        else if (p.var_len <= 10) e = launch_pair<4, 16, 10, false, 4, STORE>(p, stream);
+        else if (p.var_len <= 12) e = launch_pair<4, 16, 12, false, 4, STORE>(p, stream);
+        else if (p.var_len <= 16) e = launch_pair<4, 16, 16, false, 4, STORE>(p, stream);
+        else e = launch_pair<4, 16, 32, false, 4, STORE>(p, stream);
+    } else if (mo && p.D >= 128) {
+        e = p.var_len <= 16 ? launch_pair<2, 16, 16, true, 8, STORE>(p, stream) : launch_pair<2, 16, 32, true, 8, STORE>(p, stream);
+    } else if (!mo) {
+        e = p.var_len <= 16 ? launch_pair<1, 32, 16, false, 16, STORE>(p, stream) : launch_pair<1, 32, 32, false, 16, STORE>(p, stream);
+    } else {
+        e = p.var_len <= 16 ? launch_pair<1, 32, 16, true, 16, STORE>(p, stream) : launch_pair<1, 32, 32, true, 16, STORE>(p, stream);
+    }
     if (e != hipSuccess) return (int)e;
     return (int)launch_general<STORE>(p, 1, stream);
 }

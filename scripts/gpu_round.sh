@@ -16,6 +16,7 @@ if [ "$MODE" != "benchonly" ]; then
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/01_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/01_pytest_gpu.log
 fi
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/02_bench.log 2>&1; echo "bench rc=$?" >> $OUT/02_bench.log
+if [ "$MODE" = "quick" ]; then ls -la $OUT; exit 0; fi
 {
 for K in 1 2 4; do for DEP in 16 32; do
   echo "== K=$K DEPTH=$DEP"; EVOGP_SR_K=$K EVOGP_SR_DEPTH=$DEP timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline
