@@ -18,7 +18,17 @@ from evogp_amd.pipeline import StandardPipeline  # noqa: E402
 from evogp_amd.problem import SymbolicRegression  # noqa: E402
 from evogp_amd.tree import MAX_STACK, Forest, GenerateDescriptor, NType, Tree, randint, set_default_device  # noqa: E402
 
-set_default_device("cpu")
+from evogp_amd.tree import utils as _tree_utils  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _cpu_default_device():
+    """These tests run the host logic on CPU tensors; restore the device afterwards so that GPU tests
+    collected in the same session are unaffected."""
+    saved = _tree_utils._DEVICE
+    set_default_device("cpu")
+    yield
+    _tree_utils._DEVICE = saved
 
 
 def desc(**kw):

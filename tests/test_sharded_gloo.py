@@ -53,7 +53,7 @@ def _run(rank, world, port, outdir):
 
 def test_two_ranks_equal_one_rank(tmp_path):
     out = str(tmp_path)
-    _run(0, 1, _free_port(), out)
+    mp.spawn(_run, args=(1, _free_port(), out), nprocs=1, join=True)  # separate process: leaves this one's state alone
     mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
     one = np.load(os.path.join(out, "w1_r0.npz"))
     parts = [np.load(os.path.join(out, f"w2_r{r}.npz")) for r in range(2)]
@@ -74,7 +74,16 @@ def test_pack_unpack_roundtrip():
     cpu_ops.register()
     from evogp_amd.parallel import _pack, _unpack
     from evogp_amd.tree import Forest, GenerateDescriptor, set_default_device
+    from evogp_amd.tree import utils as tree_utils
 
+    saved = tree_utils._DEVICE
+    try:
+        _roundtrip(Forest, GenerateDescriptor, set_default_device, _pack, _unpack)
+    finally:
+        tree_utils._DEVICE = saved
+
+
+def _roundtrip(Forest, GenerateDescriptor, set_default_device, _pack, _unpack):
     set_default_device("cpu")
     desc = GenerateDescriptor(max_tree_len=L, input_len=3, output_len=2, using_funcs=["+", "*", "sin"], max_layer_cnt=4,
                               const_samples=[-1, 0, 1])
