@@ -267,10 +267,11 @@ enum TreeClass : int { TREE_OK = 0, TREE_DEEP = 1, TREE_BAD = 2, TREE_HEAVY = 3,
 // Classify a tree: walk it in chunks of 64 nodes in execution (reverse prefix) order, prefix-sum
 // the stack-height deltas, and check 1 <= height everywhere, final height == 1, and the maximum
 // height against the register stack.  type/value point at the tree's row; len is already clamped.
-// Returns TREE_BAD (malformed), TREE_HEAVY (uses a function the LEAN build lacks; only when
-// `lean`), TREE_DEEP (operand stack > max_height) or TREE_OK.
+// Returns TREE_BAD (malformed), TREE_HEAVY (uses a function this interpreter build lacks:
+// lean = 1 -> transcendental/pow, lean = 2 -> anything but leaves and + - * /), TREE_DEEP (operand
+// stack > max_height) or TREE_OK.
 __device__ inline int classify_tree(const int16_t *__restrict__ type, const float *__restrict__ value, int len,
-                                    bool multi, int var_len, int out_len, int max_height, bool lean = false) {
+                                    bool multi, int var_len, int out_len, int max_height, int lean = 0) {
     if (len <= 0) return TREE_BAD;
     const int lane = threadIdx.x & 63;
     int carry = 0, hmax = 0, hmin = 1;
@@ -282,7 +283,7 @@ __device__ inline int classify_tree(const int16_t *__restrict__ type, const floa
             const int i = len - 1 - r;
             const Decoded d = decode_node(type[i], value[i], multi, var_len, out_len);
             delta = d.delta;
-            heavy |= d.heavy;
+            heavy |= lean == 2 ? d.op > H_DIV : d.heavy;
         }
         const int hh = carry + wave_scan_incl(delta);
         const int hv = r < len ? hh : 1;
@@ -293,7 +294,7 @@ __device__ inline int classify_tree(const int16_t *__restrict__ type, const floa
     hmax = wave_max(hmax);
     hmin = -wave_max(-hmin);
     if (hmin < 1 || carry != 1) return TREE_BAD;
-    if (lean && __any(heavy)) return TREE_HEAVY;
+    if (lean != 0 && __any(heavy)) return TREE_HEAVY;
     return hmax > max_height ? TREE_DEEP : TREE_OK;
 }
 

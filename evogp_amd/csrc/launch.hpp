@@ -8,6 +8,9 @@
 #ifndef EVOGP_SR_DEFAULT_K
 #define EVOGP_SR_DEFAULT_K 4
 #endif
+#ifndef EVOGP_SR_DEFAULT_ASM
+#define EVOGP_SR_DEFAULT_ASM 12
+#endif
 #ifndef EVOGP_SR_DEFAULT_DEPTH
 #define EVOGP_SR_DEFAULT_DEPTH 16
 #endif

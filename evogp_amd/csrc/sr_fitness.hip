@@ -115,7 +115,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
             int c;
             const float *mark = STORE ? p.results + (size_t)(t0 + b) * p.D * p.out_len : p.fitness + (t0 + b);
             if (p.only_marked && uni(f2bits(*mark)) != kSentinelHeavy) c = TREE_SKIP;
-            else c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH, LEAN);
+            else c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH, LEAN ? 1 : 0);
             if (lane == 0) cls_s[par][b] = c;
         }
         __syncthreads();
@@ -229,6 +229,135 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     }
 }
 
+// ---- threaded-code build -------------------------------------------------------------------------
+// Same skeleton as sr_fast_kernel (tile-resident waves, batches from an atomic counter, classify /
+// interpret / finalise phases) for the configuration the headline benchmark runs: single output,
+// K = 4 rows per lane, trees of at most 63 nodes made of leaves and + - * /.  The interpreter core is
+// the hand-written gfx950 block generated by gen/gen_interp_asm.py: jump-table dispatch on a
+// pre-decoded handler offset, one taken jump per node.  Everything else — trees with other
+// functions, deeper stacks, longer rows — is marked for the FULL register build / the general kernel.
+#include "interp_asm_d12.inc"
+#include "interp_asm_d16.inc"
+
+constexpr int kAsmStride = 512;  // bytes per handler slot (gen_interp_asm.py)
+constexpr int kAsmEnd = 6;       // index of the END handler
+
+template <int DEPTH, int VLA, bool STORE>
+__global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
+    // [wave][VLA][64 lanes] float4 = the four rows of a lane, per variable (static and first, so that the
+    // ds_read_b128 addresses are 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) float4 xs[4 * VLA * kWave];
+    __shared__ float part[2][kMaxBatch][4];
+    __shared__ int cls_s[2][kMaxBatch];
+    __shared__ int next_s[2];
+
+    constexpr int TILE = kWave * 4;
+    const int lane = threadIdx.x & 63;
+    const int w = uni((int)(threadIdx.x >> 6));
+    const int W = blockDim.x >> 6;  // == ntiles (the launcher only takes this path when D <= 256 * 4)
+
+    int d[4], dc[4];
+    float yv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d[k] = w * TILE + k * kWave + lane;
+        dc[k] = d[k] < p.D ? d[k] : p.D - 1;
+        yv[k] = STORE ? 0.0f : p.y[dc[k]];
+    }
+    // stage this wave's tile, transposed so that one ds_read_b128 per variable fills the lane's rows
+    for (int v = 0; v < VLA; ++v) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < p.var_len) {
+            q.x = p.X[(size_t)dc[0] * p.var_len + v]; q.y = p.X[(size_t)dc[1] * p.var_len + v];
+            q.z = p.X[(size_t)dc[2] * p.var_len + v]; q.w = p.X[(size_t)dc[3] * p.var_len + v];
+        }
+        xs[(w * VLA + v) * kWave + lane] = q;
+    }
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(&xs[(w * VLA) * kWave + lane]);
+
+    if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)p.batch);
+    __syncthreads();
+    int par = 0;
+#pragma nounroll
+    for (;;) {
+        const int t0 = uni(next_s[par]);
+        if (t0 >= p.pop) break;
+        const int nb = p.pop - t0 < p.batch ? p.pop - t0 : p.batch;
+        if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)p.batch);
+
+        for (int b = w; b < nb; b += W) {
+            const size_t row = (size_t)(t0 + b) * p.gp_len;
+            int len = uni((int)p.size[row]);
+            len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
+            int c = classify_tree(p.type + row, p.value + row, len, false, p.var_len, p.out_len, DEPTH, 2);
+            if (c == TREE_OK && len > 63) c = TREE_HEAVY; // one program register: 63 instructions + END
+            if (lane == 0) cls_s[par][b] = c;
+        }
+        __syncthreads();
+
+#pragma nounroll
+        for (int b = 0; b < nb; ++b) {
+            const int cls_b = uni(cls_s[par][b]);
+            if (cls_b != TREE_OK) {
+                if (STORE && cls_b == TREE_BAD) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (d[k] < p.D) p.results[(size_t)(t0 + b) * p.D + d[k]] = __builtin_nanf("");
+                }
+                continue;
+            }
+            const size_t row = (size_t)(t0 + b) * p.gp_len;
+            const int len = uni((int)p.size[row]);
+            uint32_t opv = kAsmEnd * kAsmStride, payv = 0;
+            if (lane < len) {
+                const int i = len - 1 - lane;
+                const Decoded dn = decode_node(p.type[row + i], p.value[row + i], false, p.var_len, p.out_len);
+                opv = dn.op * kAsmStride;
+                payv = dn.op == H_VAR ? dn.pay * 4u : dn.pay;
+            }
+            float r0, r1, r2, r3;
+            if (DEPTH == 12) { EVOGP_INTERP_ASM_D12(r0, r1, r2, r3, opv, payv, lds_addr); }
+            else { EVOGP_INTERP_ASM_D16(r0, r1, r2, r3, opv, payv, lds_addr); }
+            const float r[4] = {r0, r1, r2, r3};
+            if (STORE) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (d[k] < p.D) p.results[(size_t)(t0 + b) * p.D + d[k]] = r[k];
+            } else {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float e = err_term(yv[k] - r[k], p.use_mse);
+                    acc += d[k] < p.D ? e : 0.0f;
+                }
+                const float total = wave_sum(acc);
+                if (lane == 0) part[par][b][w] = total;
+            }
+        }
+        __syncthreads();
+
+        if ((int)threadIdx.x < nb) {
+            const int b = threadIdx.x;
+            const int c = cls_s[par][b];
+            if (STORE) {
+                if (c == TREE_DEEP || c == TREE_HEAVY)
+                    p.results[(size_t)(t0 + b) * p.D] = bits2f(c == TREE_DEEP ? kSentinelDeep : kSentinelHeavy);
+            } else {
+                float f;
+                if (c == TREE_OK) {
+                    float s = 0.0f;
+                    for (int i = 0; i < W; ++i) s += part[par][b][i];
+                    f = s / (float)p.D;
+                } else {
+                    f = c == TREE_DEEP ? bits2f(kSentinelDeep) : c == TREE_HEAVY ? bits2f(kSentinelHeavy) : __builtin_nanf("");
+                }
+                p.fitness[t0 + b] = f;
+            }
+        }
+        par ^= 1;
+    }
+}
+
 // General path: one wave per tree, lanes are datapoints, stack/outputs in scratch memory, dataset
 // read row-major from global memory.  only_marked != 0: evaluate only trees whose first output
 // word holds the sentinel written by the fast kernel.
@@ -315,6 +444,39 @@ static hipError_t launch_fast(SrParams p, int only_marked, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int DEPTH, int VLA, bool STORE>
+static hipError_t launch_asm(SrParams p, hipStream_t stream) {
+    auto kern = sr_asm_kernel<DEPTH, VLA, STORE>;
+    const DeviceInfo &dev = device_info();
+    p.ntiles = (p.D + 255) / 256;
+    p.only_marked = 0;
+    const int W = p.ntiles;
+    const size_t lds = 0; // the tile staging area is static LDS
+    static int per_cu_cache[5] = {0};
+    int per_cu = per_cu_cache[W];
+    if (per_cu == 0) {
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, W * 64, lds);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        per_cu_cache[W] = per_cu;
+    }
+    long blocks = (long)dev.num_cus * per_cu;
+    long batch = p.pop / (blocks * 16);
+    batch = batch < 4 ? 4 : (batch > kMaxBatch ? kMaxBatch : batch);
+    if (const char *env = getenv("EVOGP_SR_BATCH")) {
+        const int b = atoi(env);
+        batch = b < 1 ? 1 : (b > kMaxBatch ? kMaxBatch : b);
+    }
+    p.batch = (int)batch;
+    const long need = (p.pop + batch - 1) / batch;
+    if (blocks > need) blocks = need;
+    hipError_t e;
+    p.counter = acquire_counter(stream, &e);
+    if (!p.counter) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
 // LEAN pass over every tree, then the FULL build over the trees the lean pass marked heavy.
 template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE>
 static hipError_t launch_pair(const SrParams &p, hipStream_t stream) {
@@ -343,7 +505,16 @@ static int run_population(const SrParams &p, hipStream_t stream) {
     if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
     const bool mo = p.out_len > 1;
     hipError_t e;
-    if (!mo && p.D >= 256) {
+    // EVOGP_SR_ASM: 0 = C++ interpreter only, 12 / 16 = threaded-code core with that stack depth
+    int asm_depth = EVOGP_SR_DEFAULT_ASM;
+    if (const char *env = getenv("EVOGP_SR_ASM")) asm_depth = atoi(env);
+    if (!mo && p.D >= 256 && p.D <= 1024 && asm_depth != 0 && p.var_len <= (asm_depth == 12 ? 10 : 12)) {
+        // threaded-code pass over every tree; whatever it marks heavy goes to the FULL register build
+        e = asm_depth == 12 ? launch_asm<12, 10, STORE>(p, stream) : launch_asm<16, 12, STORE>(p, stream);
+        if (e != hipSuccess) return (int)e;
+        if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream);
+        else e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream);
+    } else if (!mo && p.D >= 256) {
         if (p.var_len <= 9) e = launch_pair<4, 16, 9, false, 4, STORE>(p, stream);
         else if (p.var_len <= 10) e = launch_pair<4, 16, 10, false, 4, STORE>(p, stream);
         else if (p.var_len <= 12) e = launch_pair<4, 16, 12, false, 4, STORE>(p, stream);
