@@ -69,29 +69,51 @@ __device__ inline uint32_t f2bits(float f) { return __float_as_uint(f); }
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// full-wave fixed-order sum (deterministic butterfly over 64 lanes)
+// ---- wave-level scans and reductions on the DPP cross-lane path -------------------------------------
+// `__shfl_*` lowers to ds_bpermute (an LDS-crossbar round trip of ~100 cycles per step); the DPP modifiers
+// move data between lanes inside the VALU.  Inclusive scan over the 64 lanes: row_shr 1,2,4,8 scan
+// each row of 16 lanes, row_bcast:15 and row_bcast:31 carry the row totals upward (the gfx9 sequence
+// the AMDGPU atomic optimizer uses).  The last lane holds the reduction.
+constexpr int kDppRowShr = 0x110, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_move(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ inline int wave_scan_incl(int v) {
+    v += dpp_move<kDppRowShr | 1, 0xf>(0, v);
+    v += dpp_move<kDppRowShr | 2, 0xf>(0, v);
+    v += dpp_move<kDppRowShr | 4, 0xf>(0, v);
+    v += dpp_move<kDppRowShr | 8, 0xf>(0, v);
+    v += dpp_move<kDppBcast15, 0xa>(0, v);
+    v += dpp_move<kDppBcast31, 0xc>(0, v);
+    return v;
+}
+
+// wave-uniform reductions: the value of lane 63 of the scan, broadcast through an SGPR
+__device__ inline int wave_max(int v) {
+    const int lo = (int)0x80000000;
+    v = max(v, dpp_move<kDppRowShr | 1, 0xf>(lo, v));
+    v = max(v, dpp_move<kDppRowShr | 2, 0xf>(lo, v));
+    v = max(v, dpp_move<kDppRowShr | 4, 0xf>(lo, v));
+    v = max(v, dpp_move<kDppRowShr | 8, 0xf>(lo, v));
+    v = max(v, dpp_move<kDppBcast15, 0xa>(lo, v));
+    v = max(v, dpp_move<kDppBcast31, 0xc>(lo, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// fixed-order sum of the 64 lanes (deterministic: the same association every run)
 __device__ inline float wave_sum(float x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
-__device__ inline int wave_max(int x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int y = __shfl_xor(x, off, 64);
-        x = y > x ? y : x;
-    }
-    return x;
-}
-// inclusive prefix sum across the 64 lanes
-__device__ inline int wave_scan_incl(int x) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off, 64);
-        if (lane >= off) x += y;
-    }
-    return x;
+    int z = 0;
+    float v = x;
+    v += __int_as_float(dpp_move<kDppRowShr | 1, 0xf>(z, __float_as_int(v)));
+    v += __int_as_float(dpp_move<kDppRowShr | 2, 0xf>(z, __float_as_int(v)));
+    v += __int_as_float(dpp_move<kDppRowShr | 4, 0xf>(z, __float_as_int(v)));
+    v += __int_as_float(dpp_move<kDppRowShr | 8, 0xf>(z, __float_as_int(v)));
+    v += __int_as_float(dpp_move<kDppBcast15, 0xa>(z, __float_as_int(v)));
+    v += __int_as_float(dpp_move<kDppBcast31, 0xc>(z, __float_as_int(v)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 } // namespace evogp

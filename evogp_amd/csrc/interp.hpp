@@ -289,7 +289,7 @@ __device__ inline int classify_tree(const int16_t *__restrict__ type, const floa
         const int hv = r < len ? hh : 1;
         hmax = max(hmax, hv);
         hmin = min(hmin, hv);
-        carry = __shfl(hh, 63, 64);
+        carry = __builtin_amdgcn_readlane(hh, 63);
     }
     hmax = wave_max(hmax);
     hmin = -wave_max(-hmin);

@@ -285,35 +285,68 @@ __global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
         const int nb = p.pop - t0 < p.batch ? p.pop - t0 : p.batch;
         if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)p.batch);
 
-        for (int b = w; b < nb; b += W) {
-            const size_t row = (size_t)(t0 + b) * p.gp_len;
-            int len = uni((int)p.size[row]);
-            len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
-            int c = classify_tree(p.type + row, p.value + row, len, false, p.var_len, p.out_len, DEPTH, 2);
-            if (c == TREE_OK && len > 63) c = TREE_HEAVY; // one program register: 63 instructions + END
-            if (lane == 0) cls_s[par][b] = c;
-        }
-        __syncthreads();
+        // Every wave walks the whole batch on its own rows.  The tree lengths of the batch come in with ONE
+        // load (lane b = tree b); the nodes of tree b+1 are requested before tree b is interpreted, so the
+        // HBM/L2 latency of a tree row hides behind the previous tree.  Classification (valid? stack <= DEPTH?
+        // only leaves and + - * /?) is recomputed by every wave from the row it needs anyway — DPP scans, no
+        // LDS traffic, no extra barrier.
+        int lens_v = 0;
+        if (lane < nb) lens_v = (int)p.size[(size_t)(t0 + lane) * p.gp_len];
+        lens_v = lens_v < 0 ? 0 : (lens_v > p.gp_len ? p.gp_len : lens_v);
 
+        int len = __builtin_amdgcn_readlane(lens_v, 0);
+        int nt = 0;
+        float nv = 0.0f;
+        if (lane < len && lane < 64) {
+            const size_t at = (size_t)t0 * p.gp_len + (len - 1 - lane);
+            nt = p.type[at]; nv = p.value[at];
+        }
 #pragma nounroll
         for (int b = 0; b < nb; ++b) {
-            const int cls_b = uni(cls_s[par][b]);
-            if (cls_b != TREE_OK) {
-                if (STORE && cls_b == TREE_BAD) {
+            const int cur_len = len;
+            const int cur_t = nt;
+            const float cur_v = nv;
+            // ---- prefetch the next tree's row ----
+            if (b + 1 < nb) {
+                len = __builtin_amdgcn_readlane(lens_v, b + 1);
+                nt = 0; nv = 0.0f;
+                if (lane < len) {
+                    const size_t at = (size_t)(t0 + b + 1) * p.gp_len + (len - 1 - lane);
+                    nt = p.type[at]; nv = p.value[at];
+                }
+            }
+            // ---- decode + classify the current tree (one node per lane, execution order) ----
+            int cls;
+            uint32_t opv = kAsmEnd * kAsmStride, payv = 0;
+            if (cur_len <= 0) cls = TREE_BAD;
+            else if (cur_len > 63) cls = TREE_HEAVY;  // one program register: 63 instructions + END
+            else {
+                int delta = 0;
+                bool heavy = false;
+                if (lane < cur_len) {
+                    const Decoded dn = decode_node(cur_t, cur_v, false, p.var_len, p.out_len);
+                    opv = dn.op * kAsmStride;
+                    payv = dn.op == H_VAR ? dn.pay * 4u : dn.pay;
+                    delta = dn.delta;
+                    heavy = dn.op > H_DIV;
+                }
+                const int hh = wave_scan_incl(delta);
+                const int hv = lane < cur_len ? hh : 1;
+                const int hmax = wave_max(hv), hmin = -wave_max(-hv);
+                const int fin = __builtin_amdgcn_readlane(hh, 63);
+                if (hmin < 1 || fin != 1) cls = TREE_BAD;
+                else if (__any(heavy)) cls = TREE_HEAVY;
+                else cls = hmax > DEPTH ? TREE_DEEP : TREE_OK;
+            }
+            cls = uni(cls);
+            if (w == 0 && lane == 0) cls_s[par][b] = cls;
+            if (cls != TREE_OK) {
+                if (STORE && cls == TREE_BAD) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (d[k] < p.D) p.results[(size_t)(t0 + b) * p.D + d[k]] = __builtin_nanf("");
                 }
                 continue;
-            }
-            const size_t row = (size_t)(t0 + b) * p.gp_len;
-            const int len = uni((int)p.size[row]);
-            uint32_t opv = kAsmEnd * kAsmStride, payv = 0;
-            if (lane < len) {
-                const int i = len - 1 - lane;
-                const Decoded dn = decode_node(p.type[row + i], p.value[row + i], false, p.var_len, p.out_len);
-                opv = dn.op * kAsmStride;
-                payv = dn.op == H_VAR ? dn.pay * 4u : dn.pay;
             }
             float r0, r1, r2, r3;
             if (DEPTH == 12) { EVOGP_INTERP_ASM_D12(r0, r1, r2, r3, opv, payv, lds_addr); }
