@@ -29,6 +29,7 @@ PROTOTYPES = {
     "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
+    "evogp_hip_debug_set_stats": [_vp],
     "evogp_hip_abi_version": [],
 }
 

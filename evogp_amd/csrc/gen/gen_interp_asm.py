@@ -1,120 +1,108 @@
 #!/usr/bin/env python3
-"""Generate interp_asm_<name>.inc: the threaded-code interpreter core in gfx950 assembly.
+"""Generate interp_asm_<name>.inc: the interpreter core of the SR fitness kernel in gfx950 assembly.
 
-Why assembly: the inner loop is bound by scalar/branch issue.  The AMDGPU back end
-lowers `switch` and computed goto to compare-and-branch trees and cannot take `asm goto`, so a
-jump-table dispatch has to be written by hand.  The generated block is ONE `asm volatile` statement:
+Why assembly.  Micro-benchmarks on MI355X (scripts/ubench/issue_latency.hip, profiles/) show that a single
+wave issues one instruction every ~4.3 shader-clock ticks whatever the instruction, that a taken direct
+branch costs ~16 extra ticks, a computed jump (s_setpc_b64) ~28-60, and a v_readlane -> SALU -> v_readlane
+round trip ~28.  The interpreter is therefore bound by INSTRUCTIONS PER NODE and taken jumps per node, and
+the compiler's output (compare trees of ~6 taken branches, ~31 instructions per node) is 2-3x away from
+what the hardware needs.  The generated block is ONE `asm volatile` statement with these properties:
 
-  inputs   %[prog]  VGPR, lane j = byte offset of the handler of instruction j (handler index * 512),
-                    lane n = offset of the END handler
+  * the program is not fetched at all: the pre-decoder (C++, one node per lane) hands over six 64-bit
+    BALLOT MASKS (bit j set = instruction j is VAR / CONST / ADD / SUB / MUL / DIV); the dispatch at the end
+    of every handler is a chain of `s_bitcmp1_b64 mask, j` + `s_cbranch_scc1 handler` in order of expected
+    frequency — direct branches only, exactly one taken branch per tree node, no compare tree, no loop
+    counter (an instruction index with no mask bit is the end of the program);
+  * K = 4 rows per lane; the operand stack and the lane's variables live in fixed VGPRs indexed through
+    M0 (s_set_gpr_idx_on): stack slot e of row k is v[S0 + 4e + k], variable v of row k is v[V0 + 4v + k];
+    binary operators read BOTH operands and write the result through one index window
+    (`v_add_f32 v[S0+k], v[S0+4+k], v[S0+k]` with src0, src1 and dst indexed by 4(h-2)): 4 VALU per node;
+  * division is IEEE (the sequence hipcc emits for `b == 0 ? NaN : a / b`, forward.cu:183-187).
+
+  inputs   %[mvar] %[mconst] %[madd] %[msub] %[mmul] %[mdiv]   SGPR pairs, the ballot masks
            %[pay]   VGPR, lane j = payload of instruction j (constant bits, or 4 * variable index)
-           %[lds]   VGPR, byte address in LDS of this lane's float4 of variable 0; variable v is at
-                    + v * 1024 (64 lanes x 16 B)
-  outputs  %[r0..r3] the four results (top of stack of the lane's four rows)
+           %[lds]   VGPR, byte address in LDS of this lane's float4 of variable 0; variable v at + v*1024
+  outputs  %[r0..r3] the four results (stack slot 0 of the lane's four rows)
 
-Register plan (fixed VGPRs, all listed as clobbers; K = 4 rows per lane):
-  TMP  B0..B3 popped operand, D0..D4 division temporaries, NAN
-  TOS  T0..T3 cached top of stack
-  VARS [var][k]   variables of the lane's four rows, loaded from LDS at entry
-  STK  [slot][k]  operand stack; element e (e < h-1) lives in slot e+1, a push at height h parks the
-                  old top in slot h
-Scalar: s36 = j (current instruction), s37 = 4 * stack height, s[38:39] = handler table base,
-s[40:41] = jump target, s42 = next handler offset (prefetched), s43 = payload, s[44:45] scratch.
-
-Every handler is a 512-byte slot: [prefetch next opcode] [body] [jump] — threaded code, one taken
-jump per tree node, no compare tree, no loop counter (the program ends with an END instruction).
-Handlers: 0 CONST, 1 VAR, 2 ADD, 3 SUB, 4 MUL, 5 DIV (IEEE division, NaN when the divisor is 0:
-forward.cu:183-187), 6 END.  The division sequence is the one hipcc emits for `b == 0 ? NaN : a / b`.
+Fixed registers (all clobbered): VGPR block [base, top): DIV temporaries, NaN, operand copies, VARS, STK;
+s36 = j (instruction index), s37 = 4 * stack height, s43 = payload, s[44:45] scratch.
 """
 import sys
 
-STRIDE = 512
-H = {"CONST": 0, "VAR": 1, "ADD": 2, "SUB": 3, "MUL": 4, "DIV": 5, "END": 6}
 
-
-def gen(name, depth, vla, base=64):
-    B = [base + i for i in range(4)]
-    D = [base + 4 + i for i in range(5)]
-    NAN = base + 9
-    T = [base + 10 + i for i in range(4)]
+def gen(name, depth, vla, base=32):
+    D = [base + i for i in range(5)]      # division temporaries
+    NAN = base + 5
+    TA = [base + 6 + i for i in range(4)]  # operand a of the four rows (also the VAR staging registers)
+    TB = [base + 10 + i for i in range(4)]  # operand b
     V0 = base + 14
+    assert V0 % 2 == 0
     S0 = V0 + 4 * vla
-    top = S0 + 4 * depth  # first register above the block
+    top = S0 + 4 * depth
     L = []
     a = L.append
     uid = "%="
-    a("s_getpc_b64 s[38:39]")
-    a(f".Lafter_{uid}:")
-    a(f"s_add_u32 s38, s38, .Lbase_{uid}-.Lafter_{uid}")
-    a("s_addc_u32 s39, s39, 0")
+    H = {n: f".Lh_{n}_{uid}" for n in ("var", "const", "add", "sub", "mul", "div", "end")}
+
+    def dispatch(inc=True):
+        if inc:
+            a("s_add_u32 s36, s36, 1")
+        for m, n in (("mvar", "var"), ("mconst", "const"), ("madd", "add"), ("msub", "sub"), ("mmul", "mul"), ("mdiv", "div")):
+            a(f"s_bitcmp1_b64 %[{m}], s36")
+            a(f"s_cbranch_scc1 {H[n]}")
+        a(f"s_branch {H['end']}")
+
     for v in range(vla):
         a(f"ds_read_b128 v[{V0 + 4 * v}:{V0 + 4 * v + 3}], %[lds] offset:{1024 * v}")
     a(f"v_mov_b32 v{NAN}, 0x7fc00000")
     a("s_mov_b32 s36, 0")
     a("s_mov_b32 s37, 0")
-    a("v_readlane_b32 s42, %[prog], s36")
     a("s_waitcnt lgkmcnt(0)")
-    a("s_add_u32 s40, s38, s42")
-    a("s_addc_u32 s41, s39, 0")
-    a("s_setpc_b64 s[40:41]")
-    a(f".p2align 9")
-    a(f".Lbase_{uid}:")
+    dispatch(inc=False)
 
-    def prefetch(need_pay):
-        if need_pay:
-            a("v_readlane_b32 s43, %[pay], s36")
-        a("s_add_u32 s36, s36, 1")
-        a("v_readlane_b32 s42, %[prog], s36")
-
-    def jump():
-        a("s_add_u32 s40, s38, s42")
-        a("s_addc_u32 s41, s39, 0")
-        a("s_setpc_b64 s[40:41]")
-
-    def spill_tos():
-        a("s_set_gpr_idx_on s37, gpr_idx(DST)")
-        for k in range(4):
-            a(f"v_mov_b32 v{S0 + k}, v{T[k]}")
-        a("s_set_gpr_idx_off")
-        a("s_add_u32 s37, s37, 4")
-
-    def pop_b():
-        a("s_sub_u32 s37, s37, 4")
-        a("s_set_gpr_idx_on s37, gpr_idx(SRC0)")
-        for k in range(4):
-            a(f"v_mov_b32 v{B[k]}, v{S0 + k}")
-        a("s_set_gpr_idx_off")
-
-    # 0 CONST
-    prefetch(True)
-    spill_tos()
-    for k in range(4):
-        a(f"v_mov_b32 v{T[k]}, s43")
-    jump()
-    # 1 VAR
-    a(".p2align 9")
-    prefetch(True)
-    spill_tos()
+    # VAR: stack[h] = vars[var]   (two index windows: source by variable, destination by height)
+    a(f"{H['var']}:")
+    a("v_readlane_b32 s43, %[pay], s36")
     a("s_set_gpr_idx_on s43, gpr_idx(SRC0)")
     for k in range(4):
-        a(f"v_mov_b32 v{T[k]}, v{V0 + k}")
+        a(f"v_mov_b32 v{TA[k]}, v{V0 + k}")
+    a("s_set_gpr_idx_on s37, gpr_idx(DST)")
+    for k in range(4):
+        a(f"v_mov_b32 v{S0 + k}, v{TA[k]}")
     a("s_set_gpr_idx_off")
-    jump()
-    # 2..4 ADD SUB MUL  (a = top = left operand, b = popped = right operand)
-    for op in ("v_add_f32", "v_sub_f32", "v_mul_f32"):
-        a(".p2align 9")
-        prefetch(False)
-        pop_b()
+    a("s_add_u32 s37, s37, 4")
+    dispatch()
+    # CONST: stack[h] = constant
+    a(f"{H['const']}:")
+    a("v_readlane_b32 s43, %[pay], s36")
+    a("s_add_u32 s36, s36, 1")
+    a("s_set_gpr_idx_on s37, gpr_idx(DST)")
+    for k in range(4):
+        a(f"v_mov_b32 v{S0 + k}, s43")
+    a("s_set_gpr_idx_off")
+    a("s_add_u32 s37, s37, 4")
+    dispatch(inc=False)
+    # ADD SUB MUL: stack[h-2] = stack[h-1] (left operand) op stack[h-2] (right operand)
+    for n, op in (("add", "v_add_f32"), ("sub", "v_sub_f32"), ("mul", "v_mul_f32")):
+        a(f"{H[n]}:")
+        a("s_sub_u32 s37, s37, 8")
+        a("s_set_gpr_idx_on s37, gpr_idx(SRC0,SRC1,DST)")
         for k in range(4):
-            a(f"{op} v{T[k]}, v{T[k]}, v{B[k]}")
-        jump()
-    # 5 DIV
-    a(".p2align 9")
-    prefetch(False)
-    pop_b()
+            a(f"{op} v{S0 + k}, v{S0 + 4 + k}, v{S0 + k}")
+        a("s_set_gpr_idx_off")
+        a("s_add_u32 s37, s37, 4")
+        dispatch()
+    # DIV
+    a(f"{H['div']}:")
+    a("s_sub_u32 s37, s37, 8")
+    a("s_set_gpr_idx_on s37, gpr_idx(SRC0)")
+    for k in range(4):
+        a(f"v_mov_b32 v{TA[k]}, v{S0 + 4 + k}")
+        a(f"v_mov_b32 v{TB[k]}, v{S0 + k}")
+    a("s_set_gpr_idx_off")
     d3, d4, d6, d7, d8 = D
     for k in range(4):
-        x, y = T[k], B[k]
+        x, y = TA[k], TB[k]
         a(f"v_div_scale_f32 v{d3}, s[44:45], v{y}, v{y}, v{x}")
         a(f"v_rcp_f32 v{d4}, v{d3}")
         a(f"v_div_scale_f32 v{d6}, vcc, v{x}, v{y}, v{x}")
@@ -129,26 +117,29 @@ def gen(name, depth, vla, base=64):
         a(f"v_cmp_neq_f32 vcc, 0, v{y}")
         a("s_nop 1")
         a(f"v_cndmask_b32 v{x}, v{NAN}, v{x}, vcc")
-    jump()
-    # 6 END
-    a(".p2align 9")
-    a(f"s_branch .Lend_{uid}")
-    a(".p2align 9")
-    a(f".Lend_{uid}:")
+    a("s_set_gpr_idx_on s37, gpr_idx(DST)")
     for k in range(4):
-        a(f"v_mov_b32 %[r{k}], v{T[k]}")
+        a(f"v_mov_b32 v{S0 + k}, v{TA[k]}")
+    a("s_set_gpr_idx_off")
+    a("s_add_u32 s37, s37, 4")
+    dispatch()
+    # END
+    a(f"{H['end']}:")
+    for k in range(4):
+        a(f"v_mov_b32 %[r{k}], v{S0 + k}")
     body = "\n".join(f'    "{line}\\n\\t"' for line in L)
-    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(36, 46)] + [f'"v{i}"' for i in range(base, top)]
+    clob = ['"memory"', '"vcc"', '"scc"', '"s36"', '"s37"', '"s43"', '"s44"', '"s45"'] + [f'"v{i}"' for i in range(base, top)]
     clob_txt = ",\n      ".join(", ".join(clob[i:i + 12]) for i in range(0, len(clob), 12))
-    out = f'''// GENERATED by gen/gen_interp_asm.py {name} (depth {depth}, {vla} variables, VGPRs v{base}..v{top - 1}) — do not edit.
+    out = f'''// GENERATED by gen/gen_interp_asm.py {name} (stack depth {depth}, {vla} variables, VGPRs v{base}..v{top - 1}) — do not edit.
 #define EVOGP_ASM_TOP_{name.upper()} {top}
-#define EVOGP_INTERP_ASM_{name.upper()}(r0_, r1_, r2_, r3_, prog_, pay_, lds_) \\
+#define EVOGP_INTERP_ASM_{name.upper()}(r0_, r1_, r2_, r3_, mvar_, mconst_, madd_, msub_, mmul_, mdiv_, pay_, lds_) \\
   asm volatile( \\
 '''
     out += "\n".join(line + " \\" for line in body.split("\n"))
     out += f'''
     : [r0] "=v"(r0_), [r1] "=v"(r1_), [r2] "=v"(r2_), [r3] "=v"(r3_) \\
-    : [prog] "v"(prog_), [pay] "v"(pay_), [lds] "v"(lds_) \\
+    : [mvar] "s"(mvar_), [mconst] "s"(mconst_), [madd] "s"(madd_), [msub] "s"(msub_), [mmul] "s"(mmul_), [mdiv] "s"(mdiv_), \\
+      [pay] "v"(pay_), [lds] "v"(lds_) \\
     : {clob_txt.replace(chr(10), " " + chr(92) + chr(10))})
 '''
     return out
@@ -156,7 +147,7 @@ def gen(name, depth, vla, base=64):
 
 if __name__ == "__main__":
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
-    for name, depth, vla in (("d16", 16, 12), ("d12", 12, 10)):
+    for name, depth, vla in (("d10", 10, 10), ("d16", 16, 12)):
         with open(f"{outdir}/interp_asm_{name}.inc", "w") as f:
             f.write(gen(name, depth, vla))
         print("wrote", f"{outdir}/interp_asm_{name}.inc")

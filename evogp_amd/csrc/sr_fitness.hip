@@ -56,7 +56,10 @@ struct SrParams {
     int batch;       // trees per batch, <= kMaxBatch
     int ntiles;      // ceil(D / (64*K))
     int only_marked; // != 0: only trees whose output word holds kSentinelHeavy are evaluated
+    unsigned long long *stats; // optional cycle counters (profiling builds of the bench only), else nullptr
 };
+
+static unsigned long long *g_stats = nullptr; // set by evogp_hip_debug_set_stats
 
 __device__ inline float err_term(float diff, int use_mse) { return use_mse ? diff * diff : fabsf(diff); }
 
@@ -229,21 +232,19 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     }
 }
 
-// ---- threaded-code build -------------------------------------------------------------------------
-// Same skeleton as sr_fast_kernel (tile-resident waves, batches from an atomic counter, classify /
-// interpret / finalise phases) for the configuration the headline benchmark runs: single output,
-// K = 4 rows per lane, trees of at most 63 nodes made of leaves and + - * /.  The interpreter core is
-// the hand-written gfx950 block generated by gen/gen_interp_asm.py: jump-table dispatch on a
-// pre-decoded handler offset, one taken jump per node.  Everything else — trees with other
-// functions, deeper stacks, longer rows — is marked for the FULL register build / the general kernel.
-#include "interp_asm_d12.inc"
+// ---- assembly-core build ---------------------------------------------------------------------------
+// Same skeleton as sr_fast_kernel (tile-resident waves, batches from an atomic counter) for the
+// configuration the headline benchmark runs: single output, K = 4 rows per lane, trees of at most 63
+// nodes made of leaves and + - * /.  The interpreter core is the hand-written gfx950 block generated by
+// gen/gen_interp_asm.py (ballot-mask dispatch with direct branches, register stack indexed through
+// M0).  Everything else — trees with other functions, deeper stacks, longer rows — is marked for the
+// FULL register build / the general kernel.
+#include "interp_asm_d10.inc"
 #include "interp_asm_d16.inc"
 
-constexpr int kAsmStride = 512;  // bytes per handler slot (gen_interp_asm.py)
-constexpr int kAsmEnd = 6;       // index of the END handler
 
 template <int DEPTH, int VLA, bool STORE>
-__global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
+__global__ __launch_bounds__(256, DEPTH == 10 ? 4 : 3) void sr_asm_kernel(SrParams p) {
     // [wave][VLA][64 lanes] float4 = the four rows of a lane, per variable (static and first, so that the
     // ds_read_b128 addresses are 16-byte aligned)
     __shared__ __attribute__((aligned(16))) float4 xs[4 * VLA * kWave];
@@ -278,12 +279,17 @@ __global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
     if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)p.batch);
     __syncthreads();
     int par = 0;
+    // optional cycle accounting (one set of counters per wave, added to p.stats at the end)
+    const bool timing = p.stats != nullptr;
+    unsigned long long c_asm = 0, c_loop = 0, c_wait = 0, n_trees = 0, n_nodes = 0;
+    const unsigned long long k_begin = timing ? __builtin_amdgcn_s_memtime() : 0;
 #pragma nounroll
     for (;;) {
         const int t0 = uni(next_s[par]);
         if (t0 >= p.pop) break;
         const int nb = p.pop - t0 < p.batch ? p.pop - t0 : p.batch;
         if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)p.batch);
+        const unsigned long long b_begin = timing ? __builtin_amdgcn_s_memtime() : 0;
 
         // Every wave walks the whole batch on its own rows.  The tree lengths of the batch come in with ONE
         // load (lane b = tree b); the nodes of tree b+1 are requested before tree b is interpreted, so the
@@ -317,15 +323,15 @@ __global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
             }
             // ---- decode + classify the current tree (one node per lane, execution order) ----
             int cls;
-            uint32_t opv = kAsmEnd * kAsmStride, payv = 0;
+            uint32_t op = 0xFFu, payv = 0; // lanes past the end carry no opcode: their mask bits stay clear
             if (cur_len <= 0) cls = TREE_BAD;
-            else if (cur_len > 63) cls = TREE_HEAVY;  // one program register: 63 instructions + END
+            else if (cur_len > 63) cls = TREE_HEAVY;  // the ballot masks hold 64 instructions, bit len must stay clear
             else {
                 int delta = 0;
                 bool heavy = false;
                 if (lane < cur_len) {
                     const Decoded dn = decode_node(cur_t, cur_v, false, p.var_len, p.out_len);
-                    opv = dn.op * kAsmStride;
+                    op = dn.op;
                     payv = dn.op == H_VAR ? dn.pay * 4u : dn.pay;
                     delta = dn.delta;
                     heavy = dn.op > H_DIV;
@@ -349,8 +355,13 @@ __global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
                 continue;
             }
             float r0, r1, r2, r3;
-            if (DEPTH == 12) { EVOGP_INTERP_ASM_D12(r0, r1, r2, r3, opv, payv, lds_addr); }
-            else { EVOGP_INTERP_ASM_D16(r0, r1, r2, r3, opv, payv, lds_addr); }
+            const unsigned long long a_begin = timing ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned long long m_var = __ballot(op == H_VAR), m_const = __ballot(op == H_CONST),
+                                     m_add = __ballot(op == H_ADD), m_sub = __ballot(op == H_SUB),
+                                     m_mul = __ballot(op == H_MUL), m_div = __ballot(op == H_DIV);
+            if (DEPTH == 10) { EVOGP_INTERP_ASM_D10(r0, r1, r2, r3, m_var, m_const, m_add, m_sub, m_mul, m_div, payv, lds_addr); }
+            else { EVOGP_INTERP_ASM_D16(r0, r1, r2, r3, m_var, m_const, m_add, m_sub, m_mul, m_div, payv, lds_addr); }
+            if (timing) { c_asm += __builtin_amdgcn_s_memtime() - a_begin; n_trees += 1; n_nodes += cur_len; }
             const float r[4] = {r0, r1, r2, r3};
             if (STORE) {
 #pragma unroll
@@ -367,7 +378,9 @@ __global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
                 if (lane == 0) part[par][b][w] = total;
             }
         }
+        const unsigned long long b_end = timing ? __builtin_amdgcn_s_memtime() : 0;
         __syncthreads();
+        if (timing) { c_loop += b_end - b_begin; c_wait += __builtin_amdgcn_s_memtime() - b_end; }
 
         if ((int)threadIdx.x < nb) {
             const int b = threadIdx.x;
@@ -388,6 +401,11 @@ __global__ __launch_bounds__(256) void sr_asm_kernel(SrParams p) {
             }
         }
         par ^= 1;
+    }
+    if (timing && lane == 0) {
+        atomicAdd(p.stats + 0, c_asm); atomicAdd(p.stats + 1, c_loop); atomicAdd(p.stats + 2, c_wait);
+        atomicAdd(p.stats + 3, n_trees); atomicAdd(p.stats + 4, n_nodes);
+        atomicAdd(p.stats + 5, __builtin_amdgcn_s_memtime() - k_begin); atomicAdd(p.stats + 6, 1ull);
     }
 }
 
@@ -483,6 +501,7 @@ static hipError_t launch_asm(SrParams p, hipStream_t stream) {
     const DeviceInfo &dev = device_info();
     p.ntiles = (p.D + 255) / 256;
     p.only_marked = 0;
+    p.stats = g_stats;
     const int W = p.ntiles;
     const size_t lds = 0; // the tile staging area is static LDS
     static int per_cu_cache[5] = {0};
@@ -538,12 +557,12 @@ static int run_population(const SrParams &p, hipStream_t stream) {
     if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
     const bool mo = p.out_len > 1;
     hipError_t e;
-    // EVOGP_SR_ASM: 0 = C++ interpreter only, 12 / 16 = threaded-code core with that stack depth
+    // EVOGP_SR_ASM: 0 = C++ interpreter only, 10 / 16 = assembly core with that stack depth
     int asm_depth = EVOGP_SR_DEFAULT_ASM;
     if (const char *env = getenv("EVOGP_SR_ASM")) asm_depth = atoi(env);
-    if (!mo && p.D >= 256 && p.D <= 1024 && asm_depth != 0 && p.var_len <= (asm_depth == 12 ? 10 : 12)) {
-        // threaded-code pass over every tree; whatever it marks heavy goes to the FULL register build
-        e = asm_depth == 12 ? launch_asm<12, 10, STORE>(p, stream) : launch_asm<16, 12, STORE>(p, stream);
+    if (!mo && p.D >= 256 && p.D <= 1024 && asm_depth != 0 && p.var_len <= (asm_depth == 10 ? 10 : 12)) {
+        // assembly-core pass over every tree; whatever it marks goes to the FULL register build
+        e = asm_depth == 10 ? launch_asm<10, 10, STORE>(p, stream) : launch_asm<16, 12, STORE>(p, stream);
         if (e != hipSuccess) return (int)e;
         if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream);
         else e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream);
@@ -597,4 +616,12 @@ extern "C" int evogp_hip_batch_evaluate(unsigned pop_size, unsigned data_points,
     p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len;
     p.out_len = (int)out_len; p.use_mse = 1;
     return run_population<true>(p, (hipStream_t)stream_);
+}
+
+// Profiling hook for bench scripts (not part of the reference boundary): point the threaded-code kernel at a
+// device buffer of 8 x u64 cycle counters {asm, batch loop, barrier wait, trees, nodes, kernel, waves, -};
+// nullptr switches the accounting off (the default).
+extern "C" int evogp_hip_debug_set_stats(unsigned long long *device_counters) {
+    g_stats = device_counters;
+    return 0;
 }

@@ -110,6 +110,11 @@ int evogp_hip_batch_evaluate(unsigned pop_size, unsigned data_points, unsigned g
 int evogp_hip_timer_begin(evogp_stream_t stream);
 int evogp_hip_timer_end(evogp_stream_t stream, float *elapsed_ms);
 
+/* Profiling hook (no counterpart in the reference): when device_counters != NULL the threaded-code fitness
+ * kernel adds per-wave shader-clock cycle counts to device_counters[0..7] = {interpreter core, batch loop,
+ * barrier wait, trees, nodes, whole kernel, waves, unused}; NULL (the default) disables the accounting. */
+int evogp_hip_debug_set_stats(unsigned long long *device_counters);
+
 /* Human-readable text for a return code of any function above. */
 const char *evogp_hip_error_string(int code);
 

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-depth = sys.argv[1] if len(sys.argv) > 1 else "12"
+depth = sys.argv[1] if len(sys.argv) > 1 else "10"
 os.environ["EVOGP_SR_ASM"] = depth
 import gpu_capi as g  # noqa: E402
 from helpers import c2_dataset, depth2leaf, roulette_uniform  # noqa: E402

@@ -13,13 +13,14 @@ python -c "import torch;print('torch', torch.__version__, 'gpus', torch.cuda.dev
 echo "== smoke"; timeout 900 python __graft_entry__.py smoke; echo "smoke rc=$?"
 } > $OUT/00_smoke.log 2>&1
 # threaded-code core: first contact under a short timeout; fall back to the C++ interpreter for the rest of the run if it misbehaves
-for DEP in 12 16; do timeout 150 python scripts/asm_smoke.py $DEP > $OUT/00_asm_smoke_$DEP.log 2>&1; echo "asm_smoke $DEP rc=$?" >> $OUT/00_asm_smoke_$DEP.log; done
-if ! grep -q ASM_SMOKE_OK $OUT/00_asm_smoke_12.log; then export EVOGP_SR_ASM=0; echo "ASM DISABLED" >> $OUT/00_asm_smoke_12.log; fi
+for DEP in 10 16; do timeout 150 python scripts/asm_smoke.py $DEP > $OUT/00_asm_smoke_$DEP.log 2>&1; echo "asm_smoke $DEP rc=$?" >> $OUT/00_asm_smoke_$DEP.log; done
+if ! grep -q ASM_SMOKE_OK $OUT/00_asm_smoke_10.log; then export EVOGP_SR_ASM=0; echo "ASM DISABLED" >> $OUT/00_asm_smoke_10.log; fi
 if [ "$MODE" != "benchonly" ]; then
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/01_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/01_pytest_gpu.log
 fi
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/02_bench.log 2>&1; echo "bench rc=$?" >> $OUT/02_bench.log
-{ for A in 0 12 16; do echo "== ASM=$A"; EVOGP_SR_ASM=$A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/02b_asm_ab.log 2>&1
+{ for A in 0 10 16; do echo "== ASM=$A"; EVOGP_SR_ASM=$A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/02b_asm_ab.log 2>&1
+{ for A in 10 16; do EVOGP_SR_ASM=$A timeout 200 python scripts/asm_cycles.py; done; } > $OUT/05_cycles.log 2>&1
 if [ "$MODE" = "quick" ]; then ls -la $OUT; exit 0; fi
 {
 for K in 1 2 4; do for DEP in 16 32; do
