@@ -9,7 +9,7 @@
 #define EVOGP_SR_DEFAULT_K 4
 #endif
 #ifndef EVOGP_SR_DEFAULT_ASM
-#define EVOGP_SR_DEFAULT_ASM 10
+#define EVOGP_SR_DEFAULT_ASM 3
 #endif
 #ifndef EVOGP_SR_DEFAULT_DEPTH
 #define EVOGP_SR_DEFAULT_DEPTH 16

@@ -34,30 +34,9 @@
 // != 1 — the reference asserts, forward.cu:298-301) get a NaN fitness.
 #include "interp.hpp"
 #include "launch.hpp"
+#include "sr_params.hpp"
 
 namespace evogp {
-
-constexpr uint32_t kSentinelDeep = 0x7FC0DEEDu;  // quiet-NaN payload: "evaluate me in the general kernel"
-constexpr uint32_t kSentinelHeavy = 0x7FC0FEEDu; // quiet-NaN payload: "evaluate me in the FULL register kernel"
-constexpr int kMaxBatch = 64;                    // trees per batch (LDS partial-sum slots)
-constexpr int kMaxWaves = 16;
-
-struct SrParams {
-    const float *value;
-    const int16_t *type;
-    const int16_t *size;
-    const float *X;  // [D][var_len]
-    const float *y;  // [D][out_len]
-    float *fitness;  // [pop]            (fitness mode)
-    float *results;  // [pop][D][out_len] (store mode: batch evaluation, no reduction)
-    unsigned *counter; // batch counter (zeroed before the launch)
-    int pop, D, gp_len, var_len, out_len;
-    int use_mse;
-    int batch;       // trees per batch, <= kMaxBatch
-    int ntiles;      // ceil(D / (64*K))
-    int only_marked; // != 0: only trees whose output word holds kSentinelHeavy are evaluated
-    unsigned long long *stats; // optional cycle counters (profiling builds of the bench only), else nullptr
-};
 
 static unsigned long long *g_stats = nullptr; // set by evogp_hip_debug_set_stats
 
@@ -557,10 +536,21 @@ static int run_population(const SrParams &p, hipStream_t stream) {
     if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
     const bool mo = p.out_len > 1;
     hipError_t e;
-    // EVOGP_SR_ASM: 0 = C++ interpreter only, 10 / 16 = assembly core with that stack depth
+    // EVOGP_SR_ASM: 0 = C++ interpreter only, 10 / 16 = v2 assembly core with that stack depth, 3 = threaded code (default)
     int asm_depth = EVOGP_SR_DEFAULT_ASM;
     if (const char *env = getenv("EVOGP_SR_ASM")) asm_depth = atoi(env);
-    if (!mo && p.D >= 256 && p.D <= 1024 && asm_depth != 0 && p.var_len <= (asm_depth == 10 ? 10 : 12)) {
+    bool tc_done = false;
+    if (!STORE && !mo && asm_depth == 3) {
+        // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
+        e = launch_threaded_code(p, stream, &tc_done);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (tc_done) {
+        if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream);
+        else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream);
+        else if (p.var_len <= 16) e = launch_fast<4, 16, 16, false, 4, STORE, false>(p, 1, stream);
+        else e = launch_fast<4, 16, 32, false, 4, STORE, false>(p, 1, stream);
+    } else if (!mo && p.D >= 256 && p.D <= 1024 && (asm_depth == 10 || asm_depth == 16) && p.var_len <= (asm_depth == 10 ? 10 : 12)) {
         // assembly-core pass over every tree; whatever it marks goes to the FULL register build
         e = asm_depth == 10 ? launch_asm<10, 10, STORE>(p, stream) : launch_asm<16, 12, STORE>(p, stream);
         if (e != hipSuccess) return (int)e;

@@ -1,0 +1,35 @@
+// sr_params.hpp — argument block and marks shared by the SR-fitness kernels (sr_fitness.hip, sr_tc.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace evogp {
+
+constexpr uint32_t kSentinelDeep = 0x7FC0DEEDu;  // quiet-NaN payload: "evaluate me in the general kernel"
+constexpr uint32_t kSentinelHeavy = 0x7FC0FEEDu; // quiet-NaN payload: "evaluate me in the FULL register kernel"
+constexpr int kMaxBatch = 64;                    // trees per batch (LDS partial-sum slots)
+constexpr int kMaxWaves = 16;
+
+struct SrParams {
+    const float *value;
+    const int16_t *type;
+    const int16_t *size;
+    const float *X;  // [D][var_len]
+    const float *y;  // [D][out_len]
+    float *fitness;  // [pop]            (fitness mode)
+    float *results;  // [pop][D][out_len] (store mode: batch evaluation, no reduction)
+    unsigned *counter; // batch counter (zeroed before the launch)
+    int pop, D, gp_len, var_len, out_len;
+    int use_mse;
+    int batch;       // trees per batch, <= kMaxBatch
+    int ntiles;      // ceil(D / (64*K))
+    int only_marked; // != 0: only trees whose output word holds kSentinelHeavy are evaluated
+    unsigned long long *stats; // optional cycle counters (profiling builds of the bench only), else nullptr
+};
+
+// Threaded-code path (sr_tc.hip): compile the population into fused programs and interpret them with the
+// assembly core.  Returns hipSuccess and sets *handled when it took the launch (trees it could not take are
+// marked kSentinelHeavy / NaN in p.fitness for the follow-up kernels); *handled == false means "not eligible".
+hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled);
+
+} // namespace evogp
