@@ -43,13 +43,13 @@ unsigned *acquire_counter(hipStream_t stream, hipError_t *err) {
         std::lock_guard<std::mutex> lock(g_mu);
         if (!r.base) {
             unsigned *ptr = nullptr;
-            hipError_t e = hipMalloc((void **)&ptr, kCounterRing * sizeof(unsigned));
+            hipError_t e = hipMalloc((void **)&ptr, kCounterRing * 4 * sizeof(unsigned));
             if (e != hipSuccess) { *err = e; return nullptr; }
             r.base = ptr;
         }
     }
-    unsigned *slot = r.base + (r.next.fetch_add(1) % kCounterRing);
-    hipError_t e = hipMemsetAsync(slot, 0, sizeof(unsigned), stream);
+    unsigned *slot = r.base + 4 * (r.next.fetch_add(1) % kCounterRing);
+    hipError_t e = hipMemsetAsync(slot, 0, 4 * sizeof(unsigned), stream);
     if (e != hipSuccess) { *err = e; return nullptr; }
     *err = hipSuccess;
     return slot;

@@ -42,7 +42,7 @@ OPS = ("add", "sub", "mul", "div")
 SLOT = 256  # bytes per handler slot
 
 
-def gen(K, DEPTH):
+def gen(K, DEPTH, stats=False):
     assert K % 4 == 0
     G = K // 4
     TA, TB, Q = 24, 24 + K, 24 + 2 * K
@@ -50,15 +50,32 @@ def gen(K, DEPTH):
     NV = S0 + K * DEPTH
     DT = [16, 17, 18, 19, 20]
     W = 36
-    sPC, sJ, sH, sDST, sTILE, sB, sNB, sT0, sT0N, sOK, sREC, sA, sBop = 16, 18, 19, 20, 21, 22, 23, 24, 25, 26, 28, 30, 31
-    T1, T2, T3, T4 = 32, 33, 34, 35
-    sBLK = T3
+    sPC, sJ, sH, sDST, sTILE, sB, sNB, sT0, sT0N, sOK, sREC, sA, sBop = 20, 22, 23, 24, 25, 26, 27, 28, 29, 30, 32, 34, 35
+    T1, T2 = 100, 101
+    T4 = sDST    # free outside the division stubs
+    sBLK = sT0N  # the next grab is only live between two batches
+    P1, P2, P3, P4 = 20, 21, 22, 23  # prologue scratch (control registers that are not live yet)
     uid = "%="
     L = []
     a = L.append
 
     def lab(n):
         return f".Ltc_{n}_{uid}"
+
+    # cycle accounting (stats build only): v22 = ticks waiting for program records, v23 = ticks waiting for work,
+    # v5 is not available (VV handlers), so the start tick of an interval is parked in the spare stack slot NV-1
+    def tick_begin():
+        if stats:
+            a(f"s_memtime s[{T1}:{T2}]")
+            a("s_waitcnt lgkmcnt(0)")
+            a(f"v_mov_b32 v{NV - 1}, s{T1}")
+
+    def tick_end(acc):
+        if stats:
+            a(f"s_memtime s[{T1}:{T2}]")
+            a("s_waitcnt lgkmcnt(0)")
+            a(f"v_sub_u32 v{NV - 1}, s{T1}, v{NV - 1}")
+            a(f"v_add_u32 v{acc}, v{acc}, v{NV - 1}")
 
     hid = {}
     for o, op in enumerate(OPS):
@@ -87,66 +104,111 @@ def gen(K, DEPTH):
     a("v_add_u32 v1, %[ldsx], v1")
     a("v_lshlrev_b32 v15, 2, v0")
     a("v_mov_b32 v8, 0x7fc00000")
-    a("s_load_dwordx4 s[4:7], %[karg], 0x0")    # program records, fitness
-    a(f"s_load_dwordx2 s[{T3}:{T4}], %[karg], 0x10")  # work counter
-    a("s_load_dwordx8 s[8:15], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, query, record stride
+    a("s_load_dwordx4 s[8:11], %[karg], 0x0")    # program records, fitness
+    a(f"s_load_dwordx2 s[{P3}:{P4}], %[karg], 0x10")  # work counter
+    a("s_load_dwordx8 s[12:19], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, query, record stride
     a("s_waitcnt lgkmcnt(0)")
-    a(f"v_mov_b32 v10, s{T3}")
-    a(f"v_mov_b32 v11, s{T4}")
-    a("v_mov_b32 v13, s12")
-    a("s_mul_i32 s10, s10, s11")
-    a(f"s_mul_i32 s10, s10, {G * 1024}")  # s10 = LDS distance from X to y
+    a(f"v_mov_b32 v10, s{P3}")
+    a(f"v_mov_b32 v11, s{P4}")
+    a("v_mov_b32 v13, s16")
+    a("s_mul_i32 s14, s14, s15")
+    a(f"s_mul_i32 s14, s14, {G * 1024}")  # s14 = LDS distance from X to y
+    a(f"s_load_dwordx4 s[{P1}:{P4}], %[karg], 0x48")  # static trees per workgroup, first dynamic tree, LDS offset of the queue head
+    a("s_waitcnt lgkmcnt(0)")
+    a(f"v_mov_b32 v21, s{P3}")                  # LDS address of the workgroup's queue head
+    a("v_add_u32 v21, %[ldsx], v21")
+    a(f"s_mul_i32 %[wgid], %[wgid], s{P1}")     # first tree of the workgroup's static share
+    a(f"s_mov_b32 %[ldsx], s{P1}")              # from here on: size of the static share
+    a(f"s_mov_b32 %[dyn], s{P2}")               # first tree of the dynamic region
     a(f"s_getpc_b64 s[{T1}:{T2}]")
     a(f"{lab('pc')}:")
     a(f"s_add_u32 s{T1}, s{T1}, {lab('hbase')}-{lab('pc')}")
     a(f"s_addc_u32 s{T2}, s{T2}, 0")
     a(f"s_mov_b32 s{sPC + 1}, s{T2}")
     # query mode: report the handler base address and leave
-    a("s_cmp_eq_u32 s14, 0")
+    a("s_cmp_eq_u32 s18, 0")
     a(f"s_cbranch_scc1 {lab('run')}")
     a(f"v_mov_b32 v4, s{T1}")
     a(f"v_mov_b32 v5, s{T2}")
     a("v_mov_b32 v9, 0")
-    a("global_store_dwordx2 v9, v[4:5], s[6:7]")
+    a("global_store_dwordx2 v9, v[4:5], s[10:11]")
     a("s_waitcnt vmcnt(0)")
     a("s_endpgm")
     a(f"{lab('run')}:")
+    if stats:
+        a("v_mov_b32 v22, 0")
+        a("v_mov_b32 v23, 0")
+        a(f"v_mov_b32 v{NV - 2}, 0")  # trees
+        a(f"v_mov_b32 v{NV - 3}, 0")  # dispatches
+        a(f"s_memtime s[{T1}:{T2}]")
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"v_mov_b32 v{NV - 4}, s{T1}")  # start tick
+    a("s_mov_b32 s18, 1")  # 1 while the workgroup's static share lasts
+    # ------------------------------------------------------------------ batch loop
+    # Work distribution: every workgroup owns a contiguous static share that its waves split through an LDS
+    # counter (cheap); the rest of the population is handed out from one global counter (atomics on one
+    # address serialise at ~11 ns each, so only the load-balancing tail goes through them).
+    a(f"{lab('batch')}:")
+    a("s_cmp_eq_u32 s18, 0")
+    a(f"s_cbranch_scc1 {lab('dyn')}")
+    tick_begin()
+    a("s_mov_b64 exec, 1")
+    a("ds_add_rtn_u32 v12, v21, v13")
+    a("s_mov_b64 exec, -1")
+    a("s_waitcnt lgkmcnt(0)")
+    tick_end(23)
+    a(f"v_readfirstlane_b32 s{sT0}, v12")
+    a(f"s_cmp_lt_u32 s{sT0}, %[ldsx]")
+    a(f"s_cbranch_scc0 {lab('to_dyn')}")
+    a(f"s_sub_u32 s{sNB}, %[ldsx], s{sT0}")
+    a(f"s_min_u32 s{sNB}, s{sNB}, s16")
+    a(f"s_add_u32 s{sT0}, s{sT0}, %[wgid]")
+    a(f"s_branch {lab('have_batch')}")
+    a(f"{lab('to_dyn')}:")
+    a("s_mov_b32 s18, 0")
+    tick_begin()
     a("s_mov_b64 exec, 1")
     a("global_atomic_add v12, v[10:11], v13, off sc0")
     a("s_mov_b64 exec, -1")
     a("s_waitcnt vmcnt(0)")
+    tick_end(23)
     a(f"v_readfirstlane_b32 s{sT0N}, v12")
-    # ------------------------------------------------------------------ batch loop
-    a(f"{lab('batch')}:")
+    a(f"s_add_u32 s{sT0N}, s{sT0N}, %[dyn]")
+    a(f"{lab('dyn')}:")
     a(f"s_mov_b32 s{sT0}, s{sT0N}")
-    a(f"s_cmp_ge_u32 s{sT0}, s8")
+    a(f"s_cmp_ge_u32 s{sT0}, s12")
     a(f"s_cbranch_scc1 {lab('exit')}")
     a("s_mov_b64 exec, 1")
     a("global_atomic_add v12, v[10:11], v13, off sc0")  # the next batch, consumed at the end of this one
     a("s_mov_b64 exec, -1")
-    a(f"s_sub_u32 s{sNB}, s8, s{sT0}")
-    a(f"s_min_u32 s{sNB}, s{sNB}, s12")
+    a(f"s_sub_u32 s{sNB}, s12, s{sT0}")
+    a(f"s_min_u32 s{sNB}, s{sNB}, s16")
+    a(f"{lab('have_batch')}:")
     a(f"s_mov_b32 s{sB}, 0")
     a(f"s_mov_b64 s[{sOK}:{sOK + 1}], 0")
     a("v_mov_b32 v7, 0")
     # ------------------------------------------------------------------ tree loop
     a(f"{lab('tree')}:")
     a(f"s_add_u32 s{T1}, s{sT0}, s{sB}")
-    a(f"s_mul_hi_u32 s{sREC + 1}, s{T1}, s15")
-    a(f"s_mul_i32 s{sREC}, s{T1}, s15")
-    a(f"s_add_u32 s{sREC}, s{sREC}, s4")
-    a(f"s_addc_u32 s{sREC + 1}, s{sREC + 1}, s5")
+    a(f"s_mul_hi_u32 s{sREC + 1}, s{T1}, s19")
+    a(f"s_mul_i32 s{sREC}, s{T1}, s19")
+    a(f"s_add_u32 s{sREC}, s{sREC}, s8")
+    a(f"s_addc_u32 s{sREC + 1}, s{sREC + 1}, s9")
+    tick_begin()
     for i in range(4):
         a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
     a("v_mov_b32 v6, 0")
     a(f"s_mov_b32 s{sTILE}, 0")
     a(f"s_mov_b32 s{sBLK}, 0")
     a("s_waitcnt lgkmcnt(0)")
+    tick_end(22)
+    if stats:
+        a(f"v_add_u32 v{NV - 2}, 1, v{NV - 2}")
     # ------------------------------------------------------------------ tile loop (one pass of the program)
     a(f"{lab('tile')}:")
     a(f"s_mul_i32 s{T1}, s{sTILE}, {G * 1024}")
     a(f"v_add_u32 v2, s{T1}, v1")
-    a("v_add_u32 v3, s10, v2")
+    a("v_add_u32 v3, s14, v2")
     a(f"s_mov_b32 s{sH}, 0")
     a(f"s_mov_b32 s{sJ}, 0")
     a(f"s_cmp_eq_u32 s{sBLK}, 0")
@@ -348,11 +410,13 @@ def gen(K, DEPTH):
     # end of the program: fold this tile's errors into the accumulator
     a(f"{lab('endbody')}:")
     a("s_set_gpr_idx_off")
+    if stats:
+        a(f"v_add_u32 v{NV - 3}, s{sJ}, v{NV - 3}")
     for g in range(G):
         a(f"ds_read_b128 v[{TB + 4 * g}:{TB + 4 * g + 3}], v3" + (f" offset:{1024 * g}" if g else ""))
     a(f"s_add_u32 s{T1}, s{sTILE}, 1")
-    a(f"s_cmp_lt_u32 s{T1}, s11")
-    a(f"s_cselect_b32 s{T2}, 0, s13")  # flag bit 1 (ragged) survives only on the last tile
+    a(f"s_cmp_lt_u32 s{T1}, s15")
+    a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile
     a(f"s_and_b32 s{T2}, s{T2}, 2")
     a("s_waitcnt lgkmcnt(0)")
     a(f"s_cmp_eq_u32 s{T2}, 0")
@@ -364,8 +428,8 @@ def gen(K, DEPTH):
         a(f"s_add_u32 s{T4}, s{T2}, {g * 256 + q}")
         a(f"v_add_u32 v4, s{T4}, v15")
         a(f"v_sub_f32 v9, v{TB + k}, v{S0 + k}")
-        a("v_cmp_gt_u32 vcc, s9, v4")
-        a("s_bitcmp0_b32 s13, 0")
+        a("v_cmp_gt_u32 vcc, s13, v4")
+        a("s_bitcmp0_b32 s17, 0")
         a(f"s_cbranch_scc1 {lab(f'rag_abs{k}')}")
         a("v_mul_f32 v9, v9, v9")
         a(f"{lab(f'rag_abs{k}')}:")
@@ -374,7 +438,7 @@ def gen(K, DEPTH):
         a("v_add_f32 v6, v6, v9")
     a(f"s_branch {lab('end_acc')}")
     a(f"{lab('end_full')}:")
-    a("s_bitcmp0_b32 s13, 0")
+    a("s_bitcmp0_b32 s17, 0")
     a(f"s_cbranch_scc1 {lab('end_abs')}")
     for k in range(K):
         a(f"v_sub_f32 v9, v{TB + k}, v{S0 + k}")
@@ -387,7 +451,7 @@ def gen(K, DEPTH):
         a("v_add_f32_e64 v6, v6, |v9|")
     a(f"{lab('end_acc')}:")
     a(f"s_mov_b32 s{sTILE}, s{T1}")
-    a(f"s_cmp_lt_u32 s{sTILE}, s11")
+    a(f"s_cmp_lt_u32 s{sTILE}, s15")
     a(f"s_cbranch_scc1 {lab('tile')}")
     # the tree is finished: fixed-order sum of the 64 lanes, lane b of v7 receives it
     for ctl in ("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0",
@@ -404,11 +468,20 @@ def gen(K, DEPTH):
     a(f"s_add_u32 s{sB}, s{sB}, 1")
     a(f"s_cmp_lt_u32 s{sB}, s{sNB}")
     a(f"s_cbranch_scc1 {lab('tree')}")
-    # batch finished: mean = sum / D, one coalesced store for the evaluated trees
+    # batch finished: take the prefetched grab first (the store below then never sits in front of a wait),
+    # then mean = sum / D and one coalesced store for the evaluated trees
+    a("s_cmp_eq_u32 s18, 0")
+    a(f"s_cbranch_scc0 {lab('no_grab')}")
+    tick_begin()
+    a("s_waitcnt vmcnt(0)")
+    tick_end(23)
+    a(f"v_readfirstlane_b32 s{sT0N}, v12")
+    a(f"s_add_u32 s{sT0N}, s{sT0N}, %[dyn]")
+    a(f"{lab('no_grab')}:")
     a(f"s_cmp_eq_u64 s[{sOK}:{sOK + 1}], 0")
-    a(f"s_cbranch_scc1 {lab('batch_done')}")
+    a(f"s_cbranch_scc1 {lab('batch')}")
     a(f"s_mov_b64 exec, s[{sOK}:{sOK + 1}]")
-    a("v_cvt_f32_u32 v9, s9")
+    a("v_cvt_f32_u32 v9, s13")
     d3, d4, d6, d7, d8 = DT
     a(f"v_div_scale_f32 v{d3}, s[{T1}:{T2}], v9, v9, v7")
     a(f"v_rcp_f32 v{d4}, v{d3}")
@@ -423,11 +496,8 @@ def gen(K, DEPTH):
     a(f"v_div_fixup_f32 v{d3}, v{d3}, v9, v7")
     a(f"v_add_u32 v14, s{sT0}, v0")
     a("v_lshlrev_b32 v14, 2, v14")
-    a(f"global_store_dword v14, v{d3}, s[6:7]")
+    a(f"global_store_dword v14, v{d3}, s[10:11]")
     a("s_mov_b64 exec, -1")
-    a(f"{lab('batch_done')}:")
-    a("s_waitcnt vmcnt(0)")
-    a(f"v_readfirstlane_b32 s{sT0N}, v12")
     a(f"s_branch {lab('batch')}")
 
     # shared division body: K rows, then the scatter through v_div_fixup with an indexed destination
@@ -439,23 +509,40 @@ def gen(K, DEPTH):
     epilogue()
 
     a(f"{lab('exit')}:")
+    if stats:  # {record wait, work wait, trees, 4 * dispatches, wave ticks, waves} += this wave's counters
+        a(f"s_memtime s[{T1}:{T2}]")
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"v_sub_u32 v{NV - 4}, s{T1}, v{NV - 4}")
+        a(f"s_load_dwordx2 s[{T1}:{T2}], %[karg], 0x58")
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"v_mov_b32 v10, s{T1}")
+        a(f"v_mov_b32 v11, s{T2}")
+        a("v_mov_b32 v13, 0")
+        a("s_mov_b64 exec, 1")
+        for i, src in enumerate((22, 23, NV - 2, NV - 3, NV - 4, None)):
+            if src is None:
+                a("v_mov_b32 v12, 1")
+            else:
+                a(f"v_mov_b32 v12, v{src}")
+            a(f"global_atomic_add_x2 v[10:11], v[12:13], off offset:{8 * i}")
+        a("s_waitcnt vmcnt(0)")
     a("s_endpgm")
 
     body = "\n".join(f'    "{line}\\n\\t"' for line in L)
-    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(4, 100)] + [f'"v{i}"' for i in range(0, NV)]
+    clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV)]
     clob_txt = ", ".join(clob)
-    name = f"K{K}"
+    name = f"K{K}" + ("S" if stats else "")
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
-    if K == 8:
+    if K == 8 and not stats:
         out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NH}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
-    out += f"#define EVOGP_TC_ASM_{name}(karg_, ldsx_) \\\n  asm volatile( \\\n"
+    out += f"#define EVOGP_TC_ASM_{name}(karg_, ldsx_, wgid_, dyn_) \\\n  asm volatile( \\\n"
     out += "\n".join(line + " \\" for line in body.split("\n"))
     out += f'''
-    : \\
-    : [karg] "s"(karg_), [ldsx] "s"(ldsx_) \\
+    : [ldsx] "+s"(ldsx_), [wgid] "+s"(wgid_), [dyn] "+s"(dyn_) \\
+    : [karg] "s"(karg_) \\
     : {clob_txt})
 '''
     return out
@@ -466,4 +553,6 @@ if __name__ == "__main__":
     for K, depth in ((8, 10), (4, 15)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:
             f.write(gen(K, depth))
+            if K == 8:
+                f.write(gen(K, depth, stats=True))  # cycle-accounting build (its top stack slot holds the counters)
         print("wrote", f"{outdir}/tc_interp_k{K}.inc")

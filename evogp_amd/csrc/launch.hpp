@@ -27,7 +27,7 @@ struct DeviceInfo {
 // Properties of the CURRENT device (cached per device id).
 const DeviceInfo &device_info();
 
-// A zero-initialised 32-bit work counter in device memory for one launch on `stream`
+// Four zero-initialised 32-bit words in device memory (a work counter, or the pending-marks flags) for one launch on `stream`
 // (dynamic batch distribution inside persistent kernels).  Counters come from a small per-device
 // ring; the slot is cleared with hipMemsetAsync on `stream` before it is handed out, so reuse is
 // ordered by the stream.  Returns nullptr and sets *err on failure.

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     __shared__ int cls_s[2][kMaxBatch];
     __shared__ int next_s[2];
 
+    if (p.only_marked && p.marks && uni((int)p.marks[0]) == 0) return;  // nothing was marked for this build
     using VARS = typename VecOf<VL>::type;
     constexpr int TILE = kWave * K;
     const int lane = threadIdx.x & 63;
@@ -187,6 +188,11 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
         __syncthreads();
 
         // ---- phase 3: one thread per tree adds the tile partials in tile order ----
+        if (p.marks && threadIdx.x < 64) {  // batches are at most 64 trees: wave 0 sees every class of the batch
+            const int c = (int)threadIdx.x < nb ? cls_s[par][threadIdx.x] : TREE_OK;
+            if (__any(c == TREE_HEAVY) && threadIdx.x == 0) p.marks[0] = 1u;
+            if (__any(c == TREE_DEEP) && threadIdx.x == 0) p.marks[1] = 1u;
+        }
         if (STORE) {
             if ((int)threadIdx.x < nb) {
                 const int c = cls_s[par][threadIdx.x];
@@ -361,6 +367,11 @@ __global__ __launch_bounds__(256, DEPTH == 10 ? 4 : 3) void sr_asm_kernel(SrPara
         __syncthreads();
         if (timing) { c_loop += b_end - b_begin; c_wait += __builtin_amdgcn_s_memtime() - b_end; }
 
+        if (p.marks && threadIdx.x < 64) {
+            const int c = (int)threadIdx.x < nb ? cls_s[par][threadIdx.x] : TREE_OK;
+            if (__any(c == TREE_HEAVY) && threadIdx.x == 0) p.marks[0] = 1u;
+            if (__any(c == TREE_DEEP) && threadIdx.x == 0) p.marks[1] = 1u;
+        }
         if ((int)threadIdx.x < nb) {
             const int b = threadIdx.x;
             const int c = cls_s[par][b];
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(256, DEPTH == 10 ? 4 : 3) void sr_asm_kernel(SrPara
 template <bool MO, bool STORE>
 __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_marked) {
     const int lane = threadIdx.x & 63;
+    if (only_marked && p.marks && uni((int)p.marks[1]) == 0) return;  // no tree needs the general path
     float stk[kMaxStack + 2];
     float outs[MO ? kGeneralOuts : 1];
     for (int t = blockIdx.x; t < p.pop; t += gridDim.x) {
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
 
 // ---- host side -----------------------------------------------------------------------------------
 template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE, bool LEAN>
-static hipError_t launch_fast(SrParams p, int only_marked, hipStream_t stream) {
+static hipError_t launch_fast(SrParams p, int only_marked, hipStream_t stream, unsigned *zeroed_counter = nullptr) {
     auto kern = sr_fast_kernel<K, DEPTH, VL, MO, MAXW, STORE, LEAN>;
     const DeviceInfo &dev = device_info();
     p.ntiles = (p.D + 64 * K - 1) / (64 * K);
@@ -468,7 +480,7 @@ static hipError_t launch_fast(SrParams p, int only_marked, hipStream_t stream) {
     const long need = (p.pop + batch - 1) / batch;
     if (blocks > need) blocks = need;
     hipError_t e;
-    p.counter = acquire_counter(stream, &e);
+    p.counter = zeroed_counter ? zeroed_counter : acquire_counter(stream, &e);
     if (!p.counter) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), 0, stream, p);
     return hipGetLastError();
@@ -531,7 +543,13 @@ static hipError_t launch_general(const SrParams &p, int only_marked, hipStream_t
 //   multi output,  D >= 128 : K = 2 (16 output accumulators per row live in registers as well)
 //   small datasets          : K = 1, 32-entry stack
 template <bool STORE>
-static int run_population(const SrParams &p, hipStream_t stream) {
+static int run_population(const SrParams &p_in, hipStream_t stream) {
+    SrParams p = p_in;
+    {   // pending-marks flags of this call: follow-up kernels leave at once when nothing was marked for them
+        hipError_t me;
+        p.marks = acquire_counter(stream, &me);
+        if (!p.marks) return (int)me;
+    }
     const bool fast_ok = p.var_len <= 32 && p.out_len <= kMaxOutRegs && !getenv("EVOGP_SR_FORCE_GENERAL");
     if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
     const bool mo = p.out_len > 1;
@@ -542,14 +560,16 @@ static int run_population(const SrParams &p, hipStream_t stream) {
     bool tc_done = false;
     if (!STORE && !mo && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
+        p.stats = g_stats;
         e = launch_threaded_code(p, stream, &tc_done);
+        p.stats = nullptr;
         if (e != hipSuccess) return (int)e;
     }
     if (tc_done) {
-        if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream);
-        else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream);
-        else if (p.var_len <= 16) e = launch_fast<4, 16, 16, false, 4, STORE, false>(p, 1, stream);
-        else e = launch_fast<4, 16, 32, false, 4, STORE, false>(p, 1, stream);
+        if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
+        else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
+        else if (p.var_len <= 16) e = launch_fast<4, 16, 16, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
+        else e = launch_fast<4, 16, 32, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
     } else if (!mo && p.D >= 256 && p.D <= 1024 && (asm_depth == 10 || asm_depth == 16) && p.var_len <= (asm_depth == 10 ? 10 : 12)) {
         // assembly-core pass over every tree; whatever it marks goes to the FULL register build
         e = asm_depth == 10 ? launch_asm<10, 10, STORE>(p, stream) : launch_asm<16, 12, STORE>(p, stream);
