@@ -1,36 +1,45 @@
 #!/usr/bin/env python3
-"""Generate tc_interp_k<K>.inc: the threaded-code SR-fitness interpreter for gfx950, v3.
+"""Generate tc_interp_k<K>.inc: the threaded-code SR-fitness interpreter for gfx950 (v3.1).
 
-What changed against the v2 core (gen_interp_asm.py) and why — all numbers from scripts/ubench/issue_model.hip
-on MI355X (profiles/r01_issue_model_ubench.log):
+Why it looks the way it does — all numbers measured on MI355X (scripts/ubench/issue_model.hip,
+profiles/r01_issue_model_ubench.log; PMC counters in profiles/):
 
   * one SIMD retires a wave64 fp32 VALU instruction every ~2.3 clocks but only ONE scalar instruction every
-    4 clocks, a v_readlane costs 8-12 VALU clocks, and a single wave issues at most one instruction per
-    ~4.3 clocks.  v2 spent ~11 SALU + 2 v_readlane per tree node for 4-8 VALU: scalar bound.
-  * v3 therefore (1) interprets a COMPILED program: a separate kernel (sr_tc.hip: tc_compile_kernel) fuses every
-    leaf into its parent operator, so the number of dispatches is the number of function nodes (12.6 instead
-    of 26.3 per tree on configs[1]) and the operand stack only holds intermediate results;
-    (2) fetches the program with scalar loads into a 64-SGPR window (16 instructions of 4 dwords:
-    {handler address, -, operand a, operand b}); the dispatch is  s_movrels_b32 + s_setpc_b64  on an
-    ABSOLUTE handler address — no v_readlane, no decode, no compare chain;
-    (3) works on K = 8 rows per lane (one tree instruction = 8 VALU), so the scalar work per dispatch
-    (5-7 SALU + 1 jump) hides behind the vector work of the other resident waves;
-    (4) keeps the dataset in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per
-    four rows: variable operands cost LDS bandwidth instead of VALU moves and the VGPR budget (128 = 4 waves
-    per SIMD) goes to the operand stack;
-    (5) lets every wave evaluate WHOLE trees (all datapoint tiles, one after the other): no barrier, no partial
-    sums in LDS, no float atomics; trees are handed out in small batches from a global counter.
+    4 clocks, a v_readlane costs 8-12 VALU clocks, a single wave issues at most one instruction per ~4.3 clocks,
+    a computed jump costs the wave ~60 clocks, an LDS read ~200-300 under load, a scalar load of a cold
+    record ~6000.  The interpreter is bound by per-wave LATENCY per tree instruction, so everything below
+    is about fewer dispatches, more vector work per dispatch and no exposed waits.
+  * it interprets a COMPILED program: tc_compile_kernel (sr_tc.hip) fuses every leaf into its parent
+    operator, so there is one dispatch per FUNCTION node (12.9 instead of 26.3 per tree on configs[1]) and
+    the operand stack only holds intermediate results;
+  * the program is fetched with scalar loads into a 64-SGPR window (16 instructions of 4 dwords:
+    {handler address, LDS offset of its first variable operand, operand a, operand b}); the dispatch is
+    s_movrels_b32 + s_setpc_b64 on an ABSOLUTE handler address — no v_readlane, no decode, no compare chain;
+  * K = 8 rows per lane: one tree instruction = 8 VALU (a division ~120);
+  * the dataset lives in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per four
+    rows.  Variable operands are PREFETCHED one instruction ahead: every handler starts by issuing the LDS
+    reads for the NEXT instruction's variable into the other of two operand banks, so the LDS latency runs
+    under the current handler's arithmetic.  Handlers therefore come in two flavours (current bank 0 / 1),
+    chosen by the compiler from the parity of the instruction index;
+  * every wave evaluates WHOLE trees (all datapoint tiles, one after the other): no barrier, no partial sums
+    in LDS, no float atomics.  Work distribution: each workgroup owns a static share that its waves walk
+    round-robin (no atomics, the next batch is known, so its program records are pulled into L2 with one
+    vector load while the current batch runs); the load-balancing tail comes from one global counter
+    (same-address atomics serialise at ~11 ns each).
 
 The block is ONE `asm volatile` statement that never returns (it ends the wave).  Register map (fixed):
 
-  SGPR  s[16:17] jump target (lo from the program, hi constant)   s18 J = dword offset of the current instruction
-        s19 H = K * stack height   s20 scatter M0 of the DIV body   s21 tile   s22 b (tree in batch)   s23 trees in batch
-        s24 t0   s25 next t0   s[26:27] mask of evaluated trees   s[28:29] record address   s[30:31] operands a, b
-        s32..s35 scratch   s[36:99] program window
-  VGPR  v0 lane   v1 X base of the lane   v2 X base of the tile   v3 y address of the tile   v4,v5 scratch addresses
-        v6 error accumulator   v7 batch results (lane b = tree b)   v8 NaN   v9 scratch   v[10:11] counter address
-        v12 grabbed t0   v13 batch size   v14 store offset   v15 4*lane   v16..v20 division temporaries
-        TA = v[24:24+K)  TB  Q  then the operand stack S0.. (slot e of row k = S0 + K*e + k)
+  SGPR  s[8:9] records  s[10:11] fitness  s12 pop  s13 D  s14 LDS distance X->y  s15 tiles  s16 batch  s17 flags
+        s18 static phase  s19 record stride  s[20:21] jump target  s22 J = dword offset of the current instruction
+        s23 H = K * stack height  s24 scatter M0 of the division / scratch  s25 tile  s26 b (tree in batch)
+        s27 trees in batch  s28 t0  s29 next dynamic t0 / program block  s[30:31] mask of evaluated trees
+        s[32:33] record address  s[34:35] operands a, b  s[36:99] program window  s[100:101] scratch
+        in/out operands of the statement: static cursor, static end, static stride, first dynamic tree, prefetch offset
+  VGPR  v0 lane  v1 X base of the lane  v2 X base of the tile  v3 y address of the tile  v4,v5 addresses
+        v6 error accumulator  v7 batch results (lane b = tree b)  v8 NaN  v9 scratch  v[10:11] counter address
+        v12 grabbed t0  v13 warm-up offset  v[14:17] warm-up sink  v18..v22 division temporaries
+        P0 P1 (variable-operand banks)  T (second operand / labels)  Q (quotients)  then the operand stack
+        (slot e of row k = S0 + K*e + k)
 
 VGPR indexing stays enabled while a program runs; handlers select the indexed operands by writing
 M0 = (mode << 12) | index directly (s_add_u32 m0, H, imm), which replaces s_set_gpr_idx_on/off pairs.
@@ -40,21 +49,24 @@ import sys
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 OPS = ("add", "sub", "mul", "div")
 SLOT = 256  # bytes per handler slot
+NHF = 37    # handlers per flavour
 
 
 def gen(K, DEPTH, stats=False):
     assert K % 4 == 0
     G = K // 4
-    TA, TB, Q = 24, 24 + K, 24 + 2 * K
-    S0 = 24 + 3 * K
+    P = [24, 24 + K]
+    T, Q = 24 + 2 * K, 24 + 3 * K
+    S0 = 24 + 4 * K
     NV = S0 + K * DEPTH
-    DT = [16, 17, 18, 19, 20]
+    DT = [18, 19, 20, 21, 22]
     W = 36
     sPC, sJ, sH, sDST, sTILE, sB, sNB, sT0, sT0N, sOK, sREC, sA, sBop = 20, 22, 23, 24, 25, 26, 27, 28, 29, 30, 32, 34, 35
     T1, T2 = 100, 101
     T4 = sDST    # free outside the division stubs
-    sBLK = sT0N  # the next grab is only live between two batches
-    P1, P2, P3, P4 = 20, 21, 22, 23  # prologue scratch (control registers that are not live yet)
+    sBLK = sT0N  # the next dynamic grab is only live between two batches
+    P1_, P2_, P3_, P4_ = 20, 21, 22, 23  # prologue scratch (control registers that are not live yet)
+    CUR, END_, STRIDE, DYN, PF = "%[cur]", "%[lim]", "%[stride]", "%[dyn]", "%[pf]"
     uid = "%="
     L = []
     a = L.append
@@ -62,64 +74,87 @@ def gen(K, DEPTH, stats=False):
     def lab(n):
         return f".Ltc_{n}_{uid}"
 
-    # cycle accounting (stats build only): v22 = ticks waiting for program records, v23 = ticks waiting for work,
-    # v5 is not available (VV handlers), so the start tick of an interval is parked in the spare stack slot NV-1
-    def tick_begin():
-        if stats:
-            a(f"s_memtime s[{T1}:{T2}]")
-            a("s_waitcnt lgkmcnt(0)")
-            a(f"v_mov_b32 v{NV - 1}, s{T1}")
-
-    def tick_end(acc):
-        if stats:
-            a(f"s_memtime s[{T1}:{T2}]")
-            a("s_waitcnt lgkmcnt(0)")
-            a(f"v_sub_u32 v{NV - 1}, s{T1}, v{NV - 1}")
-            a(f"v_add_u32 v{acc}, v{acc}, v{NV - 1}")
-
     hid = {}
     for o, op in enumerate(OPS):
         for f, form in enumerate(FORMS):
             hid[f"{op}_{form}"] = o * 8 + f
     hid["push_c"], hid["push_v"], hid["end"], hid["skip"], hid["next"] = 32, 33, 34, 35, 36
-    NH = 37
+    assert NHF == 37
+
+    # cycle accounting (stats build only); counters live in the top operand-stack slot
+    A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
+
+    def tick_begin():
+        if stats:
+            a(f"s_memtime s[{T1}:{T2}]")
+            a("s_waitcnt lgkmcnt(0)")
+            a(f"v_mov_b32 v{A_TICK}, s{T1}")
+
+    def tick_end(acc):
+        if stats:
+            a(f"s_memtime s[{T1}:{T2}]")
+            a("s_waitcnt lgkmcnt(0)")
+            a(f"v_sub_u32 v{A_TICK}, s{T1}, v{A_TICK}")
+            a(f"v_add_u32 v{acc}, v{acc}, v{A_TICK}")
 
     def epilogue():
         a(f"s_add_u32 s{sJ}, s{sJ}, 4")
         a(f"s_mov_b32 m0, s{sJ}")
         a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
 
-    def prefetch_pc():
-        a(f"s_movrels_b32 s{sPC}, s{W + 4}")
-
-    def load_var(bank, sreg, vaddr):
-        a(f"v_add_u32 v{vaddr}, s{sreg}, v2")
+    def read_bank(bank, vaddr):
         for g in range(G):
             a(f"ds_read_b128 v[{bank + 4 * g}:{bank + 4 * g + 3}], v{vaddr}" + (f" offset:{1024 * g}" if g else ""))
+
+    def entry():
+        """common head of a handler: address of the next handler and LDS offset of the next instruction's variable"""
+        a(f"s_movrels_b32 s{sPC}, s{W + 4}")
+        a(f"s_movrels_b32 {PF}, s{W + 5}")
+
+    def prefetch(nxt):
+        a(f"v_add_u32 v4, {PF}, v2")
+        read_bank(nxt, 4)
+
+    def warm(sreg):
+        """pull the first block of the four records starting at tree `sreg` into L2 (result discarded)"""
+        a(f"s_mul_hi_u32 s{T2}, {sreg}, s19")
+        a(f"s_mul_i32 s{T1}, {sreg}, s19")
+        a(f"s_add_u32 s{T1}, s{T1}, s8")
+        a(f"s_addc_u32 s{T2}, s{T2}, s9")
+        a(f"global_load_dwordx4 v[14:17], v13, s[{T1}:{T2}]")
+
+    def grab():
+        a("s_mov_b64 exec, 1")
+        a("v_mov_b32 v9, s16")
+        a("global_atomic_add v12, v[10:11], v9, off sc0")
+        a("s_mov_b64 exec, -1")
 
     # ------------------------------------------------------------------ prologue
     a("v_mbcnt_lo_u32_b32 v0, -1, 0")
     a("v_mbcnt_hi_u32_b32 v0, -1, v0")
     a("v_lshlrev_b32 v1, 4, v0")
-    a("v_add_u32 v1, %[ldsx], v1")
-    a("v_lshlrev_b32 v15, 2, v0")
+    a(f"v_add_u32 v1, {END_}, v1")               # END_ carries the LDS base of X on entry
     a("v_mov_b32 v8, 0x7fc00000")
     a("s_load_dwordx4 s[8:11], %[karg], 0x0")    # program records, fitness
-    a(f"s_load_dwordx2 s[{P3}:{P4}], %[karg], 0x10")  # work counter
+    a(f"s_load_dwordx2 s[{P3_}:{P4_}], %[karg], 0x10")  # work counter
     a("s_load_dwordx8 s[12:19], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, query, record stride
     a("s_waitcnt lgkmcnt(0)")
-    a(f"v_mov_b32 v10, s{P3}")
-    a(f"v_mov_b32 v11, s{P4}")
-    a("v_mov_b32 v13, s16")
+    a(f"v_mov_b32 v10, s{P3_}")
+    a(f"v_mov_b32 v11, s{P4_}")
     a("s_mul_i32 s14, s14, s15")
-    a(f"s_mul_i32 s14, s14, {G * 1024}")  # s14 = LDS distance from X to y
-    a(f"s_load_dwordx4 s[{P1}:{P4}], %[karg], 0x48")  # static trees per workgroup, first dynamic tree, LDS offset of the queue head
+    a(f"s_mul_i32 s14, s14, {G * 1024}")          # s14 = LDS distance from X to y
+    a("v_lshrrev_b32 v13, 4, v0")                 # warm-up offset: 16 lanes per record, 16 bytes per lane
+    a("v_mul_lo_u32 v13, v13, s19")
+    a("v_and_b32 v9, 15, v0")
+    a("v_lshl_add_u32 v13, v9, 4, v13")
+    a(f"s_load_dwordx4 s[{P1_}:{P4_}], %[karg], 0x48")  # static trees per workgroup, first dynamic tree, waves per workgroup
     a("s_waitcnt lgkmcnt(0)")
-    a(f"v_mov_b32 v21, s{P3}")                  # LDS address of the workgroup's queue head
-    a("v_add_u32 v21, %[ldsx], v21")
-    a(f"s_mul_i32 %[wgid], %[wgid], s{P1}")     # first tree of the workgroup's static share
-    a(f"s_mov_b32 %[ldsx], s{P1}")              # from here on: size of the static share
-    a(f"s_mov_b32 %[dyn], s{P2}")               # first tree of the dynamic region
+    a(f"s_mul_i32 {CUR}, {CUR}, s{P1_}")          # CUR carries the workgroup id on entry: first tree of its static share
+    a(f"s_add_u32 {END_}, {CUR}, s{P1_}")         # end of the static share
+    a(f"s_mul_i32 {STRIDE}, {STRIDE}, s16")       # STRIDE carries the wave id on entry
+    a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")        # this wave's first static batch
+    a(f"s_mul_i32 {STRIDE}, s{P3_}, s16")         # distance between two batches of one wave
+    a(f"s_mov_b32 {DYN}, s{P2_}")                 # first tree of the dynamic region
     a(f"s_getpc_b64 s[{T1}:{T2}]")
     a(f"{lab('pc')}:")
     a(f"s_add_u32 s{T1}, s{T1}, {lab('hbase')}-{lab('pc')}")
@@ -136,51 +171,43 @@ def gen(K, DEPTH, stats=False):
     a("s_endpgm")
     a(f"{lab('run')}:")
     if stats:
-        a("v_mov_b32 v22, 0")
-        a("v_mov_b32 v23, 0")
-        a(f"v_mov_b32 v{NV - 2}, 0")  # trees
-        a(f"v_mov_b32 v{NV - 3}, 0")  # dispatches
+        for r in (A_REC, A_WORK, A_TREES, A_DISP):
+            a(f"v_mov_b32 v{r}, 0")
         a(f"s_memtime s[{T1}:{T2}]")
         a("s_waitcnt lgkmcnt(0)")
-        a(f"v_mov_b32 v{NV - 4}, s{T1}")  # start tick
-    a("s_mov_b32 s18, 1")  # 1 while the workgroup's static share lasts
+        a(f"v_mov_b32 v{A_START}, s{T1}")
+    a("s_mov_b32 s18, 1")  # 1 while this wave's part of the static share lasts
+    a(f"s_cmp_lt_u32 {CUR}, {END_}")
+    a(f"s_cbranch_scc0 {lab('batch')}")
+    warm(CUR)
     # ------------------------------------------------------------------ batch loop
-    # Work distribution: every workgroup owns a contiguous static share that its waves split through an LDS
-    # counter (cheap); the rest of the population is handed out from one global counter (atomics on one
-    # address serialise at ~11 ns each, so only the load-balancing tail goes through them).
     a(f"{lab('batch')}:")
     a("s_cmp_eq_u32 s18, 0")
     a(f"s_cbranch_scc1 {lab('dyn')}")
-    tick_begin()
-    a("s_mov_b64 exec, 1")
-    a("ds_add_rtn_u32 v12, v21, v13")
-    a("s_mov_b64 exec, -1")
-    a("s_waitcnt lgkmcnt(0)")
-    tick_end(23)
-    a(f"v_readfirstlane_b32 s{sT0}, v12")
-    a(f"s_cmp_lt_u32 s{sT0}, %[ldsx]")
+    a(f"s_cmp_lt_u32 {CUR}, {END_}")
     a(f"s_cbranch_scc0 {lab('to_dyn')}")
-    a(f"s_sub_u32 s{sNB}, %[ldsx], s{sT0}")
+    a(f"s_mov_b32 s{sT0}, {CUR}")
+    a(f"s_sub_u32 s{sNB}, {END_}, s{sT0}")
     a(f"s_min_u32 s{sNB}, s{sNB}, s16")
-    a(f"s_add_u32 s{sT0}, s{sT0}, %[wgid]")
+    a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")
+    a(f"s_cmp_lt_u32 {CUR}, {END_}")
+    a(f"s_cbranch_scc0 {lab('have_batch')}")
+    warm(CUR)                                      # the records of this wave's NEXT batch
     a(f"s_branch {lab('have_batch')}")
     a(f"{lab('to_dyn')}:")
     a("s_mov_b32 s18, 0")
     tick_begin()
-    a("s_mov_b64 exec, 1")
-    a("global_atomic_add v12, v[10:11], v13, off sc0")
-    a("s_mov_b64 exec, -1")
+    grab()
     a("s_waitcnt vmcnt(0)")
-    tick_end(23)
+    tick_end(A_WORK)
     a(f"v_readfirstlane_b32 s{sT0N}, v12")
-    a(f"s_add_u32 s{sT0N}, s{sT0N}, %[dyn]")
+    a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
     a(f"{lab('dyn')}:")
     a(f"s_mov_b32 s{sT0}, s{sT0N}")
     a(f"s_cmp_ge_u32 s{sT0}, s12")
     a(f"s_cbranch_scc1 {lab('exit')}")
-    a("s_mov_b64 exec, 1")
-    a("global_atomic_add v12, v[10:11], v13, off sc0")  # the next batch, consumed at the end of this one
-    a("s_mov_b64 exec, -1")
+    grab()                                         # the next batch, consumed at the end of this one
+    warm(f"s{sT0}")
     a(f"s_sub_u32 s{sNB}, s12, s{sT0}")
     a(f"s_min_u32 s{sNB}, s{sNB}, s16")
     a(f"{lab('have_batch')}:")
@@ -201,9 +228,9 @@ def gen(K, DEPTH, stats=False):
     a(f"s_mov_b32 s{sTILE}, 0")
     a(f"s_mov_b32 s{sBLK}, 0")
     a("s_waitcnt lgkmcnt(0)")
-    tick_end(22)
+    tick_end(A_REC)
     if stats:
-        a(f"v_add_u32 v{NV - 2}, 1, v{NV - 2}")
+        a(f"v_add_u32 v{A_TREES}, 1, v{A_TREES}")
     # ------------------------------------------------------------------ tile loop (one pass of the program)
     a(f"{lab('tile')}:")
     a(f"s_mul_i32 s{T1}, s{sTILE}, {G * 1024}")
@@ -218,6 +245,8 @@ def gen(K, DEPTH, stats=False):
     a(f"s_mov_b32 s{sBLK}, 0")
     a("s_waitcnt lgkmcnt(0)")
     a(f"{lab('tile_go')}:")
+    a(f"v_add_u32 v4, s{W + 1}, v2")              # variable operand of the first instruction -> bank 0
+    read_bank(P[0], 4)
     a(f"s_set_gpr_idx_on s{sJ}, 0")  # J == 0: enables indexing with no operand selected, M0 = 0
     a(f"s_mov_b32 s{sPC}, s{W}")
     a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
@@ -226,9 +255,9 @@ def gen(K, DEPTH, stats=False):
     a(".p2align 8")
     a(f"{lab('hbase')}:")
 
-    def begin(name):
-        a(f".org {lab('hbase')}+{SLOT * hid[name]}")  # fails to assemble if the previous handler overflowed its slot
-        a(f"{lab('h_' + name)}:")
+    def begin(name, fl):
+        a(f".org {lab('hbase')}+{SLOT * (fl * NHF + hid[name])}")  # fails to assemble if the previous handler overflowed its slot
+        a(f"{lab(f'h{fl}_' + name)}:")
 
     MODE = {"SRC0": 1, "SRC1": 2, "SRC2": 4, "DST": 8}
 
@@ -237,112 +266,117 @@ def gen(K, DEPTH, stats=False):
         imm = (mode_bits << 12) + off
         a(f"s_add_u32 m0, s{sH}, {hex(imm & 0xFFFFFFFF)}")
 
-    def arith(op, form):
+    def wait_cur():
+        a(f"s_waitcnt lgkmcnt({G})")  # everything but the prefetch just issued has landed (LDS returns in order)
+
+    def arith(op, form, fl):
+        cur, nxt = P[fl], P[1 - fl]
         ins = {"add": "v_add_f32", "sub": "v_sub_f32", "mul": "v_mul_f32"}[op]
         rev = {"add": "v_add_f32", "sub": "v_subrev_f32", "mul": "v_mul_f32"}[op]
-        begin(f"{op}_{form}")
-        prefetch_pc()
+        begin(f"{op}_{form}", fl)
+        entry()
         if form == "SS":
+            prefetch(nxt)
             m0_stack(MODE["SRC0"] | MODE["SRC1"] | MODE["DST"], -2 * K)
             for k in range(K):
                 a(f"{ins} v{S0 + k}, v{S0 + K + k}, v{S0 + k}")
             a(f"s_sub_u32 s{sH}, s{sH}, {K}")
         elif form == "SV":  # stack top (left) op variable
-            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
-            load_var(TB, sBop, 4)
+            prefetch(nxt)
             m0_stack(MODE["SRC0"] | MODE["DST"], -K)
-            a("s_waitcnt lgkmcnt(0)")
+            wait_cur()
             for k in range(K):
-                a(f"{ins} v{S0 + k}, v{S0 + k}, v{TB + k}")
+                a(f"{ins} v{S0 + k}, v{S0 + k}, v{cur + k}")
         elif form == "VS":  # variable (left) op stack top
-            a(f"s_movrels_b32 s{sA}, s{W + 2}")
-            load_var(TA, sA, 4)
+            prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
-            a("s_waitcnt lgkmcnt(0)")
+            wait_cur()
             for k in range(K):
-                a(f"{ins} v{S0 + k}, v{TA + k}, v{S0 + k}")
+                a(f"{ins} v{S0 + k}, v{cur + k}, v{S0 + k}")
         elif form == "SC":  # stack top op constant
             a(f"s_movrels_b32 s{sBop}, s{W + 3}")
+            prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
             for k in range(K):
                 a(f"{rev} v{S0 + k}, s{sBop}, v{S0 + k}")
         elif form == "CS":  # constant op stack top
             a(f"s_movrels_b32 s{sA}, s{W + 2}")
+            prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
             for k in range(K):
                 a(f"{ins} v{S0 + k}, s{sA}, v{S0 + k}")
-        elif form == "VV":
-            a(f"s_movrels_b64 s[{sA}:{sBop}], s[{W + 2}:{W + 3}]")
-            load_var(TA, sA, 4)
-            load_var(TB, sBop, 5)
+        elif form == "VV":  # a was prefetched, b is read here
+            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
+            a(f"v_add_u32 v5, s{sBop}, v2")
+            read_bank(T, 5)
+            prefetch(nxt)
             m0_stack(MODE["DST"], 0)
-            a("s_waitcnt lgkmcnt(0)")
+            wait_cur()
             for k in range(K):
-                a(f"{ins} v{S0 + k}, v{TA + k}, v{TB + k}")
+                a(f"{ins} v{S0 + k}, v{cur + k}, v{T + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         elif form == "VC":  # variable op constant
-            a(f"s_movrels_b64 s[{sA}:{sBop}], s[{W + 2}:{W + 3}]")
-            load_var(TA, sA, 4)
+            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
+            prefetch(nxt)
             m0_stack(MODE["DST"], 0)
-            a("s_waitcnt lgkmcnt(0)")
+            wait_cur()
             for k in range(K):
-                a(f"{rev} v{S0 + k}, s{sBop}, v{TA + k}")
+                a(f"{rev} v{S0 + k}, s{sBop}, v{cur + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         elif form == "CV":  # constant op variable
-            a(f"s_movrels_b64 s[{sA}:{sBop}], s[{W + 2}:{W + 3}]")
-            load_var(TB, sBop, 4)
+            a(f"s_movrels_b32 s{sA}, s{W + 2}")
+            prefetch(nxt)
             m0_stack(MODE["DST"], 0)
-            a("s_waitcnt lgkmcnt(0)")
+            wait_cur()
             for k in range(K):
-                a(f"{ins} v{S0 + k}, s{sA}, v{TB + k}")
+                a(f"{ins} v{S0 + k}, s{sA}, v{cur + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         epilogue()
 
-    def div_stub(form):
-        """gather a -> TA, b -> TB, set the scatter index of the result, adjust H, go to the shared body"""
-        begin(f"div_{form}")
-        prefetch_pc()
+    DIV_KIND = {"SS": "Tc", "SV": "Tc", "VS": "cT", "SC": "Tc", "CS": "Tc", "VV": "cT", "VC": "cT", "CV": "Tc"}
+
+    def div_stub(form, fl):
+        """put a into x and b into y (one of them the current operand bank, the other T), set the scatter index of the
+        result, adjust H, go to the division body for this bank assignment"""
+        cur, nxt = P[fl], P[1 - fl]
+        kind = DIV_KIND[form]
+        x, y = (T, cur) if kind == "Tc" else (cur, T)
+        begin(f"div_{form}", fl)
+        entry()
         la, rb = form[0], form[1]
+        if la == "C":
+            a(f"s_movrels_b32 s{sA}, s{W + 2}")
+        if rb == "C" or form == "VV":
+            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
+        if form == "VV":
+            a(f"v_add_u32 v5, s{sBop}, v2")
+            read_bank(T, 5)
+        prefetch(nxt)
+        wait_cur()  # the current bank is overwritten or read below: its (possibly unused) prefetch must have landed
         if form == "SS":
             m0_stack(MODE["SRC0"], -2 * K)
             for k in range(K):
-                a(f"v_mov_b32 v{TA + k}, v{S0 + K + k}")
-                a(f"v_mov_b32 v{TB + k}, v{S0 + k}")
+                a(f"v_mov_b32 v{x + k}, v{S0 + K + k}")
+                a(f"v_mov_b32 v{y + k}, v{S0 + k}")
             a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - 2 * K)}")
             a(f"s_sub_u32 s{sH}, s{sH}, {K}")
-            a("s_mov_b32 m0, 0")
+        elif la == "S" or rb == "S":
+            m0_stack(MODE["SRC0"], -K)
+            bank = x if la == "S" else y
+            for k in range(K):
+                a(f"v_mov_b32 v{bank + k}, v{S0 + k}")
+            a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
         else:
-            need_a = la != "S"
-            need_b = rb != "S"
-            if need_a and need_b:
-                a(f"s_movrels_b64 s[{sA}:{sBop}], s[{W + 2}:{W + 3}]")
-            elif need_a:
-                a(f"s_movrels_b32 s{sA}, s{W + 2}")
-            else:
-                a(f"s_movrels_b32 s{sBop}, s{W + 3}")
-            if la == "V":
-                load_var(TA, sA, 4)
-            if rb == "V":
-                load_var(TB, sBop, 5)
-            if la == "S" or rb == "S":
-                m0_stack(MODE["SRC0"], -K)
-                bank = TA if la == "S" else TB
-                for k in range(K):
-                    a(f"v_mov_b32 v{bank + k}, v{S0 + k}")
-                a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
-            else:
-                a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
-                a(f"s_add_u32 s{sH}, s{sH}, {K}")
-            a("s_mov_b32 m0, 0")
-            if la == "C":
-                for k in range(K):
-                    a(f"v_mov_b32 v{TA + k}, s{sA}")
-            if rb == "C":
-                for k in range(K):
-                    a(f"v_mov_b32 v{TB + k}, s{sBop}")
-            if la == "V" or rb == "V":
-                a("s_waitcnt lgkmcnt(0)")
-        a(f"s_branch {lab('divbody')}")
+            a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
+            a(f"s_add_u32 s{sH}, s{sH}, {K}")
+        a("s_mov_b32 m0, 0")
+        if la == "C":
+            for k in range(K):
+                a(f"v_mov_b32 v{x + k}, s{sA}")
+        if rb == "C":
+            for k in range(K):
+                a(f"v_mov_b32 v{y + k}, s{sBop}")
+        a(f"s_branch {lab(f'divbody_{kind}{fl}')}")
 
     def div_rows(xs, ys, qs):
         """IEEE division rows: q = (y == 0) ? NaN : x / y  up to (not including) v_div_fixup (forward.cu:183-187)"""
@@ -361,59 +395,74 @@ def gen(K, DEPTH, stats=False):
             a(f"v_fma_f32 v{d3}, -v{d3}, v{d7}, v{d6}")
             a(f"v_div_fmas_f32 v{q}, v{d3}, v{d4}, v{d7}")
 
-    for op in ("add", "sub", "mul"):
+    for fl in (0, 1):
+        cur, nxt = P[fl], P[1 - fl]
+        for op in ("add", "sub", "mul"):
+            for form in FORMS:
+                arith(op, form, fl)
         for form in FORMS:
-            arith(op, form)
-    for form in FORMS:
-        div_stub(form)
+            div_stub(form, fl)
+        # push constant (folded constant subtree, or a tree that is a single constant)
+        begin("push_c", fl)
+        entry()
+        a(f"s_movrels_b32 s{sA}, s{W + 2}")
+        prefetch(nxt)
+        m0_stack(MODE["DST"], 0)
+        for k in range(K):
+            a(f"v_mov_b32 v{S0 + k}, s{sA}")
+        a(f"s_add_u32 s{sH}, s{sH}, {K}")
+        epilogue()
+        # push variable (a tree that is a single variable)
+        begin("push_v", fl)
+        entry()
+        prefetch(nxt)
+        m0_stack(MODE["DST"], 0)
+        wait_cur()
+        for k in range(K):
+            a(f"v_mov_b32 v{S0 + k}, v{cur + k}")
+        a(f"s_add_u32 s{sH}, s{sH}, {K}")
+        epilogue()
+        begin("end", fl)
+        a(f"s_branch {lab('endbody')}")
+        # a tree the compiler could not take: leave its (marked) fitness word alone
+        begin("skip", fl)
+        a("s_set_gpr_idx_off")
+        a(f"s_branch {lab('next_tree')}")
+        # continuation: the program goes on in the next 256-byte block of the record; the instruction that follows
+        # has this handler's flavour, so its variable operand is prefetched into `cur`
+        begin("next", fl)
+        a(f"s_add_u32 s{sBLK}, s{sBLK}, 1")
+        a(f"s_lshl_b32 s{T1}, s{sBLK}, 8")
+        a(f"s_add_u32 s{T1}, s{sREC}, s{T1}")
+        a(f"s_addc_u32 s{T2}, s{sREC + 1}, 0")
+        for i in range(4):
+            a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{T1}:{T2}], {hex(64 * i)}")
+        a(f"s_mov_b32 s{sJ}, 0")
+        a("s_mov_b32 m0, 0")
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"v_add_u32 v4, s{W + 1}, v2")
+        read_bank(cur, 4)
+        a(f"s_mov_b32 s{sPC}, s{W}")
+        a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
+    a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
-    # push constant (folded constant subtree, or a tree that is a single constant)
-    begin("push_c")
-    prefetch_pc()
-    a(f"s_movrels_b32 s{sA}, s{W + 2}")
-    m0_stack(MODE["DST"], 0)
-    for k in range(K):
-        a(f"v_mov_b32 v{S0 + k}, s{sA}")
-    a(f"s_add_u32 s{sH}, s{sH}, {K}")
-    epilogue()
-    # push variable (a tree that is a single variable; H == 0)
-    begin("push_v")
-    prefetch_pc()
-    a(f"s_movrels_b32 s{sA}, s{W + 2}")
-    load_var(S0, sA, 4)
-    a(f"s_add_u32 s{sH}, s{sH}, {K}")
-    a("s_waitcnt lgkmcnt(0)")
-    epilogue()
-
-    # end of the program: fold this tile's errors into the accumulator
-    begin("end")
-    a(f"s_branch {lab('endbody')}")
-    # a tree the compiler could not take: leave its (marked) fitness word alone
-    begin("skip")
-    a("s_set_gpr_idx_off")
-    a(f"s_branch {lab('next_tree')}")
-    # continuation: the program goes on in the next 256-byte block of the record
-    begin("next")
-    a(f"s_add_u32 s{sBLK}, s{sBLK}, 1")
-    a(f"s_lshl_b32 s{T1}, s{sBLK}, 8")
-    a(f"s_add_u32 s{T1}, s{sREC}, s{T1}")
-    a(f"s_addc_u32 s{T2}, s{sREC + 1}, 0")
-    for i in range(4):
-        a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{T1}:{T2}], {hex(64 * i)}")
-    a(f"s_mov_b32 s{sJ}, 0")
-    a("s_mov_b32 m0, 0")
-    a("s_waitcnt lgkmcnt(0)")
-    a(f"s_mov_b32 s{sPC}, s{W}")
-    a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
-    a(f".org {lab('hbase')}+{SLOT * NH}")
+    # shared division bodies: K rows, then the scatter through v_div_fixup with an indexed destination
+    for fl in (0, 1):
+        for kind in ("Tc", "cT"):
+            x, y = (T, P[fl]) if kind == "Tc" else (P[fl], T)
+            a(f"{lab(f'divbody_{kind}{fl}')}:")
+            div_rows([x + k for k in range(K)], [y + k for k in range(K)], [Q + k for k in range(K)])
+            a(f"s_mov_b32 m0, s{sDST}")
+            for k in range(K):
+                a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
+            epilogue()
 
     # end of the program: fold this tile's errors into the accumulator
     a(f"{lab('endbody')}:")
     a("s_set_gpr_idx_off")
     if stats:
-        a(f"v_add_u32 v{NV - 3}, s{sJ}, v{NV - 3}")
-    for g in range(G):
-        a(f"ds_read_b128 v[{TB + 4 * g}:{TB + 4 * g + 3}], v3" + (f" offset:{1024 * g}" if g else ""))
+        a(f"v_add_u32 v{A_DISP}, s{sJ}, v{A_DISP}")
+    read_bank(T, 3)
     a(f"s_add_u32 s{T1}, s{sTILE}, 1")
     a(f"s_cmp_lt_u32 s{T1}, s15")
     a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile
@@ -423,11 +472,12 @@ def gen(K, DEPTH, stats=False):
     a(f"s_cbranch_scc1 {lab('end_full')}")
     # ragged tile: rows >= D contribute nothing
     a(f"s_mul_i32 s{T2}, s{sTILE}, {256 * G}")
+    a("v_lshlrev_b32 v5, 2, v0")
     for k in range(K):
         g, q = divmod(k, 4)
         a(f"s_add_u32 s{T4}, s{T2}, {g * 256 + q}")
-        a(f"v_add_u32 v4, s{T4}, v15")
-        a(f"v_sub_f32 v9, v{TB + k}, v{S0 + k}")
+        a(f"v_add_u32 v4, s{T4}, v5")
+        a(f"v_sub_f32 v9, v{T + k}, v{S0 + k}")
         a("v_cmp_gt_u32 vcc, s13, v4")
         a("s_bitcmp0_b32 s17, 0")
         a(f"s_cbranch_scc1 {lab(f'rag_abs{k}')}")
@@ -441,13 +491,13 @@ def gen(K, DEPTH, stats=False):
     a("s_bitcmp0_b32 s17, 0")
     a(f"s_cbranch_scc1 {lab('end_abs')}")
     for k in range(K):
-        a(f"v_sub_f32 v9, v{TB + k}, v{S0 + k}")
+        a(f"v_sub_f32 v9, v{T + k}, v{S0 + k}")
         a("v_mul_f32 v9, v9, v9")
         a("v_add_f32 v6, v6, v9")
     a(f"s_branch {lab('end_acc')}")
     a(f"{lab('end_abs')}:")
     for k in range(K):
-        a(f"v_sub_f32 v9, v{TB + k}, v{S0 + k}")
+        a(f"v_sub_f32 v9, v{T + k}, v{S0 + k}")
         a("v_add_f32_e64 v6, v6, |v9|")
     a(f"{lab('end_acc')}:")
     a(f"s_mov_b32 s{sTILE}, s{T1}")
@@ -468,15 +518,15 @@ def gen(K, DEPTH, stats=False):
     a(f"s_add_u32 s{sB}, s{sB}, 1")
     a(f"s_cmp_lt_u32 s{sB}, s{sNB}")
     a(f"s_cbranch_scc1 {lab('tree')}")
-    # batch finished: take the prefetched grab first (the store below then never sits in front of a wait),
-    # then mean = sum / D and one coalesced store for the evaluated trees
-    a("s_cmp_eq_u32 s18, 0")
-    a(f"s_cbranch_scc0 {lab('no_grab')}")
+    # batch finished: everything outstanding has long landed (warm-up load, the next dynamic grab); take the grab
+    # first, then mean = sum / D and one coalesced store for the evaluated trees
     tick_begin()
     a("s_waitcnt vmcnt(0)")
-    tick_end(23)
+    tick_end(A_WORK)
+    a("s_cmp_eq_u32 s18, 0")
+    a(f"s_cbranch_scc0 {lab('no_grab')}")
     a(f"v_readfirstlane_b32 s{sT0N}, v12")
-    a(f"s_add_u32 s{sT0N}, s{sT0N}, %[dyn]")
+    a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
     a(f"{lab('no_grab')}:")
     a(f"s_cmp_eq_u64 s[{sOK}:{sOK + 1}], 0")
     a(f"s_cbranch_scc1 {lab('batch')}")
@@ -494,32 +544,24 @@ def gen(K, DEPTH, stats=False):
     a(f"v_fma_f32 v{d3}, -v{d3}, v{d7}, v{d6}")
     a(f"v_div_fmas_f32 v{d3}, v{d3}, v{d4}, v{d7}")
     a(f"v_div_fixup_f32 v{d3}, v{d3}, v9, v7")
-    a(f"v_add_u32 v14, s{sT0}, v0")
-    a("v_lshlrev_b32 v14, 2, v14")
-    a(f"global_store_dword v14, v{d3}, s[10:11]")
+    a(f"v_add_u32 v4, s{sT0}, v0")
+    a("v_lshlrev_b32 v4, 2, v4")
+    a(f"global_store_dword v4, v{d3}, s[10:11]")
     a("s_mov_b64 exec, -1")
     a(f"s_branch {lab('batch')}")
-
-    # shared division body: K rows, then the scatter through v_div_fixup with an indexed destination
-    a(f"{lab('divbody')}:")
-    div_rows([TA + k for k in range(K)], [TB + k for k in range(K)], [Q + k for k in range(K)])
-    a(f"s_mov_b32 m0, s{sDST}")
-    for k in range(K):
-        a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{TB + k}, v{TA + k}")
-    epilogue()
 
     a(f"{lab('exit')}:")
     if stats:  # {record wait, work wait, trees, 4 * dispatches, wave ticks, waves} += this wave's counters
         a(f"s_memtime s[{T1}:{T2}]")
         a("s_waitcnt lgkmcnt(0)")
-        a(f"v_sub_u32 v{NV - 4}, s{T1}, v{NV - 4}")
+        a(f"v_sub_u32 v{A_START}, s{T1}, v{A_START}")
         a(f"s_load_dwordx2 s[{T1}:{T2}], %[karg], 0x58")
         a("s_waitcnt lgkmcnt(0)")
         a(f"v_mov_b32 v10, s{T1}")
         a(f"v_mov_b32 v11, s{T2}")
         a("v_mov_b32 v13, 0")
         a("s_mov_b64 exec, 1")
-        for i, src in enumerate((22, 23, NV - 2, NV - 3, NV - 4, None)):
+        for i, src in enumerate((A_REC, A_WORK, A_TREES, A_DISP, A_START, None)):
             if src is None:
                 a("v_mov_b32 v12, 1")
             else:
@@ -535,13 +577,13 @@ def gen(K, DEPTH, stats=False):
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
     if K == 8 and not stats:
-        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NH}\n"
+        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
-    out += f"#define EVOGP_TC_ASM_{name}(karg_, ldsx_, wgid_, dyn_) \\\n  asm volatile( \\\n"
+    out += f"#define EVOGP_TC_ASM_{name}(karg_, wgid_, ldsx_, wave_, dyn_, pf_) \\\n  asm volatile( \\\n"
     out += "\n".join(line + " \\" for line in body.split("\n"))
     out += f'''
-    : [ldsx] "+s"(ldsx_), [wgid] "+s"(wgid_), [dyn] "+s"(dyn_) \\
+    : [cur] "+s"(wgid_), [lim] "+s"(ldsx_), [stride] "+s"(wave_), [dyn] "+s"(dyn_), [pf] "+s"(pf_) \\
     : [karg] "s"(karg_) \\
     : {clob_txt})
 '''
@@ -550,7 +592,7 @@ def gen(K, DEPTH, stats=False):
 
 if __name__ == "__main__":
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
-    for K, depth in ((8, 10), (4, 15)):
+    for K, depth in ((8, 9), (4, 15)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:
             f.write(gen(K, depth))
             if K == 8:
