@@ -197,7 +197,7 @@ def gen(K, DEPTH, stats=False):
     a(f"{lab('to_dyn')}:")
     a("s_mov_b32 s18, 0")
     tick_begin()
-    grab()
+    grab()  # (reserving this batch at kernel start instead would hand the whole dynamic region to the first waves to ask)
     a("s_waitcnt vmcnt(0)")
     tick_end(A_WORK)
     a(f"v_readfirstlane_b32 s{sT0N}, v12")
@@ -423,7 +423,7 @@ def gen(K, DEPTH, stats=False):
         a(f"s_add_u32 s{sH}, s{sH}, {K}")
         epilogue()
         begin("end", fl)
-        a(f"s_branch {lab('endbody')}")
+        a(f"s_branch {lab(f'endbody{fl}')}")
         # a tree the compiler could not take: leave its (marked) fitness word alone
         begin("skip", fl)
         a("s_set_gpr_idx_off")
@@ -457,48 +457,53 @@ def gen(K, DEPTH, stats=False):
                 a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
             epilogue()
 
-    # end of the program: fold this tile's errors into the accumulator
-    a(f"{lab('endbody')}:")
-    a("s_set_gpr_idx_off")
-    if stats:
-        a(f"v_add_u32 v{A_DISP}, s{sJ}, v{A_DISP}")
-    read_bank(T, 3)
-    a(f"s_add_u32 s{T1}, s{sTILE}, 1")
-    a(f"s_cmp_lt_u32 s{T1}, s15")
-    a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile
-    a(f"s_and_b32 s{T2}, s{T2}, 2")
-    a("s_waitcnt lgkmcnt(0)")
-    a(f"s_cmp_eq_u32 s{T2}, 0")
-    a(f"s_cbranch_scc1 {lab('end_full')}")
-    # ragged tile: rows >= D contribute nothing
-    a(f"s_mul_i32 s{T2}, s{sTILE}, {256 * G}")
-    a("v_lshlrev_b32 v5, 2, v0")
-    for k in range(K):
-        g, q = divmod(k, 4)
-        a(f"s_add_u32 s{T4}, s{T2}, {g * 256 + q}")
-        a(f"v_add_u32 v4, s{T4}, v5")
-        a(f"v_sub_f32 v9, v{T + k}, v{S0 + k}")
-        a("v_cmp_gt_u32 vcc, s13, v4")
+    # end of the program: fold this tile's errors into the accumulator.  The labels of the tile were prefetched by the
+    # last instruction of the program (the compiler gives END the LDS offset of y as its "variable"), so they sit in
+    # the current operand bank of END's flavour.
+    for fl in (0, 1):
+        Y = P[fl]
+        a(f"{lab(f'endbody{fl}')}:")
+        a("s_set_gpr_idx_off")
+        if stats:
+            a(f"v_add_u32 v{A_DISP}, s{sJ}, v{A_DISP}")
+        a(f"s_add_u32 s{T1}, s{sTILE}, 1")
+        a(f"s_cmp_lt_u32 s{T1}, s15")
+        a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile
+        a(f"s_and_b32 s{T2}, s{T2}, 2")
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"s_cmp_eq_u32 s{T2}, 0")
+        a(f"s_cbranch_scc1 {lab(f'end_full{fl}')}")
+        # ragged tile: rows >= D contribute nothing
+        a(f"s_mul_i32 s{T2}, s{sTILE}, {256 * G}")
+        a("v_lshlrev_b32 v5, 2, v0")
+        for k in range(K):
+            g, q = divmod(k, 4)
+            a(f"s_add_u32 s{T4}, s{T2}, {g * 256 + q}")
+            a(f"v_add_u32 v4, s{T4}, v5")
+            a(f"v_sub_f32 v9, v{Y + k}, v{S0 + k}")
+            a("v_cmp_gt_u32 vcc, s13, v4")
+            a("s_bitcmp0_b32 s17, 0")
+            a(f"s_cbranch_scc1 {lab(f'rag_abs{fl}_{k}')}")
+            a("v_mul_f32 v9, v9, v9")
+            a(f"{lab(f'rag_abs{fl}_{k}')}:")
+            a("v_and_b32 v9, 0x7fffffff, v9")
+            a("v_cndmask_b32 v9, 0, v9, vcc")
+            a("v_add_f32 v6, v6, v9")
+        a(f"s_branch {lab('end_acc')}")
+        a(f"{lab(f'end_full{fl}')}:")
         a("s_bitcmp0_b32 s17, 0")
-        a(f"s_cbranch_scc1 {lab(f'rag_abs{k}')}")
-        a("v_mul_f32 v9, v9, v9")
-        a(f"{lab(f'rag_abs{k}')}:")
-        a("v_and_b32 v9, 0x7fffffff, v9")
-        a("v_cndmask_b32 v9, 0, v9, vcc")
-        a("v_add_f32 v6, v6, v9")
-    a(f"s_branch {lab('end_acc')}")
-    a(f"{lab('end_full')}:")
-    a("s_bitcmp0_b32 s17, 0")
-    a(f"s_cbranch_scc1 {lab('end_abs')}")
-    for k in range(K):
-        a(f"v_sub_f32 v9, v{T + k}, v{S0 + k}")
-        a("v_mul_f32 v9, v9, v9")
-        a("v_add_f32 v6, v6, v9")
-    a(f"s_branch {lab('end_acc')}")
-    a(f"{lab('end_abs')}:")
-    for k in range(K):
-        a(f"v_sub_f32 v9, v{T + k}, v{S0 + k}")
-        a("v_add_f32_e64 v6, v6, |v9|")
+        a(f"s_cbranch_scc1 {lab(f'end_abs{fl}')}")
+        for k in range(K):
+            a(f"v_sub_f32 v9, v{Y + k}, v{S0 + k}")
+            a("v_mul_f32 v9, v9, v9")
+            a("v_add_f32 v6, v6, v9")
+        a(f"s_branch {lab('end_acc')}")
+        a(f"{lab(f'end_abs{fl}')}:")
+        for k in range(K):
+            a(f"v_sub_f32 v9, v{Y + k}, v{S0 + k}")
+            a("v_add_f32_e64 v6, v6, |v9|")
+        if fl == 0:
+            a(f"s_branch {lab('end_acc')}")
     a(f"{lab('end_acc')}:")
     a(f"s_mov_b32 s{sTILE}, s{T1}")
     a(f"s_cmp_lt_u32 s{sTILE}, s15")
