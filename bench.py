@@ -189,10 +189,12 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "sr_fast_kernel (+ sr_general_kernel for marked trees)",
+                "kernel": "tree_SR_fitness = tc_compile_kernel + sr_tc_kernel<8> (+ the two marked-tree follow-ups); launch_ms covers "
+                          "the whole call, HIP events on the launch stream",
                 "launch_ms": launch_s * 1000.0, "algorithmic_bytes": alg_bytes,
-                "note": "stack-machine interpreter: ~0.16 algorithmic B per tree-eval at D=1024, issue-bound not HBM-bound "
-                        "(DESIGN.md); lane-node-evals/s is the meaningful utilisation figure",
+                "note": "threaded-code interpreter: ~0.16 algorithmic B per tree-eval at D=1024, bound by the VALU work of the "
+                        "IEEE divisions (~54 clocks per row) and per-instruction latency, not by HBM (DESIGN.md section 5); "
+                        "traffic = FETCH_SIZE + WRITE_SIZE of the call from profiles/pmc_latest.json",
             },
         }
         if not args.no_cpu_baseline and n == 1:

@@ -14,6 +14,6 @@ for set in "$@"; do
   python $R/scripts/rocpd_summary.py $(find $OUT/pmc$i -name "*.db" | head -1) > $OUT/32_pmc$i.md 2>&1
   rm -rf $OUT/pmc$i
   tail -3 $OUT/31_pmc$i.log | cut -c1-300
-  grep -i "sr_tc_kernel" $OUT/32_pmc$i.md | cut -c1-250
+  grep -i "sr_tc_kernel\|tc_compile\|sr_fast\|sr_general" $OUT/32_pmc$i.md | cut -c1-250
 done
 ls $OUT
