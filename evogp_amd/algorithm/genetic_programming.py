@@ -3,6 +3,8 @@
 kept (``enable_pareto_front``); it is torch-level bookkeeping."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..tree import Forest
@@ -54,9 +56,54 @@ class GeneticProgramming:
             f"fitness shape should be ({self.forest.pop_size}, ), but got {fitness.shape}")
         if self.enable_pareto_front:
             self.pareto_front.update(fitness, self.forest)
+        if self._native_default_ok():
+            return self._native_default_step(fitness)
         elite_indices, survivor_indices = self.selection(self.forest, fitness)
         offspring = self.crossover(forest=self.forest, survivor_indices=survivor_indices,
                                    target_cnt=self.pop_size - elite_indices.shape[0], fitness=fitness)
         offspring = self.mutation(offspring)
         self.forest = self.forest[elite_indices] + offspring  # elites first (genetic_programming.py:122)
+        return self.forest
+
+    # ---- fused default step ------------------------------------------------------------
+    def _native_default_ok(self) -> bool:
+        """The three default operators on a device forest: one sort, one randint, masked donor generation and ONE
+        breeding pass instead of ~90 small launches and two host syncs (same distribution of offspring; the random
+        words come from one torch.randint instead of the reference's seven draws).  EVOGP_NATIVE_STEP=0 disables it."""
+        from .crossover import DefaultCrossover
+        from .mutation import DefaultMutation
+        from .selection import DefaultSelection
+
+        if os.environ.get("EVOGP_NATIVE_STEP", "1") == "0":
+            return False
+        if type(self.selection) is not DefaultSelection or type(self.crossover) is not DefaultCrossover \
+                or type(self.mutation) is not DefaultMutation:
+            return False
+        f = self.forest
+        if not f.batch_node_value.is_cuda or self.mutation.descriptor.max_tree_len != f.max_tree_len:
+            return False
+        n_elite, n_surv = self.selection.counts(f.pop_size)
+        return 0 <= n_elite < f.pop_size and 0 < n_surv <= f.pop_size
+
+    def _native_default_step(self, fitness: torch.Tensor) -> Forest:
+        f = self.forest
+        dev = f.batch_node_value.device
+        pop, L = f.pop_size, f.max_tree_len
+        n_elite, n_surv = self.selection.counts(pop)
+        n_new = pop - n_elite
+        order = torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv)].to(torch.int32).contiguous()
+        rnd = torch.randint(0, 2**31 - 1, (6, n_new), dtype=torch.int32, device=dev)
+        below = int(min(max(self.mutation.mutation_rate, 0.0), 1.0) * (2**31 - 1))
+        d = self.mutation.descriptor
+        try:
+            keys = torch.randint(low=0, high=1000000, size=(2,), dtype=torch.uint32, device=dev)
+        except RuntimeError:
+            keys = torch.randint(0, 1000000, (2,), device=dev).to(torch.uint32)
+        value, ntype, size = f._tensors()
+        donors = torch.ops.evogp_hip.tree_generate_masked(
+            n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
+            d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, rnd[4], below)
+        nv, nt, ns, _ = torch.ops.evogp_hip.breed_default(pop, L, n_elite, n_surv, value, ntype, size, order, rnd, below,
+                                                          *donors, False)
+        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns)
         return self.forest

@@ -1,0 +1,133 @@
+// breed.hip — the default generation step as ONE pass over the next population (gfx950).
+//
+// Fuses what  GeneticProgramming.step  does with the default operators
+// (src/evogp/algorithm/genetic_programming.py:105-124, selection/default.py:42-71, crossover/default.py:16-66,
+// mutation/default.py:32-75) after the fitness sort:
+//
+//     next[0 .. e)        = forest[order[0 .. e)]                                           elites
+//     child_i             = crossover(forest[order[r0 % s]], p = r2 % size_left,
+//                                     forest[order[r1 % s]], q = r3 % size_right)           i in [0, pop - e)
+//     next[e + i]         = r4 < mutate_below ? mutate(child_i, (r5 % 1024) % size(child_i), donor_i) : child_i
+//
+// `order` is the descending fitness order, s the number of survivors, r0..r5 six raw 31-bit random words per offspring
+// (drawn by ONE torch.randint), donor_i the tree that tree_generate produces for tree index i (evogp_hip_generate_masked
+// writes only the rows whose r4 word says "mutate").  The reference composes this from a gather of the survivors, four
+// index tensors, tree_crossover, a CPU Bernoulli mask, boolean-mask gathers and scatters, tree_generate, tree_mutate and
+// three concatenations — about 90 kernel launches and two host syncs per generation in PyTorch.  The subtree surgery is
+// the row builder of replace.hip (same fallback rules: mutation.cu:150-160,170-180,256-266,279-289); a mutated child
+// is staged in LDS between the two replacements, so every output row is written exactly once.
+//
+// One wave per output row.  HBM traffic per offspring: the live prefixes of both parents' rows, the donor (20 % of the
+// rows), one full output row.
+#include "evogp_defs.hpp"
+#include "launch.hpp"
+#include "replace_row.hpp"
+
+namespace evogp {
+
+struct BreedParams {
+    const float *v; const int16_t *t; const int16_t *s;    // current generation [pop][gp_len]
+    const int *order;                                        // [n_surv] descending fitness order
+    const int *rnd;                                          // [6][n_new] raw words in [0, 2^31 - 1)
+    const float *dv; const int16_t *dt; const int16_t *ds;  // donors [n_new][gp_len] (rows of mutating offspring only)
+    float *ov; int16_t *ot; int16_t *os;                    // next generation [pop][gp_len]
+    int *decisions;                                          // optional [n_new][6]: left, right, p, q, mutated, mutate position
+    int pop, gp_len, n_elite, n_surv, n_new;
+    unsigned mutate_below;
+};
+
+__global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char breed_lds[];
+    const int w = uni((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    // this wave's staging row: value f32[gp_len] | type i16[gp_len] | size i16[gp_len]
+    unsigned char *mine = breed_lds + (size_t)w * a.gp_len * 8;
+    float *cv = (float *)mine;
+    int16_t *ct = (int16_t *)(mine + (size_t)a.gp_len * 4);
+    int16_t *cs = ct + a.gp_len;
+    const int wave = uni((int)(blockIdx.x * (kRepBlock / 64) + w));
+    const int nwaves = gridDim.x * (kRepBlock / 64);
+    for (int n = wave; n < a.pop; n += nwaves) {
+        const size_t off = (size_t)n * a.gp_len;
+        if (n < a.n_elite) {  // elite: verbatim copy (live prefix + zero tail)
+            int e = uni(a.order[n]);
+            e = e < 0 ? 0 : (e >= a.pop ? a.pop - 1 : e);
+            const size_t eo = (size_t)e * a.gp_len;
+            const Row L{a.v + eo, a.t + eo, a.s + eo};
+            int S = uni((int)L.s[0]);
+            S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+            build_row(L, L, S, 0, 0, 0, true, a.gp_len, a.ov + off, a.ot + off, a.os + off);
+            continue;
+        }
+        const int i = n - a.n_elite;
+        const unsigned r0 = (unsigned)uni(a.rnd[i]), r1 = (unsigned)uni(a.rnd[a.n_new + i]), r2 = (unsigned)uni(a.rnd[2 * a.n_new + i]),
+                       r3 = (unsigned)uni(a.rnd[3 * a.n_new + i]), r4 = (unsigned)uni(a.rnd[4 * a.n_new + i]),
+                       r5 = (unsigned)uni(a.rnd[5 * a.n_new + i]);
+        int li = uni(a.order[r0 % (unsigned)a.n_surv]), ri = uni(a.order[r1 % (unsigned)a.n_surv]);
+        li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
+        ri = ri < 0 ? 0 : (ri >= a.pop ? a.pop - 1 : ri);
+        const size_t lo = (size_t)li * a.gp_len, ro = (size_t)ri * a.gp_len;
+        const Row L{a.v + lo, a.t + lo, a.s + lo}, R{a.v + ro, a.t + ro, a.s + ro};
+        int S = uni((int)L.s[0]), RS = uni((int)R.s[0]);
+        S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+        RS = RS < 0 ? 0 : (RS > a.gp_len ? a.gp_len : RS);
+        // positions: u % tree_size (crossover/default.py:49-58); an empty tree falls back to a copy
+        const int p = S > 0 ? (int)(r2 % (unsigned)S) : 0, q = RS > 0 ? (int)(r3 % (unsigned)RS) : 0;
+        bool fallback = S <= 0 || RS <= 0;
+        int m = 0;
+        if (!fallback) {
+            m = uni((int)R.s[q]);
+            fallback = m < 1 || q + m > a.gp_len || S + (m - uni((int)L.s[p])) > a.gp_len;  // mutation.cu:279-289
+        }
+        const bool mutating = r4 < a.mutate_below;
+        int pm = -1;
+        if (!mutating) {
+            build_row(L, R, S, p, q, m, fallback, a.gp_len, a.ov + off, a.ot + off, a.os + off);
+        } else {
+            build_row(L, R, S, p, q, m, fallback, a.gp_len, cv, ct, cs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const size_t doff = (size_t)i * a.gp_len;
+            const Row C{cv, ct, cs}, D{a.dv + doff, a.dt + doff, a.ds + doff};
+            int CS = uni((int)C.s[0]);
+            CS = CS < 0 ? 0 : (CS > a.gp_len ? a.gp_len : CS);
+            pm = CS > 0 ? (int)((r5 % (unsigned)kMaxStack) % (unsigned)CS) : 0;  // mutation/default.py:59-66
+            const int dm = uni((int)D.s[0]);
+            bool mfall = CS <= 0 || dm < 1 || dm > a.gp_len;                      // mutation.cu:150-160 (+ donor sanity)
+            if (!mfall) mfall = CS + (dm - uni((int)C.s[pm])) > a.gp_len;         // :170-180
+            build_row(C, D, CS, pm, 0, dm, mfall, a.gp_len, a.ov + off, a.ot + off, a.os + off);
+            __builtin_amdgcn_wave_barrier();  // the staging row is rewritten by this wave's next offspring
+        }
+        if (a.decisions && lane == 0) {
+            int *d = a.decisions + (size_t)i * 6;
+            d[0] = li; d[1] = ri; d[2] = p; d[3] = q; d[4] = mutating ? 1 : 0; d[5] = pm;
+        }
+    }
+}
+
+} // namespace evogp
+
+using namespace evogp;
+
+extern "C" int evogp_hip_breed_default(int pop_size, int gp_len, int n_elite, int n_surv, const float *value,
+                                       const int16_t *type, const int16_t *size, const int *order, const int *rnd,
+                                       unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                                       const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
+                                       int *decisions, evogp_stream_t stream_) {
+    if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0 || n_surv > pop_size)
+        return EVOGP_E_BADARG;
+    if (!value || !type || !size || !order || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
+    const int n_new = pop_size - n_elite;
+    if (n_new > 0 && !rnd) return EVOGP_E_NULLPTR;
+    if (mutate_below != 0 && n_new > 0 && (!donor_value || !donor_type || !donor_size)) return EVOGP_E_NULLPTR;
+    BreedParams a{value, type, size, order, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
+                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, mutate_below};
+    const DeviceInfo &dev = device_info();
+    long blocks = ((long)pop_size + (kRepBlock / 64) - 1) / (kRepBlock / 64);
+    const long cap = (long)dev.num_cus * 8 * 4;
+    if (blocks > cap) blocks = cap;
+    const size_t lds = (size_t)(kRepBlock / 64) * gp_len * 8;
+    hipLaunchKernelGGL(breed_kernel, dim3((unsigned)blocks), dim3(kRepBlock), lds, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}

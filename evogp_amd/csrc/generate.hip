@@ -37,6 +37,8 @@ struct GenParams {
     int16_t *type;
     int16_t *size;
     unsigned index_offset;
+    const int *active_word;    // optional: tree n is generated only when (unsigned)active_word[n] < active_below
+    unsigned active_below;
 };
 
 template <bool MO>
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
     __shared__ float leaf_s[kMaxFullDepth + 1];
     const int tid = threadIdx.x;
     const unsigned n = blockIdx.x * kGenBlock + tid;
-    const bool active = n < p.pop;
+    const bool active = n < p.pop && (p.active_word == nullptr || (unsigned)p.active_word[n] < p.active_below);
     if (tid < kMaxFullDepth) leaf_s[tid] = p.leaf_probs[tid];
     if (tid == kMaxFullDepth) leaf_s[tid] = 1.0f; // depths past the table are leaves
     __syncthreads();
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
     for (int l = 0; l < kWave; ++l) {
         const unsigned tn = wave_first + l;
         if (tn >= p.pop) break;
-        const unsigned len = (unsigned)__shfl((int)cnt, l, 64);
+        const unsigned len = (unsigned)__shfl(active ? (int)cnt : (int)p.gp_len, l, 64);  // rows that were skipped stay untouched
         const size_t r0 = (size_t)tn * p.gp_len;
         for (unsigned i = len + lane; i < p.gp_len; i += kWave) {
             p.value[r0 + i] = 0.0f;
@@ -141,8 +143,24 @@ extern "C" int evogp_hip_generate(unsigned pop_size, unsigned gp_len, unsigned v
     if (!(out_prob >= 0.0f && out_prob <= 1.0f) || !(const_prob >= 0.0f && const_prob <= 1.0f)) return EVOGP_E_BADARG;
     if (!keys || !depth2leaf_probs || !roulette_funcs || !const_samples || !value_res || !type_res || !size_res)
         return EVOGP_E_NULLPTR;
+    return evogp_hip_generate_masked(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys,
+                                     depth2leaf_probs, roulette_funcs, const_samples, value_res, type_res, size_res,
+                                     tree_index_offset, nullptr, 0u, stream_);
+}
+
+extern "C" int evogp_hip_generate_masked(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                         unsigned const_samples_len, float out_prob, float const_prob, const unsigned *keys,
+                                         const float *depth2leaf_probs, const float *roulette_funcs,
+                                         const float *const_samples, float *value_res, int16_t *type_res, int16_t *size_res,
+                                         unsigned tree_index_offset, const int *active_word, unsigned active_below,
+                                         evogp_stream_t stream_) {
+    if (pop_size == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len == 0 || const_samples_len == 0)
+        return EVOGP_E_BADARG;
+    if (!(out_prob >= 0.0f && out_prob <= 1.0f) || !(const_prob >= 0.0f && const_prob <= 1.0f)) return EVOGP_E_BADARG;
+    if (!keys || !depth2leaf_probs || !roulette_funcs || !const_samples || !value_res || !type_res || !size_res)
+        return EVOGP_E_NULLPTR;
     GenParams p{pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys, depth2leaf_probs,
-                roulette_funcs, const_samples, value_res, type_res, size_res, tree_index_offset};
+                roulette_funcs, const_samples, value_res, type_res, size_res, tree_index_offset, active_word, active_below};
     const unsigned blocks = (pop_size + kGenBlock - 1) / kGenBlock;
     hipStream_t stream = (hipStream_t)stream_;
     if (out_len > 1) hipLaunchKernelGGL(generate_kernel<true>, dim3(blocks), dim3(kGenBlock), 0, stream, p);

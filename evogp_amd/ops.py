@@ -13,9 +13,11 @@ ROCm builds of PyTorch dispatch HIP tensors on the ``CUDA`` key, so the implemen
 registered for ``"CUDA"``; there is deliberately no CPU implementation (the reference has none,
 torch_wrapper.cu:301) and no fallback.
 
-Two extra ops live in the ``evogp_hip`` namespace (they have no counterpart in the reference):
-``evogp_hip::tree_generate_offset`` (tree-index offset for sharded populations) and
-``evogp_hip::tree_batch_evaluate`` (non-replicating ``Forest.batch_forward``).
+Extra ops live in the ``evogp_hip`` namespace (they have no counterpart in the reference):
+``evogp_hip::tree_generate_offset`` (tree-index offset for sharded populations),
+``evogp_hip::tree_batch_evaluate`` (non-replicating ``Forest.batch_forward``),
+``evogp_hip::tree_generate_masked`` and ``evogp_hip::breed_default`` (the default generation step in two launches,
+SURVEY.md §8f N2).
 """
 from __future__ import annotations
 
@@ -67,6 +69,20 @@ torch.library.define(
 )
 
 
+torch.library.define(
+    "evogp_hip::tree_generate_masked",
+    "(int pop_size, int gp_len, int var_len, int out_len, int const_samples_len, float out_prob, float const_prob,"
+    " Tensor keys, Tensor depth2leaf_probs, Tensor roulette_funcs, Tensor const_samples, int tree_index_offset,"
+    " Tensor active_word, int active_below) -> (Tensor value, Tensor node_type, Tensor subtree_size)",
+)
+torch.library.define(
+    "evogp_hip::breed_default",
+    "(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
+    " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
+    " bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)",
+)
+
+
 # ---- helpers ----------------------------------------------------------------------------------
 def _check(cond: bool, msg: str) -> None:
     if not cond:
@@ -99,7 +115,7 @@ def _keys_u32(keys: torch.Tensor) -> torch.Tensor:
 
 
 def _generate(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys, depth2leaf_probs,
-              roulette_funcs, const_samples, tree_index_offset):
+              roulette_funcs, const_samples, tree_index_offset, active_word=None, active_below=0):
     _check_sizes_common(pop_size, gp_len)
     _check(var_len > 0, f"var_len must larger than 0, but got {var_len}")
     _check(out_len > 0, f"out_len must larger than 0, but got {out_len}")
@@ -117,10 +133,13 @@ def _generate(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, c
         value = torch.empty((pop_size, gp_len), dtype=torch.float32, device=dev)
         ntype = torch.empty((pop_size, gp_len), dtype=torch.int16, device=dev)
         size = torch.empty((pop_size, gp_len), dtype=torch.int16, device=dev)
-        rc = _lib_h.evogp_hip_generate(
+        if active_word is not None:
+            _check_tensor(active_word, (pop_size,), "active_word", torch.int32)
+        rc = _lib_h.evogp_hip_generate_masked(
             pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob,
             keys.data_ptr(), depth2leaf_probs.data_ptr(), roulette_funcs.data_ptr(), const_samples.data_ptr(),
-            value.data_ptr(), ntype.data_ptr(), size.data_ptr(), tree_index_offset, _stream(dev))
+            value.data_ptr(), ntype.data_ptr(), size.data_ptr(), tree_index_offset,
+            active_word.data_ptr() if active_word is not None else None, active_below, _stream(dev))
     _lib.check(rc, "tree_generate")
     return value, ntype, size
 
@@ -136,6 +155,45 @@ def tree_generate_offset(pop_size, gp_len, var_len, out_len, const_samples_len, 
                          depth2leaf_probs, roulette_funcs, const_samples, tree_index_offset):
     return _generate(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys,
                      depth2leaf_probs, roulette_funcs, const_samples, tree_index_offset)
+
+
+@torch.library.impl("evogp_hip::tree_generate_masked", "CUDA")
+def tree_generate_masked(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys,
+                         depth2leaf_probs, roulette_funcs, const_samples, tree_index_offset, active_word, active_below):
+    """Rows of trees with active_word[n] >= active_below are left uninitialised."""
+    _check(0 <= active_below < 2**32, "active_below must fit in 32 bits")
+    return _generate(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys,
+                     depth2leaf_probs, roulette_funcs, const_samples, tree_index_offset, active_word, active_below)
+
+
+@torch.library.impl("evogp_hip::breed_default", "CUDA")
+def breed_default(pop_size, gp_len, n_elite, n_surv, value, ntype, size, order, rnd, mutate_below, donor_value,
+                  donor_type, donor_size, want_decisions):
+    _check_sizes_common(pop_size, gp_len)
+    _check(0 <= n_elite <= pop_size, f"n_elite must be in [0, pop_size], but got {n_elite}")
+    _check(0 < n_surv <= pop_size, f"n_surv must be in (0, pop_size], but got {n_surv}")
+    _check_forest(pop_size, gp_len, value, ntype, size)
+    n_new = pop_size - n_elite
+    _check(order.is_cuda and order.is_contiguous() and order.dtype == torch.int32 and order.dim() == 1
+           and order.shape[0] >= max(n_elite, n_surv), "order must be a contiguous int32 CUDA vector of >= max(n_elite, n_surv) entries")
+    _check_tensor(rnd, (6, n_new), "rnd", torch.int32)
+    _check(0 <= mutate_below < 2**32, "mutate_below must fit in 32 bits")
+    for t, nm, dt in ((donor_value, "donor_value", torch.float32), (donor_type, "donor_type", torch.int16),
+                      (donor_size, "donor_size", torch.int16)):
+        _check_tensor(t, (n_new, gp_len), nm, dt)
+    dev = value.device
+    shp = (pop_size, gp_len)
+    with torch.cuda.device(dev):
+        ov = torch.empty(shp, dtype=torch.float32, device=dev)
+        ot = torch.empty(shp, dtype=torch.int16, device=dev)
+        osz = torch.empty(shp, dtype=torch.int16, device=dev)
+        dec = torch.empty((n_new, 6) if want_decisions else (0, 6), dtype=torch.int32, device=dev)
+        rc = _lib_h.evogp_hip_breed_default(
+            pop_size, gp_len, n_elite, n_surv, value.data_ptr(), ntype.data_ptr(), size.data_ptr(), order.data_ptr(),
+            rnd.data_ptr(), mutate_below, donor_value.data_ptr(), donor_type.data_ptr(), donor_size.data_ptr(),
+            ov.data_ptr(), ot.data_ptr(), osz.data_ptr(), dec.data_ptr() if want_decisions else None, _stream(dev))
+    _lib.check(rc, "breed_default")
+    return ov, ot, osz, dec
 
 
 @torch.library.impl("evogp_cuda::tree_mutate", "CUDA")

@@ -96,6 +96,34 @@ int evogp_hip_sr_fitness(unsigned pop_size, unsigned data_points, unsigned gp_le
                          const float *variables, const float *labels, float *fitnesses,
                          unsigned kernel_type, evogp_stream_t stream);
 
+/* evogp_hip_generate restricted to the trees n with (unsigned)active_word[n] < active_below (active_word == NULL: all of
+ * them).  Rows of the other trees are not touched.  Used by the fused generation step: donors are only produced for
+ * the offspring that will mutate. */
+int evogp_hip_generate_masked(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                              unsigned const_samples_len, float out_prob, float const_prob,
+                              const unsigned *keys, const float *depth2leaf_probs,
+                              const float *roulette_funcs, const float *const_samples,
+                              float *value_res, int16_t *type_res, int16_t *size_res,
+                              unsigned tree_index_offset, const int *active_word, unsigned active_below,
+                              evogp_stream_t stream);
+
+/* The default generation step in one pass (replaces the PyTorch composition of
+ * src/evogp/algorithm/genetic_programming.py:105-124 with selection/default.py, crossover/default.py and
+ * mutation/default.py):
+ *     res[0 .. n_elite)      = forest[order[0 .. n_elite)]
+ *     child_i                = crossover(forest[order[r0 % n_surv]] at r2 % size, forest[order[r1 % n_surv]] at r3 % size)
+ *     res[n_elite + i]       = r4 < mutate_below ? mutate(child_i, (r5 % 1024) % size(child_i), donor_i) : child_i
+ * order: i32[n_surv] (descending fitness order), rnd: i32[6][pop_size - n_elite] raw words in [0, 2^31 - 1),
+ * donors: [pop_size - n_elite][gp_len] (only the rows with r4 < mutate_below are read), decisions: optional
+ * i32[pop_size - n_elite][6] = {left, right, p, q, mutated, mutate position} for tests, or NULL.
+ * Fallback rules of the subtree replacement: mutation.cu:150-160,170-180,256-266,279-289. */
+int evogp_hip_breed_default(int pop_size, int gp_len, int n_elite, int n_surv,
+                            const float *value, const int16_t *type, const int16_t *size,
+                            const int *order, const int *rnd, unsigned mutate_below,
+                            const float *donor_value, const int16_t *donor_type, const int16_t *donor_size,
+                            float *value_res, int16_t *type_res, int16_t *size_res,
+                            int *decisions, evogp_stream_t stream);
+
 /* Non-replicating batch evaluation (replaces the repeat_interleave + tree_evaluate
  * composition of src/evogp/tree/forest.py:143-176): results[t][d][:] = tree_t(variables[d][:]),
  * variables: f32[D][var_len], results: f32[pop][D][out_len]. */

@@ -91,3 +91,31 @@ def batch_evaluate(value, type_, size, X, out_len):
     assert rc == 0, L.evogp_hip_error_string(rc)
     torch.cuda.synchronize()
     return res.cpu().numpy()
+
+
+def generate_masked(pop, gp_len, var_len, out_len, out_prob, const_prob, keys, d2l, rou, cs, active_word, active_below, offset=0):
+    """-> (value, type, size) with the rows of inactive trees still holding the poison pattern."""
+    k = dev(keys, np.uint32); d = dev(d2l, np.float32); r = dev(rou, np.float32); c = dev(cs, np.float32)
+    aw = dev(active_word, np.int32)
+    v, t, s = _out3(pop, gp_len)
+    rc = L.evogp_hip_generate_masked(pop, gp_len, var_len, out_len, c.shape[0], out_prob, const_prob, k.data_ptr(), d.data_ptr(),
+                                     r.data_ptr(), c.data_ptr(), v.data_ptr(), t.data_ptr(), s.data_ptr(), offset,
+                                     aw.data_ptr(), int(active_below), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    return _np3(v, t, s)
+
+
+def breed_default(value, type_, size, order, rnd, mutate_below, n_elite, n_surv, dvalue, dtype_, dsize):
+    """-> ((value, type, size) of the next generation, decisions int32[n_new][6])"""
+    pop, gp_len = value.shape
+    n_new = pop - n_elite
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(order, np.int32), dev(rnd, np.int32)]
+    d = [dev(dvalue, np.float32), dev(dtype_, np.int16), dev(dsize, np.int16)]
+    v, t, s = _out3(pop, gp_len)
+    dec = torch.full((n_new, 6), -9, dtype=torch.int32, device=DEV)
+    rc = L.evogp_hip_breed_default(pop, gp_len, n_elite, n_surv, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                   a[3].data_ptr(), a[4].data_ptr(), int(mutate_below), d[0].data_ptr(), d[1].data_ptr(),
+                                   d[2].data_ptr(), v.data_ptr(), t.data_ptr(), s.data_ptr(), dec.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    out = _np3(v, t, s)
+    return out, dec.cpu().numpy()

@@ -1,0 +1,118 @@
+"""GPU parity of the fused default generation step: evogp_hip_generate_masked and
+evogp_hip_breed_default through the C ABI against the oracle's generate / crossover / mutate composed the way
+GeneticProgramming.step composes them (genetic_programming.py:105-124), on explicit random words."""
+import numpy as np
+import pytest
+
+from helpers import ARITH, ALLF, assert_forest_equal, depth2leaf, roulette_uniform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gpu_capi
+
+    return gpu_capi
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle.pyoracle import Oracle
+
+    return Oracle("port")
+
+
+def _expected(oracle, forest, order, rnd, below, n_elite, n_surv, donors):
+    """What the reference's operators produce for these draws."""
+    v, t, s = forest
+    pop, L = v.shape
+    n_new = pop - n_elite
+    sizes = s[:, 0].astype(np.int64)
+    r = rnd.astype(np.int64)
+    li = order[r[0] % n_surv]
+    ri = order[r[1] % n_surv]
+    p = (r[2] % sizes[li]).astype(np.int32)
+    q = (r[3] % sizes[ri]).astype(np.int32)
+    child = [a.copy() for a in oracle.crossover(v, t, s, li.astype(np.int32), ri.astype(np.int32), p, q)]
+    mut = r[4] < below
+    pm = np.full(n_new, -1, np.int32)
+    if mut.any():
+        cs = child[2][mut, 0].astype(np.int64)
+        pm_m = ((r[5][mut] % 1024) % cs).astype(np.int32)
+        pm[mut] = pm_m
+        res = oracle.mutate(child[0][mut], child[1][mut], child[2][mut], pm_m, donors[0][mut], donors[1][mut], donors[2][mut])
+        for a, b in zip(child, res):
+            a[mut] = b
+    elite = order[:n_elite]
+    out = tuple(np.concatenate([src[elite], ch]) for src, ch in zip((v, t, s), child))
+    dec = np.stack([li, ri, p, q, mut.astype(np.int64), pm], axis=1).astype(np.int32)
+    return out, dec
+
+
+@pytest.mark.parametrize("pop,L,mlc,dmlc,funcs,rate,elite_rate,surv_rate", [
+    (4000, 64, 6, 3, ARITH, 0.2, 0.01, 0.3),
+    (3000, 32, 4, 3, ARITH, 1.0, 0.0, 0.5),
+    (2500, 128, 5, 4, ALLF, 0.5, 0.1, 0.05),
+    (700, 1024, 9, 5, ARITH, 0.3, 0.02, 1.0),
+    (64, 16, 3, 2, ARITH, 0.0, 0.5, 0.3),
+])
+def test_breed_default_bit_exact(g, oracle, pop, L, mlc, dmlc, funcs, rate, elite_rate, surv_rate):
+    rng = np.random.default_rng(pop + L)
+    forest = oracle.generate(pop, L, 5, 1, 0.5, 0.5, [11, 22], depth2leaf(mlc), roulette_uniform(funcs), [-1, 0, 1, 0.5])
+    n_elite, n_surv = int(pop * elite_rate), max(1, int(pop * surv_rate))
+    n_new = pop - n_elite
+    fitness = rng.normal(size=pop).astype(np.float32)
+    order = np.argsort(-fitness, kind="stable").astype(np.int32)[:max(n_elite, n_surv)]
+    rnd = rng.integers(0, 2**31 - 1, (6, n_new)).astype(np.int32)
+    below = int(rate * (2**31 - 1))
+    keys = [7, 9]
+    dargs = (n_new, L, 5, 1, 0.5, 0.5, keys, depth2leaf(dmlc), roulette_uniform(funcs), [-1, 0, 1])
+    donors = oracle.generate(*dargs)
+    got_d = g.generate_masked(*dargs, rnd[4], below)
+    act = rnd[4].astype(np.int64) < below
+    for a, b in zip(got_d, donors):
+        assert np.array_equal(a[act].view(np.uint8), b[act].view(np.uint8)), "masked generate: active rows differ from tree_generate"
+    # inactive rows keep the poison the helper put there (value NaN, type/size -7)
+    assert np.isnan(got_d[0][~act]).all() and (got_d[1][~act] == -7).all() and (got_d[2][~act] == -7).all()
+    want, want_dec = _expected(oracle, forest, order, rnd, below, n_elite, n_surv, donors)
+    # hand the kernel the masked donor rows only (the others are poison): it must not read them
+    got, dec = g.breed_default(*forest, order, rnd, below, n_elite, n_surv, *got_d)
+    assert np.array_equal(dec, want_dec), "breed: decisions differ"
+    assert_forest_equal(got, want, "breed_default")
+
+
+def test_genetic_programming_default_step_uses_the_fused_path_and_stays_valid(g):
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=4, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5,
+                              const_samples=[-1, 0, 1])
+    mdesc = desc.update(max_layer_cnt=3)
+    pop = 5000
+    forest = Forest.random_generate(pop, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
+    algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
+    assert algo._native_default_ok()
+    X = torch.rand(256, 4, device=dev) * 4 - 2
+    y = (X[:, 0] * X[:, 1] - X[:, 2]).unsqueeze(1)
+    best = []
+    for _ in range(6):
+        fit = -algo.forest.SR_fitness(X, y)
+        fit[torch.isnan(fit)] = -torch.inf
+        best.append(float(fit.max()))
+        top = algo.forest[int(torch.argmax(fit))]
+        new = algo.step(fit)
+        # the elite (best tree) survives verbatim in row 0; every row is a structurally valid tree
+        assert str(new[0]) == str(top)
+        sizes = new.batch_subtree_size[:, 0].to(torch.int64)
+        assert int(sizes.min()) >= 1 and int(sizes.max()) <= 64
+        ntype = new.batch_node_type.to(torch.int64)
+        live = torch.arange(64, device=dev)[None, :] < sizes[:, None]
+        leaf = (ntype <= 1)
+        delta = torch.where(live, torch.where(leaf, 1, -1), 0)   # binary functions only
+        assert bool((delta.sum(1) == 1).all())
+    assert best[-1] >= best[0]
