@@ -1,37 +1,33 @@
 #!/bin/bash
-# One gpurun call: smoke, GPU parity tests, bench, variant sweep, rocprofv3 kernel trace.
-# Usage (from the dev container):  gpurun --timeout 2400 -- 'bash scripts/gpu_round.sh [quick]'
+# One gpurun call that produces everything a round needs: smoke(), first-contact checks of the threaded-code path, the GPU
+# test suite, the bench line (with CPU baseline), A/B lines, a rocprofv3 kernel trace summary, cycle accounting and
+# HBM-traffic counters.  Usage (from the dev container):  gpurun --timeout 2400 -- 'bash scripts/gpu_round.sh [tag]'
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
+TAG=${1:-round}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-MODE=${1:-full}
 {
 echo "== device"; rocminfo | grep -E "Marketing Name|gfx9|Compute Unit" | head -8; nproc
 python -c "import torch;print('torch', torch.__version__, 'gpus', torch.cuda.device_count())"
 echo "== smoke"; timeout 900 python __graft_entry__.py smoke; echo "smoke rc=$?"
-} > $OUT/00_smoke.log 2>&1
-# threaded-code core: first contact under a short timeout; fall back to the C++ interpreter for the rest of the run if it misbehaves
-for DEP in 10 16; do timeout 150 python scripts/asm_smoke.py $DEP > $OUT/00_asm_smoke_$DEP.log 2>&1; echo "asm_smoke $DEP rc=$?" >> $OUT/00_asm_smoke_$DEP.log; done
-if ! grep -q ASM_SMOKE_OK $OUT/00_asm_smoke_10.log; then export EVOGP_SR_ASM=0; echo "ASM DISABLED" >> $OUT/00_asm_smoke_10.log; fi
-if [ "$MODE" != "benchonly" ]; then
-timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/01_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/01_pytest_gpu.log
-fi
-timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/02_bench.log 2>&1; echo "bench rc=$?" >> $OUT/02_bench.log
-{ for A in 0 10 16; do echo "== ASM=$A"; EVOGP_SR_ASM=$A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/02b_asm_ab.log 2>&1
-{ for A in 10 16; do EVOGP_SR_ASM=$A timeout 200 python scripts/asm_cycles.py; done; } > $OUT/05_cycles.log 2>&1
-if [ "$MODE" = "quick" ]; then ls -la $OUT; exit 0; fi
-{
-for K in 1 2 4; do for DEP in 16 32; do
-  echo "== K=$K DEPTH=$DEP"; EVOGP_SR_K=$K EVOGP_SR_DEPTH=$DEP timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline
-done; done
-echo "== structured build (no skip-uniform-regions), default K/DEPTH"
-EVOGP_HIP_LIB=$R/evogp_amd/lib/libevogp_hip_structured.so timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline
-for B in 4 8 16 32 64; do echo "== batch=$B"; EVOGP_SR_BATCH=$B timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline; done
-} > $OUT/03_sweep.log 2>&1
+} > $OUT/${TAG}_00_smoke.log 2>&1
+for K in 8 4; do timeout 240 python scripts/tc_smoke.py $K > $OUT/${TAG}_01_tc_smoke_$K.log 2>&1; echo "tc_smoke $K rc=$?" >> $OUT/${TAG}_01_tc_smoke_$K.log; done
+timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_02_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_02_pytest_gpu.log
+timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_03_bench.json 2> $OUT/${TAG}_03_bench.err; echo "bench rc=$?" >> $OUT/${TAG}_03_bench.err
+{ for A in "EVOGP_SR_ASM=3" "EVOGP_SR_ASM=10" "EVOGP_SR_ASM=0" "EVOGP_NATIVE_STEP=0"; do echo "== $A"; env $A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/${TAG}_04_ab.log 2>&1
+timeout 200 python scripts/tc_cycles.py > $OUT/${TAG}_05_cycles.json 2>/dev/null
+timeout 300 python scripts/tc_mix.py > $OUT/${TAG}_06_mix.log 2>/dev/null
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r01 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/04_rocprof.log 2>&1
-echo "rocprof rc=$?" >> $OUT/04_rocprof.log
-find $OUT/prof -name "*stats*" | head >> $OUT/04_rocprof.log
-ls -la $OUT
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o tr -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_07_rocprof.log 2>&1
+python $R/scripts/rocpd_summary.py $(find $OUT/prof_$TAG -name "*.db" | head -1) > $OUT/${TAG}_07_kernel_stats.md 2>&1
+rm -rf $OUT/prof_$TAG
+i=0
+for set in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$TAG$i -o pmc -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  python $R/scripts/rocpd_summary.py $(find $OUT/pmc_$TAG$i -name "*.db" | head -1) 2>&1 | grep -A40 "counter" | grep -i "counter\|---\|sr_tc\|tc_compile\|breed\|generate" > $OUT/${TAG}_08_pmc$i.md
+  rm -rf $OUT/pmc_$TAG$i
+done
+tail -2 $OUT/${TAG}_00_smoke.log; tail -1 $OUT/${TAG}_01_tc_smoke_8.log; tail -2 $OUT/${TAG}_02_pytest_gpu.log; cut -c1-400 $OUT/${TAG}_03_bench.json; head -6 $OUT/${TAG}_07_kernel_stats.md | cut -c1-160
