@@ -17,7 +17,7 @@
 // the row builder of replace.hip (same fallback rules: mutation.cu:150-160,170-180,256-266,279-289); a mutated child
 // is staged in LDS between the two replacements, so every output row is written exactly once.
 //
-// One wave per output row.  HBM traffic per offspring: the live prefixes of both parents' rows, the donor (20 % of the
+// HBM traffic per offspring: the live prefixes of both parents' rows, the donor (20 % of the
 // rows), one full output row.
 #include "evogp_defs.hpp"
 #include "launch.hpp"
@@ -36,6 +36,10 @@ struct BreedParams {
     unsigned mutate_below;
 };
 
+// A workgroup (4 waves) takes 64 consecutive output rows in two phases.  DECIDE: lane l of wave 0 owns row n0 + l and
+// chases the dependent loads of its decisions (random words -> order[] -> tree sizes -> subtree sizes -> donor size):
+// 64 chains in flight instead of one per wave.  BUILD: every wave builds every fourth row with all arguments ready in
+// LDS — two memory round trips per row (loads, stores) instead of six.
 __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char breed_lds[];
     const int w = uni((int)(threadIdx.x >> 6));
@@ -45,64 +49,93 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
     float *cv = (float *)mine;
     int16_t *ct = (int16_t *)(mine + (size_t)a.gp_len * 4);
     int16_t *cs = ct + a.gp_len;
-    const int wave = uni((int)(blockIdx.x * (kRepBlock / 64) + w));
-    const int nwaves = gridDim.x * (kRepBlock / 64);
-    for (int n = wave; n < a.pop; n += nwaves) {
-        const size_t off = (size_t)n * a.gp_len;
-        if (n < a.n_elite) {  // elite: verbatim copy (live prefix + zero tail)
-            int e = uni(a.order[n]);
-            e = e < 0 ? 0 : (e >= a.pop ? a.pop - 1 : e);
-            const size_t eo = (size_t)e * a.gp_len;
-            const Row L{a.v + eo, a.t + eo, a.s + eo};
-            int S = uni((int)L.s[0]);
-            S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
-            build_row(L, L, S, 0, 0, 0, true, a.gp_len, a.ov + off, a.ot + off, a.os + off);
-            continue;
+    __shared__ int dec_s[10][64];  // decisions of the chunk's 64 rows
+    const int nchunks = (a.pop + 63) >> 6;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int n0 = c << 6;
+        // ---- DECIDE (wave 0) ----
+        const int n = n0 + lane;
+        int li = 0, ri = 0, S = 0, p = 0, q = 0, m = 0, o = 0, dm = 0;
+        unsigned r5 = 0;
+        bool fallback = true, mutating = false;
+        if (w == 0 && n < a.pop) {
+            if (n < a.n_elite) {
+                li = a.order[n];
+                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
+                ri = li;
+                S = (int)a.s[(size_t)li * a.gp_len];
+                S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+            } else {
+                const int i = n - a.n_elite;
+                const unsigned r0 = (unsigned)a.rnd[i], r1 = (unsigned)a.rnd[a.n_new + i], r2 = (unsigned)a.rnd[2 * a.n_new + i],
+                               r3 = (unsigned)a.rnd[3 * a.n_new + i], r4 = (unsigned)a.rnd[4 * a.n_new + i];
+                r5 = (unsigned)a.rnd[5 * a.n_new + i];
+                li = a.order[r0 % (unsigned)a.n_surv];
+                ri = a.order[r1 % (unsigned)a.n_surv];
+                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
+                ri = ri < 0 ? 0 : (ri >= a.pop ? a.pop - 1 : ri);
+                const int16_t *ls = a.s + (size_t)li * a.gp_len, *rs = a.s + (size_t)ri * a.gp_len;
+                S = (int)ls[0];
+                int RS = (int)rs[0];
+                S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+                RS = RS < 0 ? 0 : (RS > a.gp_len ? a.gp_len : RS);
+                // positions: u % tree_size (crossover/default.py:49-58); an empty tree falls back to a copy
+                p = S > 0 ? (int)(r2 % (unsigned)S) : 0;
+                q = RS > 0 ? (int)(r3 % (unsigned)RS) : 0;
+                fallback = S <= 0 || RS <= 0;
+                if (!fallback) {
+                    m = (int)rs[q];
+                    o = (int)ls[p];
+                    fallback = m < 1 || q + m > a.gp_len || S + (m - o) > a.gp_len;  // mutation.cu:279-289
+                }
+                mutating = r4 < a.mutate_below;
+                if (mutating) dm = (int)a.ds[(size_t)i * a.gp_len];
+            }
         }
-        const int i = n - a.n_elite;
-        const unsigned r0 = (unsigned)uni(a.rnd[i]), r1 = (unsigned)uni(a.rnd[a.n_new + i]), r2 = (unsigned)uni(a.rnd[2 * a.n_new + i]),
-                       r3 = (unsigned)uni(a.rnd[3 * a.n_new + i]), r4 = (unsigned)uni(a.rnd[4 * a.n_new + i]),
-                       r5 = (unsigned)uni(a.rnd[5 * a.n_new + i]);
-        int li = uni(a.order[r0 % (unsigned)a.n_surv]), ri = uni(a.order[r1 % (unsigned)a.n_surv]);
-        li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
-        ri = ri < 0 ? 0 : (ri >= a.pop ? a.pop - 1 : ri);
-        const size_t lo = (size_t)li * a.gp_len, ro = (size_t)ri * a.gp_len;
-        const Row L{a.v + lo, a.t + lo, a.s + lo}, R{a.v + ro, a.t + ro, a.s + ro};
-        int S = uni((int)L.s[0]), RS = uni((int)R.s[0]);
-        S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
-        RS = RS < 0 ? 0 : (RS > a.gp_len ? a.gp_len : RS);
-        // positions: u % tree_size (crossover/default.py:49-58); an empty tree falls back to a copy
-        const int p = S > 0 ? (int)(r2 % (unsigned)S) : 0, q = RS > 0 ? (int)(r3 % (unsigned)RS) : 0;
-        bool fallback = S <= 0 || RS <= 0;
-        int m = 0;
-        if (!fallback) {
-            m = uni((int)R.s[q]);
-            fallback = m < 1 || q + m > a.gp_len || S + (m - uni((int)L.s[p])) > a.gp_len;  // mutation.cu:279-289
+        if (w == 0) {
+            dec_s[0][lane] = li; dec_s[1][lane] = ri; dec_s[2][lane] = S; dec_s[3][lane] = p; dec_s[4][lane] = q;
+            dec_s[5][lane] = m; dec_s[6][lane] = o; dec_s[7][lane] = dm; dec_s[8][lane] = (int)r5;
+            dec_s[9][lane] = (fallback ? 1 : 0) | (mutating ? 2 : 0);
         }
-        const bool mutating = r4 < a.mutate_below;
-        int pm = -1;
-        if (!mutating) {
-            build_row(L, R, S, p, q, m, fallback, a.gp_len, a.ov + off, a.ot + off, a.os + off);
-        } else {
-            build_row(L, R, S, p, q, m, fallback, a.gp_len, cv, ct, cs);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const size_t doff = (size_t)i * a.gp_len;
-            const Row C{cv, ct, cs}, D{a.dv + doff, a.dt + doff, a.ds + doff};
-            int CS = uni((int)C.s[0]);
-            CS = CS < 0 ? 0 : (CS > a.gp_len ? a.gp_len : CS);
-            pm = CS > 0 ? (int)((r5 % (unsigned)kMaxStack) % (unsigned)CS) : 0;  // mutation/default.py:59-66
-            const int dm = uni((int)D.s[0]);
-            bool mfall = CS <= 0 || dm < 1 || dm > a.gp_len;                      // mutation.cu:150-160 (+ donor sanity)
-            if (!mfall) mfall = CS + (dm - uni((int)C.s[pm])) > a.gp_len;         // :170-180
-            build_row(C, D, CS, pm, 0, dm, mfall, a.gp_len, a.ov + off, a.ot + off, a.os + off);
-            __builtin_amdgcn_wave_barrier();  // the staging row is rewritten by this wave's next offspring
+        __syncthreads();
+        // ---- BUILD (every wave takes every fourth row of the chunk) ----
+        const int rows = a.pop - n0 < 64 ? a.pop - n0 : 64;
+        for (int l = w; l < rows; l += kRepBlock / 64) {
+            const int nn = n0 + l;
+            const size_t off = (size_t)nn * a.gp_len;
+            const int li_ = uni(dec_s[0][l]), ri_ = uni(dec_s[1][l]), S_ = uni(dec_s[2][l]);
+            const size_t lo = (size_t)li_ * a.gp_len, ro = (size_t)ri_ * a.gp_len;
+            const Row L{a.v + lo, a.t + lo, a.s + lo}, R{a.v + ro, a.t + ro, a.s + ro};
+            const int flags = uni(dec_s[9][l]);
+            const bool fb = (flags & 1) != 0, mu = (flags & 2) != 0;
+            const int p_ = uni(dec_s[3][l]), q_ = uni(dec_s[4][l]), m_ = uni(dec_s[5][l]), o_ = uni(dec_s[6][l]);
+            int pm = -1;
+            if (!mu) {
+                build_row(L, R, S_, p_, q_, m_, fb, a.gp_len, a.ov + off, a.ot + off, a.os + off, o_);
+            } else {
+                build_row(L, R, S_, p_, q_, m_, fb, a.gp_len, cv, ct, cs, o_);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int i = nn - a.n_elite;
+                const size_t doff = (size_t)i * a.gp_len;
+                const Row C{cv, ct, cs}, D{a.dv + doff, a.dt + doff, a.ds + doff};
+                int CS = uni((int)C.s[0]);
+                CS = CS < 0 ? 0 : (CS > a.gp_len ? a.gp_len : CS);
+                const unsigned r5_ = (unsigned)uni(dec_s[8][l]);
+                pm = CS > 0 ? (int)((r5_ % (unsigned)kMaxStack) % (unsigned)CS) : 0;  // mutation/default.py:59-66
+                const int dm_ = uni(dec_s[7][l]);
+                bool mfall = CS <= 0 || dm_ < 1 || dm_ > a.gp_len;                   // mutation.cu:150-160 (+ donor sanity)
+                if (!mfall) mfall = CS + (dm_ - uni((int)C.s[pm])) > a.gp_len;       // :170-180
+                build_row(C, D, CS, pm, 0, dm_, mfall, a.gp_len, a.ov + off, a.ot + off, a.os + off);
+                __builtin_amdgcn_wave_barrier();  // the staging row is rewritten by this wave's next mutating offspring
+            }
+            if (a.decisions && lane == 0 && nn >= a.n_elite) {
+                int *d = a.decisions + (size_t)(nn - a.n_elite) * 6;
+                d[0] = li_; d[1] = ri_; d[2] = p_; d[3] = q_; d[4] = mu ? 1 : 0; d[5] = pm;
+            }
         }
-        if (a.decisions && lane == 0) {
-            int *d = a.decisions + (size_t)i * 6;
-            d[0] = li; d[1] = ri; d[2] = p; d[3] = q; d[4] = mutating ? 1 : 0; d[5] = pm;
-        }
+        __syncthreads();  // the next chunk's decisions overwrite dec_s
     }
 }
 
@@ -124,7 +157,7 @@ extern "C" int evogp_hip_breed_default(int pop_size, int gp_len, int n_elite, in
     BreedParams a{value, type, size, order, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
                   decisions, pop_size, gp_len, n_elite, n_surv, n_new, mutate_below};
     const DeviceInfo &dev = device_info();
-    long blocks = ((long)pop_size + (kRepBlock / 64) - 1) / (kRepBlock / 64);
+    long blocks = ((long)pop_size + 63) / 64;  // one workgroup per 64 rows
     const long cap = (long)dev.num_cus * 8 * 4;
     if (blocks > cap) blocks = cap;
     const size_t lds = (size_t)(kRepBlock / 64) * gp_len * 8;

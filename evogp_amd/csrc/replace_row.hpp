@@ -14,12 +14,13 @@ struct Row {
 };
 
 // Build one output row.  fallback => copy the left tree.  All arguments are wave-uniform.
+// `o_known` >= 0: size of the replaced subtree (L.s[p]) when the caller has it already, else it is read here.
 __device__ inline void build_row(const Row &L, const Row &R, int S, int p, int q, int m, bool fallback, int gp_len,
-                                 float *ov, int16_t *ot, int16_t *os) {
+                                 float *ov, int16_t *ot, int16_t *os, int o_known = -1) {
     const int lane = threadIdx.x & 63;
     int o = 0, diff = 0;
     if (fallback) { p = S; m = 0; q = 0; } // "everything is the untouched prefix"
-    else { o = uni((int)L.s[p]); diff = m - o; }
+    else { o = o_known >= 0 ? o_known : uni((int)L.s[p]); diff = m - o; }
     const int len = S + diff;
     for (int j = lane; j < gp_len; j += kWave) {
         float v = 0.0f;
