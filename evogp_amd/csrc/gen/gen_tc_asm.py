@@ -240,10 +240,12 @@ def gen(K, DEPTH, stats=False):
     a(f"s_mov_b32 s{sJ}, 0")
     a(f"s_cmp_eq_u32 s{sBLK}, 0")
     a(f"s_cbranch_scc1 {lab('tile_go')}")
+    tick_begin()
     for i in range(4):  # a program longer than one block: its first block has to come back
         a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
     a(f"s_mov_b32 s{sBLK}, 0")
     a("s_waitcnt lgkmcnt(0)")
+    tick_end(A_DISP)   # (accounting build: this slot collects the waits for program blocks after the first fetch)
     a(f"{lab('tile_go')}:")
     a(f"v_add_u32 v4, s{W + 1}, v2")              # variable operand of the first instruction -> bank 0
     read_bank(P[0], 4)
@@ -435,11 +437,16 @@ def gen(K, DEPTH, stats=False):
         a(f"s_lshl_b32 s{T1}, s{sBLK}, 8")
         a(f"s_add_u32 s{T1}, s{sREC}, s{T1}")
         a(f"s_addc_u32 s{T2}, s{sREC + 1}, 0")
+        if stats:  # T1:T2 hold the block address: park it while the tick is taken
+            a(f"s_mov_b64 s[{sA}:{sBop}], s[{T1}:{T2}]")
+            tick_begin()
+            a(f"s_mov_b64 s[{T1}:{T2}], s[{sA}:{sBop}]")
         for i in range(4):
             a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{T1}:{T2}], {hex(64 * i)}")
         a(f"s_mov_b32 s{sJ}, 0")
         a("s_mov_b32 m0, 0")
         a("s_waitcnt lgkmcnt(0)")
+        tick_end(A_DISP)
         a(f"v_add_u32 v4, s{W + 1}, v2")
         read_bank(cur, 4)
         a(f"s_mov_b32 s{sPC}, s{W}")
@@ -465,7 +472,7 @@ def gen(K, DEPTH, stats=False):
         a(f"{lab(f'endbody{fl}')}:")
         a("s_set_gpr_idx_off")
         if stats:
-            a(f"v_add_u32 v{A_DISP}, s{sJ}, v{A_DISP}")
+            pass
         a(f"s_add_u32 s{T1}, s{sTILE}, 1")
         a(f"s_cmp_lt_u32 s{T1}, s15")
         a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile

@@ -24,7 +24,7 @@ torch.cuda.synchronize()
 _lib.lib.evogp_hip_debug_set_stats(None)
 c = stats.cpu().tolist()
 rec, work, trees, disp4, ticks, waves = c[:6]
-print(json.dumps({"waves_per_launch": waves / (reps + 1), "trees_per_wave": trees / waves, "dispatches_per_tree_pass": disp4 / 4 / trees,
+print(json.dumps({"waves_per_launch": waves / (reps + 1), "trees_per_wave": trees / waves, "later_block_wait_ticks_per_tree": disp4 / trees,
                   "ticks_per_wave": ticks / waves, "frac_record_wait": rec / ticks, "frac_work_wait": work / ticks,
                   "record_wait_ticks_per_tree": rec / trees, "work_wait_ticks_per_wave": work / waves,
                   "ticks_per_tree": (ticks - work) / trees}))
