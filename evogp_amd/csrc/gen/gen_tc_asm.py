@@ -49,7 +49,7 @@ import sys
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 OPS = ("add", "sub", "mul", "div")
 SLOT = 256  # bytes per handler slot
-NHF = 37    # handlers per flavour
+NHF = 36    # handlers per flavour
 
 
 def gen(K, DEPTH, stats=False):
@@ -61,12 +61,12 @@ def gen(K, DEPTH, stats=False):
     NV = S0 + K * DEPTH
     DT = [18, 19, 20, 21, 22]
     W = 36
-    sPC, sJ, sH, sDST, sTILE, sB, sNB, sT0, sT0N, sOK, sREC, sA, sBop = 20, 22, 23, 24, 25, 26, 27, 28, 29, 30, 32, 34, 35
+    sPC, sJ, sH, sDST, sTILE, sB, sNB, sT0, sT0N, sOK, sREC, sA, sX = 20, 22, 23, 24, 25, 26, 27, 28, 29, 30, 32, 34, 35
+    sBop = sA    # an instruction carries ONE 32-bit operand (a constant, or the 16-byte-unit LDS offset of its second variable)
     T1, T2 = 100, 101
     T4 = sDST    # free outside the division stubs
-    sBLK = sT0N  # the next dynamic grab is only live between two batches
     P1_, P2_, P3_, P4_ = 20, 21, 22, 23  # prologue scratch (control registers that are not live yet)
-    CUR, END_, STRIDE, DYN, PF = "%[cur]", "%[lim]", "%[stride]", "%[dyn]", "%[pf]"
+    CUR, END_, STRIDE, DYN, PF, BASE = "%[cur]", "%[lim]", "%[stride]", "%[dyn]", "%[pf]", "%[base]"
     uid = "%="
     L = []
     a = L.append
@@ -78,8 +78,8 @@ def gen(K, DEPTH, stats=False):
     for o, op in enumerate(OPS):
         for f, form in enumerate(FORMS):
             hid[f"{op}_{form}"] = o * 8 + f
-    hid["push_c"], hid["push_v"], hid["end"], hid["skip"], hid["next"] = 32, 33, 34, 35, 36
-    assert NHF == 37
+    hid["push_c"], hid["push_v"], hid["end"], hid["skip"] = 32, 33, 34, 35
+    assert NHF == 36
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -98,7 +98,7 @@ def gen(K, DEPTH, stats=False):
             a(f"v_add_u32 v{acc}, v{acc}, v{A_TICK}")
 
     def epilogue():
-        a(f"s_add_u32 s{sJ}, s{sJ}, 4")
+        a(f"s_add_u32 s{sJ}, s{sJ}, 2")
         a(f"s_mov_b32 m0, s{sJ}")
         a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
 
@@ -108,8 +108,10 @@ def gen(K, DEPTH, stats=False):
 
     def entry():
         """common head of a handler: address of the next handler and LDS offset of the next instruction's variable"""
-        a(f"s_movrels_b32 s{sPC}, s{W + 4}")
-        a(f"s_movrels_b32 {PF}, s{W + 5}")
+        a(f"s_movrels_b32 s{sX}, s{W + 2}")                  # next word: {LDS offset / 16 of its variable, handler offset}
+        a(f"s_pack_lh_b32_b16 s{sPC}, s{sX}, {BASE}")        # handler table is 64 KiB aligned: address = {base.hi16, offset}
+        a(f"s_lshr_b32 {PF}, s{sX}, 12")
+        a(f"s_andn2_b32 {PF}, {PF}, 15")
 
     def prefetch(nxt):
         a(f"v_add_u32 v4, {PF}, v2")
@@ -159,16 +161,8 @@ def gen(K, DEPTH, stats=False):
     a(f"{lab('pc')}:")
     a(f"s_add_u32 s{T1}, s{T1}, {lab('hbase')}-{lab('pc')}")
     a(f"s_addc_u32 s{T2}, s{T2}, 0")
+    a(f"s_mov_b32 {BASE}, s{T1}")                 # 64 KiB aligned: its low half is zero
     a(f"s_mov_b32 s{sPC + 1}, s{T2}")
-    # query mode: report the handler base address and leave
-    a("s_cmp_eq_u32 s18, 0")
-    a(f"s_cbranch_scc1 {lab('run')}")
-    a(f"v_mov_b32 v4, s{T1}")
-    a(f"v_mov_b32 v5, s{T2}")
-    a("v_mov_b32 v9, 0")
-    a("global_store_dwordx2 v9, v[4:5], s[10:11]")
-    a("s_waitcnt vmcnt(0)")
-    a("s_endpgm")
     a(f"{lab('run')}:")
     if stats:
         for r in (A_REC, A_WORK, A_TREES, A_DISP):
@@ -191,15 +185,26 @@ def gen(K, DEPTH, stats=False):
     a(f"s_min_u32 s{sNB}, s{sNB}, s16")
     a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")
     a(f"s_cmp_lt_u32 {CUR}, {END_}")
-    a(f"s_cbranch_scc0 {lab('have_batch')}")
+    a(f"s_cbranch_scc0 {lab('last_static')}")
     warm(CUR)                                      # the records of this wave's NEXT batch
     a(f"s_branch {lab('have_batch')}")
+    # this was the wave's last static batch: reserve its first dynamic batch now, one batch ahead like every later
+    # one (asked for only when the static share is used up, all waves queue at the counter at the same moment:
+    # ~11 ns per same-address atomic, 45 us for 4096 waves)
+    a(f"{lab('last_static')}:")
+    grab()
+    a("s_mov_b32 s18, 2")
+    a(f"s_branch {lab('have_batch')}")
     a(f"{lab('to_dyn')}:")
+    a("s_cmp_eq_u32 s18, 2")
     a("s_mov_b32 s18, 0")
+    a(f"s_cbranch_scc1 {lab('to_dyn_got')}")
     tick_begin()
-    grab()  # (reserving this batch at kernel start instead would hand the whole dynamic region to the first waves to ask)
+    grab()  # a wave without a static batch (tiny populations)
     a("s_waitcnt vmcnt(0)")
     tick_end(A_WORK)
+    a(f"{lab('to_dyn_got')}:")
+    a("s_waitcnt vmcnt(0)")
     a(f"v_readfirstlane_b32 s{sT0N}, v12")
     a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
     a(f"{lab('dyn')}:")
@@ -226,7 +231,6 @@ def gen(K, DEPTH, stats=False):
         a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
     a("v_mov_b32 v6, 0")
     a(f"s_mov_b32 s{sTILE}, 0")
-    a(f"s_mov_b32 s{sBLK}, 0")
     a("s_waitcnt lgkmcnt(0)")
     tick_end(A_REC)
     if stats:
@@ -238,23 +242,17 @@ def gen(K, DEPTH, stats=False):
     a("v_add_u32 v3, s14, v2")
     a(f"s_mov_b32 s{sH}, 0")
     a(f"s_mov_b32 s{sJ}, 0")
-    a(f"s_cmp_eq_u32 s{sBLK}, 0")
-    a(f"s_cbranch_scc1 {lab('tile_go')}")
-    tick_begin()
-    for i in range(4):  # a program longer than one block: its first block has to come back
-        a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
-    a(f"s_mov_b32 s{sBLK}, 0")
-    a("s_waitcnt lgkmcnt(0)")
-    tick_end(A_DISP)   # (accounting build: this slot collects the waits for program blocks after the first fetch)
     a(f"{lab('tile_go')}:")
-    a(f"v_add_u32 v4, s{W + 1}, v2")              # variable operand of the first instruction -> bank 0
+    a(f"s_lshr_b32 {PF}, s{W}, 12")                # variable operand of the first instruction -> bank 0
+    a(f"s_andn2_b32 {PF}, {PF}, 15")
+    a(f"v_add_u32 v4, {PF}, v2")
     read_bank(P[0], 4)
     a(f"s_set_gpr_idx_on s{sJ}, 0")  # J == 0: enables indexing with no operand selected, M0 = 0
-    a(f"s_mov_b32 s{sPC}, s{W}")
+    a(f"s_pack_lh_b32_b16 s{sPC}, s{W}, {BASE}")
     a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
 
     # ------------------------------------------------------------------ handlers
-    a(".p2align 8")
+    a(".p2align 16")  # 64 KiB: a handler address is {high half of the table address, 16-bit offset from the program word}
     a(f"{lab('hbase')}:")
 
     def begin(name, fl):
@@ -296,20 +294,20 @@ def gen(K, DEPTH, stats=False):
             for k in range(K):
                 a(f"{ins} v{S0 + k}, v{cur + k}, v{S0 + k}")
         elif form == "SC":  # stack top op constant
-            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
+            a(f"s_movrels_b32 s{sBop}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
             for k in range(K):
                 a(f"{rev} v{S0 + k}, s{sBop}, v{S0 + k}")
         elif form == "CS":  # constant op stack top
-            a(f"s_movrels_b32 s{sA}, s{W + 2}")
+            a(f"s_movrels_b32 s{sA}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
             for k in range(K):
                 a(f"{ins} v{S0 + k}, s{sA}, v{S0 + k}")
         elif form == "VV":  # a was prefetched, b is read here
-            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
-            a(f"v_add_u32 v5, s{sBop}, v2")
+            a(f"s_movrels_b32 s{sBop}, s{W + 1}")
+            a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
             read_bank(T, 5)
             prefetch(nxt)
             m0_stack(MODE["DST"], 0)
@@ -318,7 +316,7 @@ def gen(K, DEPTH, stats=False):
                 a(f"{ins} v{S0 + k}, v{cur + k}, v{T + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         elif form == "VC":  # variable op constant
-            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
+            a(f"s_movrels_b32 s{sBop}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["DST"], 0)
             wait_cur()
@@ -326,7 +324,7 @@ def gen(K, DEPTH, stats=False):
                 a(f"{rev} v{S0 + k}, s{sBop}, v{cur + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         elif form == "CV":  # constant op variable
-            a(f"s_movrels_b32 s{sA}, s{W + 2}")
+            a(f"s_movrels_b32 s{sA}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["DST"], 0)
             wait_cur()
@@ -347,11 +345,11 @@ def gen(K, DEPTH, stats=False):
         entry()
         la, rb = form[0], form[1]
         if la == "C":
-            a(f"s_movrels_b32 s{sA}, s{W + 2}")
+            a(f"s_movrels_b32 s{sA}, s{W + 1}")
         if rb == "C" or form == "VV":
-            a(f"s_movrels_b32 s{sBop}, s{W + 3}")
+            a(f"s_movrels_b32 s{sBop}, s{W + 1}")
         if form == "VV":
-            a(f"v_add_u32 v5, s{sBop}, v2")
+            a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
             read_bank(T, 5)
         prefetch(nxt)
         wait_cur()  # the current bank is overwritten or read below: its (possibly unused) prefetch must have landed
@@ -386,7 +384,7 @@ def gen(K, DEPTH, stats=False):
         for x, y, q in zip(xs, ys, qs):
             a(f"v_cmp_neq_f32 vcc, 0, v{y}")
             a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")  # a NaN numerator makes the quotient NaN
-            a(f"v_div_scale_f32 v{d3}, s[{T1}:{T2}], v{y}, v{y}, v{x}")
+            a(f"v_div_scale_f32 v{d3}, vcc, v{y}, v{y}, v{x}")
             a(f"v_rcp_f32 v{d4}, v{d3}")
             a(f"v_div_scale_f32 v{d6}, vcc, v{x}, v{y}, v{x}")
             a(f"v_fma_f32 v{d7}, -v{d3}, v{d4}, 1.0")
@@ -407,7 +405,7 @@ def gen(K, DEPTH, stats=False):
         # push constant (folded constant subtree, or a tree that is a single constant)
         begin("push_c", fl)
         entry()
-        a(f"s_movrels_b32 s{sA}, s{W + 2}")
+        a(f"s_movrels_b32 s{sA}, s{W + 1}")
         prefetch(nxt)
         m0_stack(MODE["DST"], 0)
         for k in range(K):
@@ -430,27 +428,6 @@ def gen(K, DEPTH, stats=False):
         begin("skip", fl)
         a("s_set_gpr_idx_off")
         a(f"s_branch {lab('next_tree')}")
-        # continuation: the program goes on in the next 256-byte block of the record; the instruction that follows
-        # has this handler's flavour, so its variable operand is prefetched into `cur`
-        begin("next", fl)
-        a(f"s_add_u32 s{sBLK}, s{sBLK}, 1")
-        a(f"s_lshl_b32 s{T1}, s{sBLK}, 8")
-        a(f"s_add_u32 s{T1}, s{sREC}, s{T1}")
-        a(f"s_addc_u32 s{T2}, s{sREC + 1}, 0")
-        if stats:  # T1:T2 hold the block address: park it while the tick is taken
-            a(f"s_mov_b64 s[{sA}:{sBop}], s[{T1}:{T2}]")
-            tick_begin()
-            a(f"s_mov_b64 s[{T1}:{T2}], s[{sA}:{sBop}]")
-        for i in range(4):
-            a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{T1}:{T2}], {hex(64 * i)}")
-        a(f"s_mov_b32 s{sJ}, 0")
-        a("s_mov_b32 m0, 0")
-        a("s_waitcnt lgkmcnt(0)")
-        tick_end(A_DISP)
-        a(f"v_add_u32 v4, s{W + 1}, v2")
-        read_bank(cur, 4)
-        a(f"s_mov_b32 s{sPC}, s{W}")
-        a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # shared division bodies: K rows, then the scatter through v_div_fixup with an indexed destination
@@ -592,10 +569,10 @@ def gen(K, DEPTH, stats=False):
         out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
-    out += f"#define EVOGP_TC_ASM_{name}(karg_, wgid_, ldsx_, wave_, dyn_, pf_) \\\n  asm volatile( \\\n"
+    out += f"#define EVOGP_TC_ASM_{name}(karg_, wgid_, ldsx_, wave_, dyn_, pf_, base_) \\\n  asm volatile( \\\n"
     out += "\n".join(line + " \\" for line in body.split("\n"))
     out += f'''
-    : [cur] "+s"(wgid_), [lim] "+s"(ldsx_), [stride] "+s"(wave_), [dyn] "+s"(dyn_), [pf] "+s"(pf_) \\
+    : [cur] "+s"(wgid_), [lim] "+s"(ldsx_), [stride] "+s"(wave_), [dyn] "+s"(dyn_), [pf] "+s"(pf_), [base] "+s"(base_) \\
     : [karg] "s"(karg_) \\
     : {clob_txt})
 '''
