@@ -217,188 +217,6 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     }
 }
 
-// ---- assembly-core build ---------------------------------------------------------------------------
-// Same skeleton as sr_fast_kernel (tile-resident waves, batches from an atomic counter) for the
-// configuration the headline benchmark runs: single output, K = 4 rows per lane, trees of at most 63
-// nodes made of leaves and + - * /.  The interpreter core is the hand-written gfx950 block generated by
-// gen/gen_interp_asm.py (ballot-mask dispatch with direct branches, register stack indexed through
-// M0).  Everything else — trees with other functions, deeper stacks, longer rows — is marked for the
-// FULL register build / the general kernel.
-#include "interp_asm_d10.inc"
-#include "interp_asm_d16.inc"
-
-
-template <int DEPTH, int VLA, bool STORE>
-__global__ __launch_bounds__(256, DEPTH == 10 ? 4 : 3) void sr_asm_kernel(SrParams p) {
-    // [wave][VLA][64 lanes] float4 = the four rows of a lane, per variable (static and first, so that the
-    // ds_read_b128 addresses are 16-byte aligned)
-    __shared__ __attribute__((aligned(16))) float4 xs[4 * VLA * kWave];
-    __shared__ float part[2][kMaxBatch][4];
-    __shared__ int cls_s[2][kMaxBatch];
-    __shared__ int next_s[2];
-
-    constexpr int TILE = kWave * 4;
-    const int lane = threadIdx.x & 63;
-    const int w = uni((int)(threadIdx.x >> 6));
-    const int W = blockDim.x >> 6;  // == ntiles (the launcher only takes this path when D <= 256 * 4)
-
-    int d[4], dc[4];
-    float yv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        d[k] = w * TILE + k * kWave + lane;
-        dc[k] = d[k] < p.D ? d[k] : p.D - 1;
-        yv[k] = STORE ? 0.0f : p.y[dc[k]];
-    }
-    // stage this wave's tile, transposed so that one ds_read_b128 per variable fills the lane's rows
-    for (int v = 0; v < VLA; ++v) {
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v < p.var_len) {
-            q.x = p.X[(size_t)dc[0] * p.var_len + v]; q.y = p.X[(size_t)dc[1] * p.var_len + v];
-            q.z = p.X[(size_t)dc[2] * p.var_len + v]; q.w = p.X[(size_t)dc[3] * p.var_len + v];
-        }
-        xs[(w * VLA + v) * kWave + lane] = q;
-    }
-    const uint32_t lds_addr = (uint32_t)(uintptr_t)(&xs[(w * VLA) * kWave + lane]);
-
-    if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)p.batch);
-    __syncthreads();
-    int par = 0;
-    // optional cycle accounting (one set of counters per wave, added to p.stats at the end)
-    const bool timing = p.stats != nullptr;
-    unsigned long long c_asm = 0, c_loop = 0, c_wait = 0, n_trees = 0, n_nodes = 0;
-    const unsigned long long k_begin = timing ? __builtin_amdgcn_s_memtime() : 0;
-#pragma nounroll
-    for (;;) {
-        const int t0 = uni(next_s[par]);
-        if (t0 >= p.pop) break;
-        const int nb = p.pop - t0 < p.batch ? p.pop - t0 : p.batch;
-        if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)p.batch);
-        const unsigned long long b_begin = timing ? __builtin_amdgcn_s_memtime() : 0;
-
-        // Every wave walks the whole batch on its own rows.  The tree lengths of the batch come in with ONE
-        // load (lane b = tree b); the nodes of tree b+1 are requested before tree b is interpreted, so the
-        // HBM/L2 latency of a tree row hides behind the previous tree.  Classification (valid? stack <= DEPTH?
-        // only leaves and + - * /?) is recomputed by every wave from the row it needs anyway — DPP scans, no
-        // LDS traffic, no extra barrier.
-        int lens_v = 0;
-        if (lane < nb) lens_v = (int)p.size[(size_t)(t0 + lane) * p.gp_len];
-        lens_v = lens_v < 0 ? 0 : (lens_v > p.gp_len ? p.gp_len : lens_v);
-
-        int len = __builtin_amdgcn_readlane(lens_v, 0);
-        int nt = 0;
-        float nv = 0.0f;
-        if (lane < len && lane < 64) {
-            const size_t at = (size_t)t0 * p.gp_len + (len - 1 - lane);
-            nt = p.type[at]; nv = p.value[at];
-        }
-#pragma nounroll
-        for (int b = 0; b < nb; ++b) {
-            const int cur_len = len;
-            const int cur_t = nt;
-            const float cur_v = nv;
-            // ---- prefetch the next tree's row ----
-            if (b + 1 < nb) {
-                len = __builtin_amdgcn_readlane(lens_v, b + 1);
-                nt = 0; nv = 0.0f;
-                if (lane < len) {
-                    const size_t at = (size_t)(t0 + b + 1) * p.gp_len + (len - 1 - lane);
-                    nt = p.type[at]; nv = p.value[at];
-                }
-            }
-            // ---- decode + classify the current tree (one node per lane, execution order) ----
-            int cls;
-            uint32_t op = 0xFFu, payv = 0; // lanes past the end carry no opcode: their mask bits stay clear
-            if (cur_len <= 0) cls = TREE_BAD;
-            else if (cur_len > 63) cls = TREE_HEAVY;  // the ballot masks hold 64 instructions, bit len must stay clear
-            else {
-                int delta = 0;
-                bool heavy = false;
-                if (lane < cur_len) {
-                    const Decoded dn = decode_node(cur_t, cur_v, false, p.var_len, p.out_len);
-                    op = dn.op;
-                    payv = dn.op == H_VAR ? dn.pay * 4u : dn.pay;
-                    delta = dn.delta;
-                    heavy = dn.op > H_DIV;
-                }
-                const int hh = wave_scan_incl(delta);
-                const int hv = lane < cur_len ? hh : 1;
-                const int hmax = wave_max(hv), hmin = -wave_max(-hv);
-                const int fin = __builtin_amdgcn_readlane(hh, 63);
-                if (hmin < 1 || fin != 1) cls = TREE_BAD;
-                else if (__any(heavy)) cls = TREE_HEAVY;
-                else cls = hmax > DEPTH ? TREE_DEEP : TREE_OK;
-            }
-            cls = uni(cls);
-            if (w == 0 && lane == 0) cls_s[par][b] = cls;
-            if (cls != TREE_OK) {
-                if (STORE && cls == TREE_BAD) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (d[k] < p.D) p.results[(size_t)(t0 + b) * p.D + d[k]] = __builtin_nanf("");
-                }
-                continue;
-            }
-            float r0, r1, r2, r3;
-            const unsigned long long a_begin = timing ? __builtin_amdgcn_s_memtime() : 0;
-            const unsigned long long m_var = __ballot(op == H_VAR), m_const = __ballot(op == H_CONST),
-                                     m_add = __ballot(op == H_ADD), m_sub = __ballot(op == H_SUB),
-                                     m_mul = __ballot(op == H_MUL), m_div = __ballot(op == H_DIV);
-            if (DEPTH == 10) { EVOGP_INTERP_ASM_D10(r0, r1, r2, r3, m_var, m_const, m_add, m_sub, m_mul, m_div, payv, lds_addr); }
-            else { EVOGP_INTERP_ASM_D16(r0, r1, r2, r3, m_var, m_const, m_add, m_sub, m_mul, m_div, payv, lds_addr); }
-            if (timing) { c_asm += __builtin_amdgcn_s_memtime() - a_begin; n_trees += 1; n_nodes += cur_len; }
-            const float r[4] = {r0, r1, r2, r3};
-            if (STORE) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (d[k] < p.D) p.results[(size_t)(t0 + b) * p.D + d[k]] = r[k];
-            } else {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float e = err_term(yv[k] - r[k], p.use_mse);
-                    acc += d[k] < p.D ? e : 0.0f;
-                }
-                const float total = wave_sum(acc);
-                if (lane == 0) part[par][b][w] = total;
-            }
-        }
-        const unsigned long long b_end = timing ? __builtin_amdgcn_s_memtime() : 0;
-        __syncthreads();
-        if (timing) { c_loop += b_end - b_begin; c_wait += __builtin_amdgcn_s_memtime() - b_end; }
-
-        if (p.marks && threadIdx.x < 64) {
-            const int c = (int)threadIdx.x < nb ? cls_s[par][threadIdx.x] : TREE_OK;
-            if (__any(c == TREE_HEAVY) && threadIdx.x == 0) p.marks[0] = 1u;
-            if (__any(c == TREE_DEEP) && threadIdx.x == 0) p.marks[1] = 1u;
-        }
-        if ((int)threadIdx.x < nb) {
-            const int b = threadIdx.x;
-            const int c = cls_s[par][b];
-            if (STORE) {
-                if (c == TREE_DEEP || c == TREE_HEAVY)
-                    p.results[(size_t)(t0 + b) * p.D] = bits2f(c == TREE_DEEP ? kSentinelDeep : kSentinelHeavy);
-            } else {
-                float f;
-                if (c == TREE_OK) {
-                    float s = 0.0f;
-                    for (int i = 0; i < W; ++i) s += part[par][b][i];
-                    f = s / (float)p.D;
-                } else {
-                    f = c == TREE_DEEP ? bits2f(kSentinelDeep) : c == TREE_HEAVY ? bits2f(kSentinelHeavy) : __builtin_nanf("");
-                }
-                p.fitness[t0 + b] = f;
-            }
-        }
-        par ^= 1;
-    }
-    if (timing && lane == 0) {
-        atomicAdd(p.stats + 0, c_asm); atomicAdd(p.stats + 1, c_loop); atomicAdd(p.stats + 2, c_wait);
-        atomicAdd(p.stats + 3, n_trees); atomicAdd(p.stats + 4, n_nodes);
-        atomicAdd(p.stats + 5, __builtin_amdgcn_s_memtime() - k_begin); atomicAdd(p.stats + 6, 1ull);
-    }
-}
-
 // General path: one wave per tree, lanes are datapoints, stack/outputs in scratch memory, dataset
 // read row-major from global memory.  only_marked != 0: evaluate only trees whose first output
 // word holds the sentinel written by the fast kernel.
@@ -486,40 +304,6 @@ static hipError_t launch_fast(SrParams p, int only_marked, hipStream_t stream, u
     return hipGetLastError();
 }
 
-template <int DEPTH, int VLA, bool STORE>
-static hipError_t launch_asm(SrParams p, hipStream_t stream) {
-    auto kern = sr_asm_kernel<DEPTH, VLA, STORE>;
-    const DeviceInfo &dev = device_info();
-    p.ntiles = (p.D + 255) / 256;
-    p.only_marked = 0;
-    p.stats = g_stats;
-    const int W = p.ntiles;
-    const size_t lds = 0; // the tile staging area is static LDS
-    static int per_cu_cache[5] = {0};
-    int per_cu = per_cu_cache[W];
-    if (per_cu == 0) {
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, W * 64, lds);
-        if (e != hipSuccess) return e;
-        if (per_cu < 1) per_cu = 1;
-        per_cu_cache[W] = per_cu;
-    }
-    long blocks = (long)dev.num_cus * per_cu;
-    long batch = p.pop / (blocks * 16);
-    batch = batch < 4 ? 4 : (batch > kMaxBatch ? kMaxBatch : batch);
-    if (const char *env = getenv("EVOGP_SR_BATCH")) {
-        const int b = atoi(env);
-        batch = b < 1 ? 1 : (b > kMaxBatch ? kMaxBatch : b);
-    }
-    p.batch = (int)batch;
-    const long need = (p.pop + batch - 1) / batch;
-    if (blocks > need) blocks = need;
-    hipError_t e;
-    p.counter = acquire_counter(stream, &e);
-    if (!p.counter) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, stream, p);
-    return hipGetLastError();
-}
-
 // LEAN pass over every tree, then the FULL build over the trees the lean pass marked heavy.
 template <int K, int DEPTH, int VL, bool MO, int MAXW, bool STORE>
 static hipError_t launch_pair(const SrParams &p, hipStream_t stream) {
@@ -554,7 +338,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
     const bool mo = p.out_len > 1;
     hipError_t e;
-    // EVOGP_SR_ASM: 0 = C++ interpreter only, 10 / 16 = v2 assembly core with that stack depth, 3 = threaded code (default)
+    // EVOGP_SR_ASM: 0 = C++ interpreter only, 3 = threaded code (default)
     int asm_depth = EVOGP_SR_DEFAULT_ASM;
     if (const char *env = getenv("EVOGP_SR_ASM")) asm_depth = atoi(env);
     bool tc_done = false;
@@ -570,12 +354,6 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
         else if (p.var_len <= 16) e = launch_fast<4, 16, 16, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
         else e = launch_fast<4, 16, 32, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
-    } else if (!mo && p.D >= 256 && p.D <= 1024 && (asm_depth == 10 || asm_depth == 16) && p.var_len <= (asm_depth == 10 ? 10 : 12)) {
-        // assembly-core pass over every tree; whatever it marks goes to the FULL register build
-        e = asm_depth == 10 ? launch_asm<10, 10, STORE>(p, stream) : launch_asm<16, 12, STORE>(p, stream);
-        if (e != hipSuccess) return (int)e;
-        if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream);
-        else e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream);
     } else if (!mo && p.D >= 256) {
         if (p.var_len <= 9) e = launch_pair<4, 16, 9, false, 4, STORE>(p, stream);
         else if (p.var_len <= 10) e = launch_pair<4, 16, 10, false, 4, STORE>(p, stream);

@@ -16,7 +16,7 @@ echo "== smoke"; timeout 900 python __graft_entry__.py smoke; echo "smoke rc=$?"
 for K in 8 4; do timeout 240 python scripts/tc_smoke.py $K > $OUT/${TAG}_01_tc_smoke_$K.log 2>&1; echo "tc_smoke $K rc=$?" >> $OUT/${TAG}_01_tc_smoke_$K.log; done
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_02_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_02_pytest_gpu.log
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_03_bench.json 2> $OUT/${TAG}_03_bench.err; echo "bench rc=$?" >> $OUT/${TAG}_03_bench.err
-{ for A in "EVOGP_SR_ASM=3" "EVOGP_SR_ASM=10" "EVOGP_SR_ASM=0" "EVOGP_NATIVE_STEP=0"; do echo "== $A"; env $A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/${TAG}_04_ab.log 2>&1
+{ for A in "EVOGP_SR_ASM=3" "EVOGP_SR_ASM=0" "EVOGP_NATIVE_STEP=0"; do echo "== $A"; env $A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/${TAG}_04_ab.log 2>&1
 timeout 200 python scripts/tc_cycles.py > $OUT/${TAG}_05_cycles.json 2>/dev/null
 timeout 300 python scripts/tc_mix.py > $OUT/${TAG}_06_mix.log 2>/dev/null
 cd /tmp
