@@ -116,3 +116,41 @@ def test_genetic_programming_default_step_uses_the_fused_path_and_stays_valid(g)
         delta = torch.where(live, torch.where(leaf, 1, -1), 0)   # binary functions only
         assert bool((delta.sum(1) == 1).all())
     assert best[-1] >= best[0]
+
+
+def test_structural_and_point_mutations_on_the_device(g):
+    """The N3 operators through the real ops (tree_crossover with left position -1 = copy, tree_mutate, masked
+    generation): well-formed populations, expected size behaviour."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm import (CombinedMutation, DeleteMutation, HoistMutation, InsertMutation, MultiConstMutation,
+                                     MultiPointMutation, SingleConstMutation, SinglePointMutation)
+    from evogp_amd.tree import Forest, GenerateDescriptor
+    from test_mutation_variants import _check_well_formed
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=128, input_len=4, output_len=2, using_funcs=["+", "-", "*", "/", "sin", "neg", "if"],
+                              max_layer_cnt=4, const_samples=[-1.0, 0.0, 1.0, 0.5])
+    f = Forest.random_generate(3000, desc, keys=torch.tensor([5, 6], dtype=torch.uint32, device=dev))
+    before = f.batch_subtree_size[:, 0].clone()
+
+    def cpu(forest):
+        return Forest(forest.input_len, forest.output_len, forest.batch_node_value.cpu(), forest.batch_node_type.cpu(),
+                      forest.batch_subtree_size.cpu())
+
+    for op in (HoistMutation(0.7), DeleteMutation(0.7), InsertMutation(0.7, desc.update(max_layer_cnt=2)),
+               SinglePointMutation(0.7, desc), MultiPointMutation(0.7, desc), SingleConstMutation(0.7, desc),
+               MultiConstMutation(0.7, desc),
+               CombinedMutation([HoistMutation(0.3), InsertMutation(0.3, desc.update(max_layer_cnt=2)), DeleteMutation(0.3)])):
+        out = op(f)
+        _check_well_formed(cpu(out))
+        after = out.batch_subtree_size[:, 0]
+        if isinstance(op, (HoistMutation, DeleteMutation)):
+            assert bool((after <= before).all()) and bool((after < before).any())
+        if isinstance(op, InsertMutation):
+            assert bool((after >= before).all()) and bool((after > before).any())
+        if "Point" in type(op).__name__ or "Const" in type(op).__name__:
+            assert torch.equal(out.batch_subtree_size, f.batch_subtree_size)
+            assert not torch.equal(out.batch_node_value, f.batch_node_value)
+    assert torch.equal(f.batch_subtree_size[:, 0], before)   # operators never modify their input
