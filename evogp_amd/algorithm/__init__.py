@@ -1,12 +1,15 @@
-"""evogp_amd.algorithm — genetic operators (reference: src/evogp/algorithm/): the default set and the structural /
-point mutations."""
-from .selection import BaseSelection, DefaultSelection
-from .crossover import BaseCrossover, DefaultCrossover
+"""evogp_amd.algorithm — genetic operators (reference: src/evogp/algorithm/): the default set, the rank / roulette /
+tournament / truncation selections, the diversity and leaf-biased crossovers, the structural and point mutations."""
+from .selection import (BaseSelection, BaseSelector, DefaultSelection, RankSelection, RankSelector, RouletteSelection,
+                        RouletteSelector, TournamentSelection, TournamentSelector, TruncationSelection, TruncationSelector)
+from .crossover import BaseCrossover, DefaultCrossover, DiversityCrossover, LeafBiasedCrossover
 from .mutation import (BaseMutation, CombinedMutation, DefaultMutation, DeleteMutation, HoistMutation, InsertMutation,
                        MultiConstMutation, MultiPointMutation, SingleConstMutation, SinglePointMutation)
 from .genetic_programming import GeneticProgramming, ParetoFront
 
-__all__ = ["BaseSelection", "DefaultSelection", "BaseCrossover", "DefaultCrossover", "BaseMutation",
+__all__ = ["BaseSelection", "DefaultSelection", "RankSelection", "RouletteSelection", "TournamentSelection",
+           "TruncationSelection", "BaseSelector", "RankSelector", "RouletteSelector", "TournamentSelector",
+           "TruncationSelector", "BaseCrossover", "DefaultCrossover", "DiversityCrossover", "LeafBiasedCrossover", "BaseMutation",
            "DefaultMutation", "HoistMutation", "InsertMutation", "DeleteMutation", "SinglePointMutation",
            "MultiPointMutation", "SingleConstMutation", "MultiConstMutation", "CombinedMutation", "GeneticProgramming",
            "ParetoFront"]

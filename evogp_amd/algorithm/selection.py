@@ -40,3 +40,150 @@ class DefaultSelection(BaseSelection):
         n_elite, n_survive = self.counts(forest.pop_size)
         order = torch.sort(fitness, descending=True, stable=True).indices
         return order[:n_elite].to(torch.int32), order[:n_survive].to(torch.int32)
+
+
+# ---- selectors and the non-default selections ---------------------------------------------------------------------
+# Reference: selection/selection_utils.py:6-130, rank.py, roulette.py, tournament.py:59-133, truncation.py.  All of them
+# are index programs over the fitness vector; they are written here for the documented behaviour (the reference's
+# Rank/Truncation code indexes its probability vectors with tree indices where ranks are meant) and run without host
+# syncs.  ``fitness`` is "higher is better"; -inf / NaN entries are never preferred.
+
+def _clean(fitness: torch.Tensor) -> torch.Tensor:
+    return torch.nan_to_num(fitness.to(torch.float32), nan=float("-inf"))
+
+
+class BaseSelector:
+    """fitness, n -> int32[n] indices of chosen individuals (with replacement)"""
+
+    def __call__(self, fitness: torch.Tensor, choosed_num: int) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class RankSelector(BaseSelector):
+    """Linear ranking: P(rank r) = (1/n) (1 + sp (1 - 2 r / (n - 1))), r = 0 for the best."""
+
+    def __init__(self, selection_pressure: float = 0.5):
+        assert 0 <= selection_pressure <= 1, "selection_pressure should be in [0, 1]"
+        self.sp = selection_pressure
+
+    def __call__(self, fitness, choosed_num):
+        n = fitness.shape[0]
+        order = torch.sort(_clean(fitness), descending=True, stable=True).indices
+        r = torch.arange(n, dtype=torch.float32, device=fitness.device)
+        prob = (1.0 / n) * (1.0 + self.sp * (1.0 - 2.0 * r / max(n - 1, 1)))
+        return order[torch.multinomial(prob, choosed_num, replacement=True)].to(torch.int32)
+
+
+class RouletteSelector(BaseSelector):
+    """P(i) proportional to fitness_i (negative / non-finite fitness counts as 0; all-zero falls back to uniform)."""
+
+    def __call__(self, fitness, choosed_num):
+        w = _clean(fitness).clamp(min=0.0)
+        w = torch.where(torch.isfinite(w), w, torch.zeros_like(w))
+        w = w + (w.sum() <= 0).to(w.dtype)  # uniform when nothing is positive
+        return torch.multinomial(w, choosed_num, replacement=True).to(torch.int32)
+
+
+class TruncationSelector(BaseSelector):
+    """Uniform among the best ``survivor_rate`` fraction."""
+
+    def __init__(self, survivor_rate: float = 0.5):
+        assert 0 <= survivor_rate <= 1, "survivor_rate should be in [0, 1]"
+        self.survivor_rate = survivor_rate
+
+    def __call__(self, fitness, choosed_num):
+        n = fitness.shape[0]
+        top = max(1, int(n * self.survivor_rate))
+        order = torch.sort(_clean(fitness), descending=True, stable=True).indices
+        return order[torch.randint(0, top, (choosed_num,), device=fitness.device)].to(torch.int32)
+
+
+class TournamentSelector(BaseSelector):
+    """``choosed_num`` tournaments of ``tournament_size`` contenders; the k-th best contender wins with probability
+    p (1 - p)^k (ranks past the tournament fall back to the best, tournament.py:98-104).  ``replace=False`` forms the
+    tournaments of one pass from a random permutation, so nobody enters twice in a pass."""
+
+    def __init__(self, tournament_size: int, best_probability: float = 1, replace: bool = True):
+        assert tournament_size >= 1
+        self.t_size = tournament_size
+        self.best_p = best_probability
+        self.replace = replace
+
+    def contenders(self, n: int, count: int, device) -> torch.Tensor:
+        t = self.t_size
+        if self.replace:
+            return torch.randint(0, n, (count, t), device=device)
+        per_pass = max(n // t, 1)
+        passes = (count - 1) // per_pass + 1
+        perm = torch.rand((passes, n), device=device).argsort(dim=1)[:, : per_pass * t]
+        if perm.shape[1] < per_pass * t:  # population smaller than one tournament
+            perm = perm.repeat(1, (per_pass * t) // perm.shape[1] + 1)[:, : per_pass * t]
+        return perm.reshape(-1, t)[:count]
+
+    def __call__(self, fitness, choosed_num):
+        f = _clean(fitness)
+        c = self.contenders(f.shape[0], choosed_num, f.device)
+        cf = f[c]
+        if self.best_p >= 1:
+            pick = cf.argmax(dim=1, keepdim=True)
+        else:
+            rank = cf.argsort(dim=1, descending=True)
+            u = torch.rand(choosed_num, device=f.device).clamp(min=1e-30)
+            nth = (torch.log(u) / torch.log(torch.tensor(1.0 - self.best_p, device=f.device))).to(torch.int64)
+            nth = torch.where((nth >= self.t_size) | (nth < 0), torch.zeros_like(nth), nth)
+            pick = rank.gather(1, nth[:, None])
+        return c.gather(1, pick).squeeze(1).to(torch.int32)
+
+
+class _SelectorSelection(BaseSelection):
+    """survivors = selector(fitness, survivor count), elites = the best elite count (rank.py, roulette.py, ...)"""
+
+    def __init__(self, selector: BaseSelector, survivor_rate: float = 0.5, elite_rate: float = 0,
+                 survivor_cnt: Optional[int] = None, elite_cnt: Optional[int] = None):
+        assert 0 <= survivor_rate <= 1, "survivor_rate should be in [0, 1]"
+        assert 0 <= elite_rate <= 1, "elite_rate should be in [0, 1]"
+        self.selector = selector
+        self.survivor_rate = survivor_rate
+        self.survivor_cnt = survivor_cnt
+        self.elite_rate = elite_rate
+        self.elite_cnt = elite_cnt
+
+    def counts(self, pop_size: int):
+        n_surv = self.survivor_cnt if self.survivor_cnt is not None else int(pop_size * self.survivor_rate)
+        n_elite = self.elite_cnt if self.elite_cnt is not None else int(pop_size * self.elite_rate)
+        return n_elite, n_surv
+
+    def __call__(self, forest: Forest, fitness: torch.Tensor):
+        n_elite, n_surv = self.counts(forest.pop_size)
+        survivors = self.selector(fitness, n_surv)
+        if n_elite > 0:
+            elites = torch.topk(_clean(fitness), n_elite, sorted=True).indices.to(torch.int32)
+        else:
+            elites = torch.empty(0, dtype=torch.int32, device=fitness.device)
+        return elites, survivors
+
+
+class RankSelection(_SelectorSelection):
+    def __init__(self, selection_pressure: float = 0.5, survivor_rate: float = 0.5, elite_rate: float = 0,
+                 survivor_cnt: Optional[int] = None, elite_cnt: Optional[int] = None):
+        super().__init__(RankSelector(selection_pressure), survivor_rate, elite_rate, survivor_cnt, elite_cnt)
+
+
+class RouletteSelection(_SelectorSelection):
+    def __init__(self, survivor_rate: float = 0.5, elite_rate: float = 0, survivor_cnt: Optional[int] = None,
+                 elite_cnt: Optional[int] = None):
+        super().__init__(RouletteSelector(), survivor_rate, elite_rate, survivor_cnt, elite_cnt)
+
+
+class TruncationSelection(_SelectorSelection):
+    def __init__(self, survivor_rate: float = 0.5, elite_rate: float = 0, survivor_cnt: Optional[int] = None,
+                 elite_cnt: Optional[int] = None):
+        super().__init__(TruncationSelector(survivor_rate), survivor_rate, elite_rate, survivor_cnt, elite_cnt)
+
+
+class TournamentSelection(_SelectorSelection):
+    def __init__(self, tournament_size: int, best_probability: float = 1, replace: bool = True,
+                 survivor_rate: float = 0.5, elite_rate: float = 0, survivor_cnt: Optional[int] = None,
+                 elite_cnt: Optional[int] = None):
+        super().__init__(TournamentSelector(tournament_size, best_probability, replace), survivor_rate, elite_rate,
+                         survivor_cnt, elite_cnt)
