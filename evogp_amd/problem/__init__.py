@@ -1,5 +1,6 @@
 """evogp_amd.problem — fitness evaluation front ends (reference: src/evogp/problem/)."""
 from .base import BaseProblem
 from .symbolic_regression import SymbolicRegression
+from .classification import Classification
 
-__all__ = ["BaseProblem", "SymbolicRegression"]
+__all__ = ["BaseProblem", "SymbolicRegression", "Classification"]

@@ -92,3 +92,32 @@ def test_crossover_variants_and_a_mixed_gp_loop():
         assert algo.forest.pop_size == 300
         _check_well_formed(algo.forest)
     assert best[-1] >= best[0]
+
+
+def test_classification_problem_on_iris():
+    """configs[3] in miniature: multi-output classifier trees on an offline sklearn set, blocked reduction == unblocked."""
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+    from evogp_amd.problem import Classification
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    torch.manual_seed(0)
+    prob = Classification(dataset="iris")
+    assert prob.problem_dim == 4 and prob.solution_dim == 3
+    desc = GenerateDescriptor(max_tree_len=32, input_len=4, output_len=3, using_funcs=["+", "-", "*", "/"], max_layer_cnt=4,
+                              const_samples=[-1.0, 0.0, 1.0], out_prob=0.5)
+    forest = Forest.random_generate(200, desc, keys=torch.tensor([3, 4], dtype=torch.uint32))
+    acc = prob.evaluate(forest)
+    assert acc.shape == (200,) and float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 and float(acc.max()) >= 1 / 3 - 1e-6
+    small = Classification(prob.datapoints, prob.labels, block_bytes=64 * 1024)
+    assert torch.equal(small.evaluate(forest), acc)
+    single = Classification(prob.datapoints, prob.labels, multi_output=False)
+    f1 = Forest.random_generate(50, desc.update(output_len=1), keys=torch.tensor([3, 4], dtype=torch.uint32))
+    assert single.evaluate(f1).shape == (50,)
+    algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, desc.update(max_layer_cnt=2)),
+                              DefaultSelection(0.3, elite_rate=0.02))
+    best = []
+    for _ in range(4):
+        fit = prob.evaluate(algo.forest)
+        best.append(float(fit.max()))
+        algo.step(fit)
+    assert best[-1] >= best[0]
