@@ -2,5 +2,6 @@
 from .base import BaseProblem
 from .symbolic_regression import SymbolicRegression
 from .classification import Classification
+from .rollout import LinearTrackingEnv, PendulumEnv, RolloutProblem
 
-__all__ = ["BaseProblem", "SymbolicRegression", "Classification"]
+__all__ = ["BaseProblem", "SymbolicRegression", "Classification", "RolloutProblem", "LinearTrackingEnv", "PendulumEnv"]

@@ -154,3 +154,30 @@ def test_structural_and_point_mutations_on_the_device(g):
             assert torch.equal(out.batch_subtree_size, f.batch_subtree_size)
             assert not torch.equal(out.batch_node_value, f.batch_node_value)
     assert torch.equal(f.batch_subtree_size[:, 0], before)   # operators never modify their input
+
+
+def test_rollout_problem_graph_replay_matches_eager(g):
+    """N4: one captured step of the rollout loop replayed as a HIP graph gives the eager result."""
+    import time
+
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.problem import LinearTrackingEnv, RolloutProblem
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    env = LinearTrackingEnv(device=dev)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=17, output_len=6, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5,
+                              const_samples=[-1.0, 0.0, 1.0, 0.5], out_prob=0.5)
+    forest = Forest.random_generate(20000, desc, keys=torch.tensor([8, 9], dtype=torch.uint32, device=dev))
+    eager = RolloutProblem(env, 60, use_graph=False)
+    graph = RolloutProblem(env, 60, use_graph=True)
+    a = eager.evaluate(forest)
+    b = graph.evaluate(forest)
+    assert torch.equal(a, b)
+    for prob, name in ((eager, "eager"), (graph, "graph")):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        prob.evaluate(forest)
+        torch.cuda.synchronize()
+        print(f"rollout {name}: {(time.perf_counter() - t0) / 60 * 1e6:.1f} us per step at pop 20000")

@@ -121,3 +121,28 @@ def test_classification_problem_on_iris():
         best.append(float(fit.max()))
         algo.step(fit)
     assert best[-1] >= best[0]
+
+
+def test_rollout_problem_runs_policy_trees_in_a_batched_environment():
+    """configs[4] in miniature (no simulator in this image): the rollout loop on the CPU, eager."""
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+    from evogp_amd.problem import LinearTrackingEnv, PendulumEnv, RolloutProblem
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    torch.manual_seed(0)
+    for env, steps in ((LinearTrackingEnv(obs_dim=5, act_dim=2), 30), (PendulumEnv(), 40)):
+        prob = RolloutProblem(env, steps, use_graph=False)
+        desc = GenerateDescriptor(max_tree_len=32, input_len=prob.problem_dim, output_len=prob.solution_dim,
+                                  using_funcs=["+", "-", "*", "/"], max_layer_cnt=4, const_samples=[-1.0, 0.0, 1.0, 0.5], out_prob=0.5)
+        forest = Forest.random_generate(120, desc, keys=torch.tensor([8, 9], dtype=torch.uint32))
+        fit = prob.evaluate(forest)
+        assert fit.shape == (120,) and bool(torch.isfinite(fit).all())
+        assert torch.equal(prob.evaluate(forest), fit)      # deterministic
+        algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, desc.update(max_layer_cnt=2)),
+                                  DefaultSelection(0.3, elite_rate=0.02))
+        best = []
+        for _ in range(4):
+            fit = prob.evaluate(algo.forest)
+            best.append(float(fit.max()))
+            algo.step(fit)
+        assert best[-1] >= best[0]
