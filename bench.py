@@ -151,6 +151,23 @@ def main():
         algo.step(f)
         torch.cuda.synchronize(); gen_ms.append((time.perf_counter() - g0) * 1000)
 
+    # the sharded generation step: fitness of the local shard, ONE all-gather of the packed shards,
+    # identical selection / random words on every rank, every rank builds its own rows of the next generation
+    sharded_ms, sharded_err = [], None
+    try:
+        from evogp_amd.algorithm import DefaultSelection as _Sel
+        from evogp_amd.parallel import ShardedGeneticProgramming
+
+        sg = ShardedGeneticProgramming(forest, 0.2, mdesc, _Sel(0.3, elite_rate=0.01), seed=1234)
+        for _ in range(4):
+            barrier(); g0 = time.perf_counter()
+            f = -sg.forest.SR_fitness(Xd, yd, True, "auto")
+            f[torch.isnan(f)] = -torch.inf
+            sg.step(f)
+            barrier(); sharded_ms.append((time.perf_counter() - g0) * 1000)
+    except Exception as exc:  # the fitness line must survive a failure of the exchange step
+        sharded_err = repr(exc)[:300]
+
     if rank == 0:
         n = world
         evals = float(pop) * DATAPOINTS * n * args.steps
@@ -186,6 +203,10 @@ def main():
             "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
             "generation_ms": {"median": float(np.median(gen_ms[1:])), "first": gen_ms[0],
                               "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
+            "generation_ms_sharded": {"median": float(np.median(sharded_ms[1:])) if len(sharded_ms) > 1 else None,
+                                      "global_pop": pop * n, "error": sharded_err,
+                                      "what": "whole population: local fitness + one all-gather of the packed shards (RCCL) + "
+                                              "sort + breeding pass for the local rows, max over ranks via barriers"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,

@@ -34,6 +34,8 @@ struct BreedParams {
     int *decisions;                                          // optional [n_new][6]: left, right, p, q, mutated, mutate position
     int pop, gp_len, n_elite, n_surv, n_new;
     unsigned mutate_below;
+    int row_begin, row_count;  // rows [row_begin, row_begin + row_count) of the next generation are built; output and donor
+                               // arrays hold exactly these rows (donor row k belongs to next-generation row row_begin + k)
 };
 
 // A workgroup (4 waves) takes 64 consecutive output rows in two phases.  DECIDE: lane l of wave 0 owns row n0 + l and
@@ -50,15 +52,16 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
     int16_t *ct = (int16_t *)(mine + (size_t)a.gp_len * 4);
     int16_t *cs = ct + a.gp_len;
     __shared__ int dec_s[10][64];  // decisions of the chunk's 64 rows
-    const int nchunks = (a.pop + 63) >> 6;
+    const int nchunks = (a.row_count + 63) >> 6;
+    const int row_end = a.row_begin + a.row_count;
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const int n0 = c << 6;
+        const int n0 = a.row_begin + (c << 6);
         // ---- DECIDE (wave 0) ----
         const int n = n0 + lane;
         int li = 0, ri = 0, S = 0, p = 0, q = 0, m = 0, o = 0, dm = 0;
         unsigned r5 = 0;
         bool fallback = true, mutating = false;
-        if (w == 0 && n < a.pop) {
+        if (w == 0 && n < row_end) {
             if (n < a.n_elite) {
                 li = a.order[n];
                 li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
                     fallback = m < 1 || q + m > a.gp_len || S + (m - o) > a.gp_len;  // mutation.cu:279-289
                 }
                 mutating = r4 < a.mutate_below;
-                if (mutating) dm = (int)a.ds[(size_t)i * a.gp_len];
+                if (mutating) dm = (int)a.ds[(size_t)(n - a.row_begin) * a.gp_len];
             }
         }
         if (w == 0) {
@@ -99,10 +102,10 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
         }
         __syncthreads();
         // ---- BUILD (every wave takes every fourth row of the chunk) ----
-        const int rows = a.pop - n0 < 64 ? a.pop - n0 : 64;
+        const int rows = row_end - n0 < 64 ? row_end - n0 : 64;
         for (int l = w; l < rows; l += kRepBlock / 64) {
             const int nn = n0 + l;
-            const size_t off = (size_t)nn * a.gp_len;
+            const size_t off = (size_t)(nn - a.row_begin) * a.gp_len;
             const int li_ = uni(dec_s[0][l]), ri_ = uni(dec_s[1][l]), S_ = uni(dec_s[2][l]);
             const size_t lo = (size_t)li_ * a.gp_len, ro = (size_t)ri_ * a.gp_len;
             const Row L{a.v + lo, a.t + lo, a.s + lo}, R{a.v + ro, a.t + ro, a.s + ro};
@@ -117,8 +120,7 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int i = nn - a.n_elite;
-                const size_t doff = (size_t)i * a.gp_len;
+                const size_t doff = off;
                 const Row C{cv, ct, cs}, D{a.dv + doff, a.dt + doff, a.ds + doff};
                 int CS = uni((int)C.s[0]);
                 CS = CS < 0 ? 0 : (CS > a.gp_len ? a.gp_len : CS);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
                 __builtin_amdgcn_wave_barrier();  // the staging row is rewritten by this wave's next mutating offspring
             }
             if (a.decisions && lane == 0 && nn >= a.n_elite) {
-                int *d = a.decisions + (size_t)(nn - a.n_elite) * 6;
+                int *d = a.decisions + (size_t)(nn - a.row_begin) * 6;
                 d[0] = li_; d[1] = ri_; d[2] = p_; d[3] = q_; d[4] = mu ? 1 : 0; d[5] = pm;
             }
         }
@@ -148,16 +150,30 @@ extern "C" int evogp_hip_breed_default(int pop_size, int gp_len, int n_elite, in
                                        unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
                                        const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
                                        int *decisions, evogp_stream_t stream_) {
+    return evogp_hip_breed_default_rows(pop_size, gp_len, n_elite, n_surv, value, type, size, order, rnd, mutate_below,
+                                        donor_value ? donor_value - (size_t)n_elite * gp_len : nullptr,
+                                        donor_type ? donor_type - (size_t)n_elite * gp_len : nullptr,
+                                        donor_size ? donor_size - (size_t)n_elite * gp_len : nullptr, value_res, type_res,
+                                        size_res, decisions ? decisions - (size_t)n_elite * 6 : nullptr, 0, pop_size, stream_);
+}
+
+extern "C" int evogp_hip_breed_default_rows(int pop_size, int gp_len, int n_elite, int n_surv, const float *value,
+                                            const int16_t *type, const int16_t *size, const int *order, const int *rnd,
+                                            unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                                            const int16_t *donor_size, float *value_res, int16_t *type_res,
+                                            int16_t *size_res, int *decisions, int row_begin, int row_count,
+                                            evogp_stream_t stream_) {
     if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0 || n_surv > pop_size)
         return EVOGP_E_BADARG;
     if (!value || !type || !size || !order || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
     const int n_new = pop_size - n_elite;
     if (n_new > 0 && !rnd) return EVOGP_E_NULLPTR;
     if (mutate_below != 0 && n_new > 0 && (!donor_value || !donor_type || !donor_size)) return EVOGP_E_NULLPTR;
+    if (row_begin < 0 || row_count <= 0 || row_begin + row_count > pop_size) return EVOGP_E_BADARG;
     BreedParams a{value, type, size, order, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
-                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, mutate_below};
+                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, mutate_below, row_begin, row_count};
     const DeviceInfo &dev = device_info();
-    long blocks = ((long)pop_size + 63) / 64;  // one workgroup per 64 rows
+    long blocks = ((long)row_count + 63) / 64;  // one workgroup per 64 rows
     const long cap = (long)dev.num_cus * 8 * 4;
     if (blocks > cap) blocks = cap;
     const size_t lds = (size_t)(kRepBlock / 64) * gp_len * 8;

@@ -83,6 +83,14 @@ torch.library.define(
 )
 
 
+torch.library.define(
+    "evogp_hip::breed_default_rows",
+    "(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
+    " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
+    " int row_begin, int row_count) -> (Tensor value, Tensor node_type, Tensor subtree_size)",
+)
+
+
 # ---- helpers ----------------------------------------------------------------------------------
 def _check(cond: bool, msg: str) -> None:
     if not cond:
@@ -194,6 +202,34 @@ def breed_default(pop_size, gp_len, n_elite, n_surv, value, ntype, size, order, 
             ov.data_ptr(), ot.data_ptr(), osz.data_ptr(), dec.data_ptr() if want_decisions else None, _stream(dev))
     _lib.check(rc, "breed_default")
     return ov, ot, osz, dec
+
+
+@torch.library.impl("evogp_hip::breed_default_rows", "CUDA")
+def breed_default_rows(pop_size, gp_len, n_elite, n_surv, value, ntype, size, order, rnd, mutate_below, donor_value,
+                       donor_type, donor_size, row_begin, row_count):
+    """Rows [row_begin, row_begin + row_count) of the next generation; donor arrays have row_count rows aligned with them."""
+    _check_sizes_common(pop_size, gp_len)
+    _check(0 <= n_elite <= pop_size and 0 < n_surv <= pop_size, "n_elite / n_surv out of range")
+    _check(0 <= row_begin and 0 < row_count and row_begin + row_count <= pop_size, "row range out of the population")
+    _check_forest(pop_size, gp_len, value, ntype, size)
+    _check(order.is_cuda and order.is_contiguous() and order.dtype == torch.int32 and order.dim() == 1
+           and order.shape[0] >= max(n_elite, n_surv), "order must be a contiguous int32 CUDA vector of >= max(n_elite, n_surv) entries")
+    _check_tensor(rnd, (6, pop_size - n_elite), "rnd", torch.int32)
+    for t, nm, dt in ((donor_value, "donor_value", torch.float32), (donor_type, "donor_type", torch.int16),
+                      (donor_size, "donor_size", torch.int16)):
+        _check_tensor(t, (row_count, gp_len), nm, dt)
+    dev = value.device
+    shp = (row_count, gp_len)
+    with torch.cuda.device(dev):
+        ov = torch.empty(shp, dtype=torch.float32, device=dev)
+        ot = torch.empty(shp, dtype=torch.int16, device=dev)
+        osz = torch.empty(shp, dtype=torch.int16, device=dev)
+        rc = _lib_h.evogp_hip_breed_default_rows(
+            pop_size, gp_len, n_elite, n_surv, value.data_ptr(), ntype.data_ptr(), size.data_ptr(), order.data_ptr(),
+            rnd.data_ptr(), mutate_below, donor_value.data_ptr(), donor_type.data_ptr(), donor_size.data_ptr(),
+            ov.data_ptr(), ot.data_ptr(), osz.data_ptr(), None, row_begin, row_count, _stream(dev))
+    _lib.check(rc, "breed_default_rows")
+    return ov, ot, osz
 
 
 @torch.library.impl("evogp_cuda::tree_mutate", "CUDA")

@@ -23,6 +23,7 @@ explicit generator so that ranks agree.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -86,6 +87,47 @@ class ShardedGeneticProgramming:
     def step(self, local_fitness: torch.Tensor) -> Forest:
         assert local_fitness.shape == (self.n_local,)
         full, fitness = self.gather(local_fitness)
+        lo, hi = self.rank * self.n_local, (self.rank + 1) * self.n_local
+        if fitness.is_cuda and self.descriptor.max_tree_len == full.max_tree_len \
+                and os.environ.get("EVOGP_NATIVE_STEP", "1") != "0":
+            self.forest = self.next_slice_native(full, fitness, lo, hi)
+        else:
+            self.forest = self.next_slice_torch(full, fitness, lo, hi)
+        return self.forest
+
+    def next_slice_native(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
+        """Rows [lo, hi) of the next generation with the fused breeding pass (csrc/breed.hip): every rank sorts the
+        gathered fitness, draws the SAME six random words per offspring and the same generation keys from its generator,
+        generates donors only for its own mutating offspring (tree index = global offspring index) and builds only its
+        own rows.  The union over the ranks is the single-device result for the same generator state."""
+        dev = fitness.device
+        pop, L = full.pop_size, full.max_tree_len
+        n_elite, n_surv = self.selection.counts(pop)
+        n_new = pop - n_elite
+        order = torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv)].to(torch.int32).contiguous()
+        g = self.gen
+        rnd = torch.randint(0, 2**31 - 1, (6, n_new), generator=g, device=dev, dtype=torch.int32)
+        keys = torch.randint(0, 1000000, (2,), generator=g, device=dev).to(torch.uint32)
+        below = int(min(max(self.mutation_rate, 0.0), 1.0) * (2**31 - 1))
+        d = self.descriptor
+        rows = hi - lo
+        o_lo, o_hi = max(lo, n_elite) - n_elite, max(hi, n_elite) - n_elite   # my offspring indices
+        head = rows - (o_hi - o_lo)                                            # elite rows at the head of my slice
+        if o_hi > o_lo:
+            donors = torch.ops.evogp_hip.tree_generate_masked(
+                o_hi - o_lo, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
+                d.depth2leaf_probs, d.roulette_funcs, d.const_samples, o_lo, rnd[4, o_lo:o_hi].contiguous(), below)
+            if head:
+                donors = tuple(torch.cat([torch.empty((head, L), dtype=t.dtype, device=dev), t]) for t in donors)
+        else:
+            donors = (torch.empty((rows, L), dtype=torch.float32, device=dev), torch.empty((rows, L), dtype=torch.int16, device=dev),
+                      torch.empty((rows, L), dtype=torch.int16, device=dev))
+        value, ntype, size = full._tensors()
+        nv, nt, ns = torch.ops.evogp_hip.breed_default_rows(pop, L, n_elite, n_surv, value, ntype, size, order, rnd, below,
+                                                            *donors, lo, rows)
+        return Forest(full.input_len, full.output_len, nv, nt, ns)
+
+    def next_slice_torch(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
         dev = fitness.device
         pop = self.pop_size
         elite_idx, surv_idx = self.selection(full, fitness)       # identical on every rank
@@ -107,7 +149,6 @@ class ShardedGeneticProgramming:
         keys = torch.randint(0, 1000000, (2,), generator=g, device=dev).to(torch.uint32)
 
         # this rank's slots of the next generation: [lo, hi) of [elites | offspring]
-        lo, hi = self.rank * self.n_local, (self.rank + 1) * self.n_local
         e_lo, e_hi = min(lo, n_elite), min(hi, n_elite)
         o_lo, o_hi = max(lo, n_elite) - n_elite, max(hi, n_elite) - n_elite
         pieces = []
@@ -129,5 +170,4 @@ class ShardedGeneticProgramming:
         nxt = pieces[0]
         for p in pieces[1:]:
             nxt = nxt + p
-        self.forest = nxt
         return nxt

@@ -124,6 +124,17 @@ int evogp_hip_breed_default(int pop_size, int gp_len, int n_elite, int n_surv,
                             float *value_res, int16_t *type_res, int16_t *size_res,
                             int *decisions, evogp_stream_t stream);
 
+/* evogp_hip_breed_default restricted to the rows [row_begin, row_begin + row_count) of the next generation (a rank's
+ * slice of a sharded population).  value_res/type_res/size_res, the donor arrays and `decisions` hold
+ * exactly row_count rows: row k of each belongs to next-generation row row_begin + k (donor rows of elite rows and of
+ * offspring that do not mutate are never read). */
+int evogp_hip_breed_default_rows(int pop_size, int gp_len, int n_elite, int n_surv,
+                                 const float *value, const int16_t *type, const int16_t *size,
+                                 const int *order, const int *rnd, unsigned mutate_below,
+                                 const float *donor_value, const int16_t *donor_type, const int16_t *donor_size,
+                                 float *value_res, int16_t *type_res, int16_t *size_res,
+                                 int *decisions, int row_begin, int row_count, evogp_stream_t stream);
+
 /* Non-replicating batch evaluation (replaces the repeat_interleave + tree_evaluate
  * composition of src/evogp/tree/forest.py:143-176): results[t][d][:] = tree_t(variables[d][:]),
  * variables: f32[D][var_len], results: f32[pop][D][out_len]. */

@@ -182,3 +182,40 @@ def test_rollout_problem_graph_replay_matches_eager(g):
         prob.evaluate(forest)
         torch.cuda.synchronize()
         print(f"rollout {name}: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per step at pop 20000 (500 steps, capture included)")
+
+
+def test_sharded_native_step_union_equals_single_device(g):
+    """SURVEY.md §8e on one GPU: the rows the ranks of a G-way sharded run would build (same gathered population, same
+    generator state) concatenate to the single-device next generation, bit for bit, for G = 1, 2, 3, 8."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm import DefaultSelection
+    from evogp_amd.parallel import ShardedGeneticProgramming
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=5, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5,
+                              const_samples=[-1.0, 0.0, 1.0])
+    pop = 4800
+    full = Forest.random_generate(pop, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
+    fitness = torch.randn(pop, device=dev)
+
+    def run(G):
+        parts = []
+        for r in range(G):
+            sg = ShardedGeneticProgramming(full[:pop // G], 0.2, desc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=5)
+            parts.append(sg.next_slice_native(full, fitness, r * (pop // G), (r + 1) * (pop // G)))
+        return [torch.cat([getattr(p, n) for p in parts]) for n in ("batch_node_value", "batch_node_type", "batch_subtree_size")]
+
+    ref = run(1)
+    assert int(ref[2][:, 0].min()) >= 1
+    for G in (2, 3, 8):
+        got = run(G)
+        for a, b in zip(got, ref):
+            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
+                               b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), f"G = {G}"
+    # and the torch composition of the same step is a valid population of the same shape (different random words)
+    sg = ShardedGeneticProgramming(full, 0.2, desc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=5)
+    nxt = sg.next_slice_torch(full, fitness, 0, pop)
+    assert nxt.pop_size == pop
