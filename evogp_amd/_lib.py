@@ -30,6 +30,7 @@ PROTOTYPES = {
     "evogp_hip_breed_default": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_breed_default_rows": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evogp_hip_batch_argmax_count": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
     "evogp_hip_debug_set_stats": [_vp],

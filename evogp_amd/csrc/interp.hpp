@@ -168,9 +168,20 @@ struct RegStack {
 // The opcode of the NEXT instruction is fetched (v_readlane) before the current one is dispatched,
 // so the VALU->SGPR latency of the fetch overlaps the handler; the payload is only fetched by the
 // handlers that use it.
-template <bool MO, bool LEAN, int K, int DEPTH, int VL>
-__device__ inline void run_chunk(uint32_t opv, uint32_t payv, int n, RegStack<K, DEPTH> &st,
-                                 const typename VecOf<VL>::type (&vars)[K], v16f (&outs)[K]) {
+// Where a lane's input rows live: RegVars = K register tuples indexed with the (uniform) variable number,
+// LdsVars = the wave's [variable][lane] block in LDS (wide inputs: more variables than a register tuple holds).
+template <int VL, int K>
+struct RegVars {
+    const typename VecOf<VL>::type (&v)[K];
+    __device__ inline float get(int k, uint32_t var) const { return v[k][var]; }
+};
+struct LdsVars {
+    const float *base;  // this wave's block, already offset by the lane
+    __device__ inline float get(int, uint32_t var) const { return base[var * 64]; }
+};
+
+template <bool MO, bool LEAN, int K, int DEPTH, class VA>
+__device__ inline void run_chunk(uint32_t opv, uint32_t payv, int n, RegStack<K, DEPTH> &st, const VA &vars, v16f (&outs)[K]) {
     uint32_t next_op = (uint32_t)__builtin_amdgcn_readlane((int)opv, 0);
     for (int j = 0; j < n; ++j) {
         const uint32_t op = next_op;
@@ -186,7 +197,7 @@ __device__ inline void run_chunk(uint32_t opv, uint32_t payv, int n, RegStack<K,
                 for (int k = 0; k < K; ++k) st.tos[k] = bits2f(pay);
             } else {
 #pragma unroll
-                for (int k = 0; k < K; ++k) st.tos[k] = vars[k][pay];
+                for (int k = 0; k < K; ++k) st.tos[k] = vars.get(k, pay);
             }
         } else if (op < H_UN) { // binary: a = top (left operand), b = next (right operand)
             const int h = st.h - 1;

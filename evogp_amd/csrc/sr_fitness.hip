@@ -148,7 +148,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
                         opv = dn.op; payv = dn.pay;
                     }
                     const int n = len - base < kWave ? len - base : kWave;
-                    run_chunk<MO, LEAN, K, DEPTH, VL>(opv, payv, n, st, vars, outs);
+                    run_chunk<MO, LEAN, K, DEPTH>(opv, payv, n, st, RegVars<VL, K>{vars}, outs);
                 }
                 if (STORE) {
 #pragma unroll
@@ -334,7 +334,14 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         p.marks = acquire_counter(stream, &me);
         if (!p.marks) return (int)me;
     }
-    const bool fast_ok = p.var_len <= 32 && p.out_len <= kMaxOutRegs && !getenv("EVOGP_SR_FORCE_GENERAL");
+    const bool forced = getenv("EVOGP_SR_FORCE_GENERAL") != nullptr;
+    if (STORE && !forced && p.out_len <= kMaxOutRegs && (size_t)p.var_len * 256 <= 150 * 1024 && (p.var_len > 32 || p.D > 1024)) {
+        // more variables than a register tuple holds, or more rows than one workgroup keeps resident: tile-group kernel
+        hipError_t we = launch_wide_store(p, stream);
+        if (we != hipSuccess) return (int)we;
+        return (int)launch_general<STORE>(p, 1, stream);
+    }
+    const bool fast_ok = p.var_len <= 32 && p.out_len <= kMaxOutRegs && !forced;
     if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
     const bool mo = p.out_len > 1;
     hipError_t e;

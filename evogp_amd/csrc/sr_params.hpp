@@ -33,4 +33,7 @@ struct SrParams {
 // marked kSentinelHeavy / NaN in p.fitness for the follow-up kernels); *handled == false means "not eligible".
 hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled);
 
+// Tile-group kernel for shapes the register kernels cannot keep resident (sr_wide.hip): STORE mode of batch_evaluate.
+hipError_t launch_wide_store(const SrParams &p, hipStream_t stream);
+
 } // namespace evogp

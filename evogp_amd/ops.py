@@ -91,6 +91,13 @@ torch.library.define(
 )
 
 
+torch.library.define(
+    "evogp_hip::tree_batch_argmax_count",
+    "(int pop_size, int data_points, int gp_len, int var_len, int out_len, Tensor value, Tensor node_type,"
+    " Tensor subtree_size, Tensor variables, Tensor labels) -> Tensor counts",
+)
+
+
 # ---- helpers ----------------------------------------------------------------------------------
 def _check(cond: bool, msg: str) -> None:
     if not cond:
@@ -202,6 +209,25 @@ def breed_default(pop_size, gp_len, n_elite, n_surv, value, ntype, size, order, 
             ov.data_ptr(), ot.data_ptr(), osz.data_ptr(), dec.data_ptr() if want_decisions else None, _stream(dev))
     _lib.check(rc, "breed_default")
     return ov, ot, osz, dec
+
+
+@torch.library.impl("evogp_hip::tree_batch_argmax_count", "CUDA")
+def tree_batch_argmax_count(pop_size, data_points, gp_len, var_len, out_len, value, ntype, size, variables, labels):
+    """counts[t] = #rows whose arg-max output (as torch.argmax(clip(softmax(.))) sees it) equals the int32 label."""
+    _check_sizes_common(pop_size, gp_len)
+    _check(data_points > 0 and var_len > 0, "data_points and var_len must be larger than 0")
+    _check(2 <= out_len <= 16, f"out_len must be in [2, 16], but got {out_len}")
+    _check_forest(pop_size, gp_len, value, ntype, size)
+    _check_tensor(variables, (data_points, var_len), "variables", torch.float32)
+    _check_tensor(labels, (data_points,), "labels", torch.int32)
+    dev = value.device
+    with torch.cuda.device(dev):
+        counts = torch.empty((pop_size,), dtype=torch.int32, device=dev)
+        rc = _lib_h.evogp_hip_batch_argmax_count(pop_size, data_points, gp_len, var_len, out_len, value.data_ptr(),
+                                                 ntype.data_ptr(), size.data_ptr(), variables.data_ptr(), labels.data_ptr(),
+                                                 counts.data_ptr(), _stream(dev))
+    _lib.check(rc, "tree_batch_argmax_count")
+    return counts
 
 
 @torch.library.impl("evogp_hip::breed_default_rows", "CUDA")

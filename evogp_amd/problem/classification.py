@@ -6,6 +6,7 @@ outputs come from ``Forest.batch_forward`` — here the non-replicating batch op
 reduced tree-block by tree-block so that the (pop, D, classes) tensor never exists in full."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -51,6 +52,13 @@ class Classification(BaseProblem):
 
     def evaluate(self, forest: Forest) -> Tensor:
         D = self.datapoints.shape[0]
+        if (self.multi_output and self.datapoints.is_cuda and 2 <= forest.output_len <= 16
+                and forest.input_len * 256 <= 150 * 1024 and os.environ.get("EVOGP_FUSED_ACCURACY", "1") != "0"):
+            # fused epilogue: only the per-tree count of correct rows leaves the kernel (csrc/sr_wide.hip)
+            counts = torch.ops.evogp_hip.tree_batch_argmax_count(
+                forest.pop_size, D, forest.max_tree_len, forest.input_len, forest.output_len, *forest._tensors(),
+                self.datapoints.contiguous().to(torch.float32), self.labels.to(torch.int32).contiguous())
+            return counts.to(torch.float32) / D
         per_tree = 4 * D * max(forest.output_len, 1) * 3        # outputs + soft-max + clip temporaries
         step = max(1, min(forest.pop_size, self.block_bytes // per_tree))
         if step >= forest.pop_size:

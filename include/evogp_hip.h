@@ -143,6 +143,17 @@ int evogp_hip_batch_evaluate(unsigned pop_size, unsigned data_points, unsigned g
                              const float *value, const int16_t *type, const int16_t *size,
                              const float *variables, float *results, evogp_stream_t stream);
 
+/* Fused epilogue of the Classification problem (src/evogp/problem/classification.py:62-75) on top of the batch
+ * evaluation: counts[t] = number of rows d with argmax_o tree_t(variables[d])_o == labels[d], where the arg-max is the
+ * one torch.argmax(clip(softmax(outputs))) returns (first maximum; index 0 when an output is NaN or the maximum is
+ * infinite).  out_len in [2, 16]; labels: i32[data_points]; counts: u32[pop_size] (zeroed here).  The
+ * (pop, data_points, out_len) output tensor is never materialised. */
+int evogp_hip_batch_argmax_count(unsigned pop_size, unsigned data_points, unsigned gp_len,
+                                 unsigned var_len, unsigned out_len,
+                                 const float *value, const int16_t *type, const int16_t *size,
+                                 const float *variables, const int *labels, unsigned *counts,
+                                 evogp_stream_t stream);
+
 /* Average duration in milliseconds of the most recent `evogp_hip_*` launch sequence that was
  * bracketed by evogp_hip_timer_begin/_end on `stream` (hipEvent pair recorded on that stream).
  * Used by bench.py to time the kernel on the stream it is launched on. */

@@ -101,5 +101,12 @@ def bev():
 us = timed(bev, 5)
 row("batch_evaluate (C4 shape, pop 20k)", us, 4.0 * pc * Dc * 10 + 6.0 * cs_[:, 0].to(torch.int64).sum().item(), f"pop {pc}, L {Lc}, in 64, out 10, D {Dc}: {pc * Dc / us / 1e3:.1f} G tree-evals/s, results written once")
 
+labels = torch.randint(0, 10, (Dc,), dtype=torch.int32, device=g.DEV)
+counts = torch.empty(pc, dtype=torch.int32, device=g.DEV)
+def acc():
+    assert L_.evogp_hip_batch_argmax_count(pc, Dc, Lc, 64, 10, cv.data_ptr(), ct.data_ptr(), cs_.data_ptr(), Xc.data_ptr(), labels.data_ptr(), counts.data_ptr(), S()) == 0
+us = timed(acc, 5)
+row("batch_argmax_count (C4 shape, pop 20k)", us, 6.0 * cs_[:, 0].to(torch.int64).sum().item() + 4.0 * pc + 4.0 * Dc * 65, f"fused classification epilogue: {pc * Dc / us / 1e3:.1f} G tree-evals/s, only the per-tree counts leave the chip")
+
 print("| operator | workload | us per call | algorithmic MB | TB/s | of 8 TB/s |\n|---|---|---|---|---|---|")
 print("\n".join(rows))

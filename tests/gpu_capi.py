@@ -119,3 +119,14 @@ def breed_default(value, type_, size, order, rnd, mutate_below, n_elite, n_surv,
     assert rc == 0, L.evogp_hip_error_string(rc)
     out = _np3(v, t, s)
     return out, dec.cpu().numpy()
+
+
+def batch_argmax_count(value, type_, size, X, labels, out_len):
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32), dev(labels, np.int32)]
+    D, var_len = a[3].shape
+    cnt = torch.full((pop,), -5, dtype=torch.int32, device=DEV)
+    rc = L.evogp_hip_batch_argmax_count(pop, D, gp_len, var_len, out_len, *[x.data_ptr() for x in a], cnt.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    torch.cuda.synchronize()
+    return cnt.cpu().numpy()

@@ -268,3 +268,32 @@ def test_full_size_properties(g, oracle):
         d = pred - y[:, 0][None, :]                    # fp32, like the kernel
         ref = (d * d).astype(np.float64).mean(1)       # squares in fp32 (same overflow), sum in fp64
     assert_close_classes(full[pick], ref.astype(np.float32), 1e-4, what="fused vs batch_evaluate")
+
+
+@pytest.mark.parametrize("var_len,out_len,D,L,pop", [(64, 10, 1797, 128, 600), (40, 1, 300, 64, 800), (8, 3, 2500, 64, 700),
+                                                     (5, 1, 1100, 64, 900), (100, 16, 130, 32, 300)])
+def test_batch_evaluate_wide_inputs_and_long_datasets(g, oracle, rng, var_len, out_len, D, L, pop):
+    """The tile-group kernel (more than 32 variables, or more rows than one workgroup keeps resident): arithmetic trees
+    bit-exact per datapoint against the oracle (classifier shape of configs[3] first)."""
+    f = oracle.generate(pop, L, var_len, out_len, 0.5, 0.5, [21, 4], depth2leaf(5), roulette_uniform(ARITH), [-1, 0, 1, 0.5])
+    X = rng.uniform(-3, 3, (D, var_len)).astype(np.float32)
+    got = g.batch_evaluate(*f, X, out_len)
+    want = oracle.batch_evaluate(*f, X, out_len)
+    assert np.array_equal(fbits(got), fbits(want))
+
+
+def test_batch_argmax_count_matches_the_torch_rule(g, oracle, rng):
+    """Fused classification epilogue: count of rows whose arg-max output equals the label, with the arg-max that
+    torch.argmax(clip(softmax(x))) returns (NaN / infinite maximum -> index 0, first maximum otherwise)."""
+    import torch
+
+    pop, L, var_len, out_len, D = 1500, 64, 64, 10, 1797
+    f = oracle.generate(pop, L, var_len, out_len, 0.5, 0.5, [3, 1], depth2leaf(5), roulette_uniform(ARITH), [-1, 0, 1, 0.5])
+    X = rng.uniform(0, 16, (D, var_len)).astype(np.float32)
+    labels = rng.integers(0, out_len, D).astype(np.int32)
+    got = g.batch_argmax_count(*f, X, labels, out_len)
+    outs = torch.from_numpy(oracle.batch_evaluate(*f, X, out_len))                       # (pop, D, out)
+    pred = torch.argmax(torch.clip(torch.softmax(outs, dim=2), 1e-15, 1 - 1e-15), dim=2)
+    want = (pred == torch.from_numpy(labels.astype(np.int64))[None, :]).sum(1).numpy()
+    # exact ties between two soft-max probabilities that differ before rounding are the only legitimate difference
+    assert np.abs(got - want).max() <= 2 and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())
