@@ -86,6 +86,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    # EVOGP_BENCH_SHARE_GPU=1 is a functional check of the multi-rank code path on a box with fewer GPUs than ranks: the
+    # ranks share the visible devices and talk over gloo (RCCL refuses two ranks on one device).  Never a measurement.
+    share_gpu = os.environ.get("EVOGP_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -93,7 +98,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import evogp_amd  # noqa: F401
     from evogp_amd import _lib
@@ -193,7 +201,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not share_gpu else "synthetic; FUNCTIONAL CHECK ONLY: ranks share a GPU over gloo",
             "config": {
                 "workload": "BASELINE configs[1]: SymbolicRegression synthetic 10-var, pop=100k per GPU, 1024 datapoints, "
                             "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass per step",

@@ -3,6 +3,8 @@
 
 #include <atomic>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 namespace evogp {
 
@@ -53,6 +55,63 @@ unsigned *acquire_counter(hipStream_t stream, hipError_t *err) {
     if (e != hipSuccess) { *err = e; return nullptr; }
     *err = hipSuccess;
     return slot;
+}
+
+// Per-stream scratch blocks for the SR-fitness call chain: two blocks of four words that alternate between calls.  The
+// block a call uses was zeroed by the PREVIOUS call's first kernel on the same stream (stream order makes that safe), so
+// the steady state needs no hipMemsetAsync in front of every call.
+struct StreamScratch {
+    unsigned *blocks = nullptr;  // 2 x 4 words
+    int cur = 0;
+    bool next_clean = false;     // the other block was zeroed by the last call's kernel
+};
+static std::mutex g_scratch_mu;
+static std::vector<std::pair<hipStream_t, StreamScratch>> g_scratch[64];
+
+unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hipError_t *err) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    StreamScratch *s = nullptr;
+    for (auto &kv : g_scratch[dev]) if (kv.first == stream) s = &kv.second;
+    if (!s) {
+        g_scratch[dev].emplace_back(stream, StreamScratch{});
+        s = &g_scratch[dev].back().second;
+        hipError_t e = hipMalloc((void **)&s->blocks, 8 * sizeof(unsigned));
+        if (e != hipSuccess) { g_scratch[dev].pop_back(); *err = e; return nullptr; }
+    }
+    const int use = s->cur ^ 1;  // alternate
+    // A call recorded into a HIP graph is replayed without this host code: it must carry its own memset and must not rely
+    // on (or promise) zeroing across calls.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (capturing) {
+        hipError_t e = hipMemsetAsync(s->blocks + 4 * use, 0, 4 * sizeof(unsigned), stream);
+        if (e != hipSuccess) { *err = e; return nullptr; }
+        s->cur = use;
+        s->next_clean = false;
+        *zero_for_next = nullptr;
+        *err = hipSuccess;
+        return s->blocks + 4 * use;
+    }
+    if (!s->next_clean) {
+        hipError_t e = hipMemsetAsync(s->blocks + 4 * use, 0, 4 * sizeof(unsigned), stream);
+        if (e != hipSuccess) { *err = e; return nullptr; }
+    }
+    s->cur = use;
+    s->next_clean = false;
+    *zero_for_next = s->blocks + 4 * (use ^ 1);
+    *err = hipSuccess;
+    return s->blocks + 4 * use;
+}
+
+void call_scratch_next_is_clean(hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto &kv : g_scratch[dev]) if (kv.first == stream) kv.second.next_clean = true;
 }
 
 struct TimerSlot {

@@ -20,6 +20,7 @@
 //     bit-identical to the single-GPU one.
 #include "evogp_defs.hpp"
 #include "launch.hpp"
+#include <cstdlib>
 
 namespace evogp {
 
@@ -128,6 +129,201 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
     }
 }
 
+
+// ---- staged variant (gp_len <= kStagedMaxLen): one WAVE per workgroup, nothing but LDS inside the serial loop ----------
+//
+// The lane-per-tree loop above is latency-bound: every node costs scattered 2- and 4-byte global stores (64 cache lines
+// per instruction) and, for constant leaves, a dependent global load.  Here the serial loop touches only LDS and the rows
+// leave the chip in coalesced pieces:
+//   * every live lane emits exactly ONE node per iteration, so iteration `it` fills column `it` of all 64 rows (finished
+//     lanes emit zeros — the zero tail comes for free).  Values and types go through a ring of kGenChunk columns that the
+//     whole wave flushes every kGenChunk iterations as 64-byte (values) / 32-byte (types) row segments;
+//   * subtree sizes close late (the root closes last), so they are staged for the whole row and flushed at the end;
+//   * the constant table, the leaf probabilities and the pending/open frames live in LDS; the 29-entry roulette table is
+//     reduced once per wave to its non-dominated thresholds (entry i can only be the "largest i with r >= roulette[i]"
+//     if every later entry is strictly larger) — with an ordinary cumulative table that is one entry per function in use.
+constexpr int kGenChunk = 16;
+constexpr int kGenPitch = 68;         // == 4 (mod 64): the 16x4 flush pattern and the per-lane pattern are both conflict-free
+constexpr int kGenConstLds = 256;
+constexpr int kGenThr = 8;
+constexpr int kStagedMaxLen = 256;
+
+static size_t staged_lds_bytes(unsigned gp_len) {
+    return (size_t)kGenChunk * kGenPitch * 4 + (size_t)kGenChunk * kGenPitch * 2 + (size_t)gp_len * kGenPitch * 2 +
+           2 * (size_t)kLevels * kWave * 2 + kGenConstLds * 4 + 64 * 4;
+}
+
+template <bool MO>
+__global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p) {
+    extern __shared__ uint32_t gen_lds[];
+    float *ring_v = reinterpret_cast<float *>(gen_lds);                                // [kGenChunk][kGenPitch]
+    uint16_t *ring_t = reinterpret_cast<uint16_t *>(ring_v + kGenChunk * kGenPitch);   // [kGenChunk][kGenPitch]
+    uint16_t *size_s = ring_t + kGenChunk * kGenPitch;                                 // [gp_len][kGenPitch]
+    uint16_t *frame_s = size_s + (size_t)p.gp_len * kGenPitch;                         // [kLevels][64]: childs | depth << 4
+    uint16_t *open_s = frame_s + kLevels * kWave;                                      // [kLevels][64]
+    float *const_s = reinterpret_cast<float *>(open_s + kLevels * kWave);              // [kGenConstLds]
+    float *misc_s = const_s + kGenConstLds;                                            // leaf probs [11], roulette [29]
+
+    const int lane = threadIdx.x;
+    const unsigned wave_first = blockIdx.x * kWave;
+    const unsigned n = wave_first + lane;
+    const bool active = n < p.pop && (p.active_word == nullptr || (unsigned)p.active_word[n] < p.active_below);
+    const unsigned long long amask = __ballot(active);
+    if (amask == 0ull) return;  // nothing to generate in these 64 rows: they stay untouched
+
+    // ---- tables ----
+    if (lane < kMaxFullDepth) misc_s[lane] = p.leaf_probs[lane];
+    if (lane == kMaxFullDepth) misc_s[lane] = 1.0f;  // depths past the table are leaves
+    const float my_roul = lane < kNumFuncs ? p.roulette[lane] : 0.0f;
+    if (lane < kNumFuncs) misc_s[16 + lane] = my_roul;
+    const bool consts_in_lds = p.n_const <= (unsigned)kGenConstLds;
+    if (consts_in_lds)
+        for (unsigned i = lane; i < p.n_const; i += kWave) const_s[i] = p.consts[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool surv = lane < kNumFuncs && my_roul == my_roul;
+    for (int j = 1; j < kNumFuncs; ++j) {
+        const float rj = misc_s[16 + j];
+        if (j > lane && rj <= my_roul) surv = false;  // a later entry that qualifies whenever this one does
+    }
+    unsigned long long smask = __ballot(surv);
+    const int n_thr = __popcll(smask);
+    float thr[kGenThr];
+    int kv[kGenThr];
+#pragma unroll
+    for (int m = 0; m < kGenThr; ++m) {
+        if (smask) {
+            const int i = __builtin_ctzll(smask);
+            smask &= smask - 1;
+            thr[m] = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(my_roul), i));
+            kv[m] = i + 1;
+        } else {
+            thr[m] = __builtin_inff();  // never reached: draws are <= 1
+            kv[m] = 0;
+        }
+    }
+
+    auto flush_chunk = [&](unsigned chunk, unsigned filled) {
+        // lanes: 16 columns x 4 rows per instruction
+        const unsigned j = lane & 15, rs = lane >> 4;
+        const unsigned node = chunk * kGenChunk + j;
+        const bool in_row = node < p.gp_len;
+#pragma unroll 4
+        for (unsigned r4 = 0; r4 < 16; ++r4) {
+            const unsigned row = r4 * 4 + rs;
+            float v = 0.0f;
+            uint16_t t = 0;
+            if (j < filled) {
+                v = ring_v[j * kGenPitch + row];
+                t = ring_t[j * kGenPitch + row];
+            }
+            if (in_row && ((amask >> row) & 1ull)) {
+                const size_t at = (size_t)(wave_first + row) * p.gp_len + node;
+                p.value[at] = v;
+                p.type[at] = (int16_t)t;
+            }
+        }
+    };
+
+    Taus88 rng(seed_hash(n + p.index_offset, p.keys[0], p.keys[1]));
+    int top = 1, deepest_open = -1;
+    unsigned cnt = 0, it = 0;
+    frame_s[lane] = 1u;  // {childs = 1, depth = 0}
+    for (;; ++it) {
+        const bool live = active && top > 0 && it < (unsigned)kMaxStack;
+        if (!__any(live)) break;
+        float v = 0.0f;
+        int t = 0;
+        if (live) {
+            const uint32_t fr = frame_s[(--top) * kWave + lane];
+            const int childs = (int)(fr & 0xFu) - 1;
+            const int depth = (int)(fr >> 4);
+            const int dl = depth < kMaxFullDepth ? depth : kMaxFullDepth;
+            int new_childs = 0;
+            if (rng.uniform() >= misc_s[dl]) {  // function node (generate.cu:71-100)
+                const float r = rng.uniform();
+                int k = 0;  // largest i with r >= roulette[i], plus one (:77-84)
+                if (n_thr <= kGenThr) {
+#pragma unroll
+                    for (int m = 0; m < kGenThr; ++m) k = r >= thr[m] ? kv[m] : k;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kNumFuncs; ++i) k = r >= misc_s[16 + i] ? i + 1 : k;
+                }
+                t = k <= F_IF ? T_TFUNC : (k <= F_GE ? T_BFUNC : T_UFUNC);
+                v = (float)k;
+                new_childs = t - 1;
+                if (MO) {
+                    if (rng.uniform() <= p.out_prob) {  // output node (:86-96)
+                        const uint32_t oi = rng.next() % p.out_len;
+                        v = bits2f(((oi & 0xFFFFu) << 16) | ((uint32_t)k & 0xFFFFu));
+                        t |= T_OUT;
+                    }
+                }
+            } else {  // leaf (:104-123)
+                if (rng.uniform() <= p.const_prob) {
+                    const uint32_t ci = rng.next() % p.n_const;
+                    if (consts_in_lds) v = const_s[ci];  // wave-uniform choice: a ds_read, not a flat load
+                    else v = p.consts[ci];
+                    t = T_CONST;
+                } else {
+                    v = (float)(rng.next() % p.var_len);
+                    t = T_VAR;
+                }
+            }
+            // close every open node at depth >= this depth: its subtree ended at this index
+            for (int dd = depth; dd <= deepest_open; ++dd) {
+                const unsigned start = open_s[dd * kWave + lane];
+                if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint16_t)(it - start);
+            }
+            open_s[depth * kWave + lane] = (uint16_t)it;
+            deepest_open = depth;
+            cnt = it + 1;
+            if (childs > 0) frame_s[(top++) * kWave + lane] = (uint16_t)((unsigned)childs | ((unsigned)depth << 4));
+            if (new_childs > 0) frame_s[(top++) * kWave + lane] = (uint16_t)((unsigned)new_childs | ((unsigned)(depth + 1) << 4));
+        }
+        const unsigned slot = it & (kGenChunk - 1);
+        ring_v[slot * kGenPitch + lane] = v;
+        ring_t[slot * kGenPitch + lane] = (uint16_t)t;
+        if (slot == kGenChunk - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            flush_chunk(it / kGenChunk, kGenChunk);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (active)
+        for (int dd = 0; dd <= deepest_open; ++dd) {
+            const unsigned start = open_s[dd * kWave + lane];
+            if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint16_t)(cnt - start);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- the partially filled chunk, then zeros up to gp_len ----
+    const unsigned nchunks = (p.gp_len + kGenChunk - 1) / kGenChunk;
+    unsigned c = it / kGenChunk;
+    if ((it & (kGenChunk - 1)) && c < nchunks) { flush_chunk(c, it & (kGenChunk - 1)); ++c; }
+    for (; c < nchunks; ++c) flush_chunk(c, 0);
+
+    // ---- subtree sizes ----
+    {
+        const unsigned j = lane & 15, rs = lane >> 4;
+        for (unsigned ch = 0; ch < nchunks; ++ch) {
+            const unsigned node = ch * kGenChunk + j;
+#pragma unroll 4
+            for (unsigned r4 = 0; r4 < 16; ++r4) {
+                const unsigned row = r4 * 4 + rs;
+                const unsigned len = (unsigned)__shfl((int)cnt, (int)row, 64);
+                uint16_t sz = 0;
+                if (node < len && node < p.gp_len) sz = size_s[node * kGenPitch + row];
+                if (node < p.gp_len && ((amask >> row) & 1ull)) p.size[(size_t)(wave_first + row) * p.gp_len + node] = (int16_t)sz;
+            }
+        }
+    }
+}
+
 } // namespace evogp
 
 using namespace evogp;
@@ -161,8 +357,16 @@ extern "C" int evogp_hip_generate_masked(unsigned pop_size, unsigned gp_len, uns
         return EVOGP_E_NULLPTR;
     GenParams p{pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys, depth2leaf_probs,
                 roulette_funcs, const_samples, value_res, type_res, size_res, tree_index_offset, active_word, active_below};
-    const unsigned blocks = (pop_size + kGenBlock - 1) / kGenBlock;
     hipStream_t stream = (hipStream_t)stream_;
+    static const bool staged_ok = [] { const char *e = getenv("EVOGP_GEN_STAGED"); return !(e && e[0] == '0'); }();
+    if (staged_ok && gp_len <= (unsigned)kStagedMaxLen) {
+        const size_t lds = staged_lds_bytes(gp_len);
+        const unsigned wgs = (pop_size + kWave - 1) / kWave;
+        if (out_len > 1) hipLaunchKernelGGL(generate_staged_kernel<true>, dim3(wgs), dim3(kWave), lds, stream, p);
+        else hipLaunchKernelGGL(generate_staged_kernel<false>, dim3(wgs), dim3(kWave), lds, stream, p);
+        return (int)hipGetLastError();
+    }
+    const unsigned blocks = (pop_size + kGenBlock - 1) / kGenBlock;
     if (out_len > 1) hipLaunchKernelGGL(generate_kernel<true>, dim3(blocks), dim3(kGenBlock), 0, stream, p);
     else hipLaunchKernelGGL(generate_kernel<false>, dim3(blocks), dim3(kGenBlock), 0, stream, p);
     return (int)hipGetLastError();

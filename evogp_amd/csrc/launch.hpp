@@ -33,4 +33,10 @@ const DeviceInfo &device_info();
 // ordered by the stream.  Returns nullptr and sets *err on failure.
 unsigned *acquire_counter(hipStream_t stream, hipError_t *err);
 
+// Four zeroed words for one SR-fitness call on `stream`, without a memset in the steady state: *zero_for_next is the block
+// the NEXT call on this stream will get; a kernel of this call zeroes it and the caller then reports that with
+// call_scratch_next_is_clean (otherwise the next acquire memsets it).
+unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hipError_t *err);
+void call_scratch_next_is_clean(hipStream_t stream);
+
 } // namespace evogp

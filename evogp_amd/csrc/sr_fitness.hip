@@ -34,6 +34,7 @@
 // != 1 — the reference asserts, forward.cu:298-301) get a NaN fitness.
 #include "interp.hpp"
 #include "launch.hpp"
+#include <mutex>
 #include "sr_params.hpp"
 
 namespace evogp {
@@ -315,7 +316,7 @@ static hipError_t launch_pair(const SrParams &p, hipStream_t stream) {
 template <bool STORE>
 static hipError_t launch_general(const SrParams &p, int only_marked, hipStream_t stream) {
     const DeviceInfo &dev = device_info();
-    long blocks = (long)dev.num_cus * 16;
+    long blocks = (long)dev.num_cus * (only_marked ? 4 : 16);  // behind a fast kernel only the marked trees are left
     if (blocks > p.pop) blocks = p.pop;
     if (p.out_len > 1) hipLaunchKernelGGL((sr_general_kernel<true, STORE>), dim3((unsigned)blocks), dim3(64), 0, stream, p, only_marked);
     else hipLaunchKernelGGL((sr_general_kernel<false, STORE>), dim3((unsigned)blocks), dim3(64), 0, stream, p, only_marked);
@@ -326,12 +327,17 @@ static hipError_t launch_general(const SrParams &p, int only_marked, hipStream_t
 //   single output, D >= 256 : K = 4 rows per lane, 16-entry stack, variable registers sized to var_len
 //   multi output,  D >= 128 : K = 2 (16 output accumulators per row live in registers as well)
 //   small datasets          : K = 1, 32-entry stack
+static std::mutex g_chain_mu;  // one for both instantiations of run_population: they share the scratch blocks
+
 template <bool STORE>
 static int run_population(const SrParams &p_in, hipStream_t stream) {
     SrParams p = p_in;
+    // The scratch block handed out below was zeroed by the previous call's first kernel ON THE SAME STREAM; two host
+    // threads feeding one stream must therefore not interleave their acquire + launch sequences.
+    std::lock_guard<std::mutex> chain_lock(g_chain_mu);
     {   // pending-marks flags of this call: follow-up kernels leave at once when nothing was marked for them
         hipError_t me;
-        p.marks = acquire_counter(stream, &me);
+        p.marks = acquire_call_scratch(stream, &p.zero_next, &me);
         if (!p.marks) return (int)me;
     }
     const bool forced = getenv("EVOGP_SR_FORCE_GENERAL") != nullptr;

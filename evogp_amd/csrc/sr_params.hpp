@@ -25,6 +25,7 @@ struct SrParams {
     int ntiles;      // ceil(D / (64*K))
     int only_marked; // != 0: only trees whose output word holds kSentinelHeavy are evaluated
     unsigned long long *stats; // optional cycle counters (profiling builds of the bench only), else nullptr
+    unsigned *zero_next; // four words the first kernel of the chain zeroes for the next call on this stream (or nullptr)
     unsigned *marks; // [0] != 0: some tree carries kSentinelHeavy, [1] != 0: some tree carries kSentinelDeep (may be nullptr)
 };
 

@@ -17,6 +17,9 @@ for K in 8 4; do timeout 240 python scripts/tc_smoke.py $K > $OUT/${TAG}_01_tc_s
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_02_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_02_pytest_gpu.log
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_03_bench.json 2> $OUT/${TAG}_03_bench.err; echo "bench rc=$?" >> $OUT/${TAG}_03_bench.err
 { for A in "EVOGP_SR_ASM=3" "EVOGP_SR_ASM=0" "EVOGP_NATIVE_STEP=0"; do echo "== $A"; env $A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/${TAG}_04_ab.log 2>&1
+# functional check of the N>1 code path of bench.py on this 1-GPU box: two ranks share the GPU over gloo (not a measurement)
+EVOGP_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 5 --warmup 1 --pop-per-gpu 20000 > $OUT/${TAG}_04b_two_ranks_shared_gpu.log 2>&1
+timeout 300 python scripts/bench_ops.py > $OUT/${TAG}_09_ops.md 2>&1
 timeout 200 python scripts/tc_cycles.py > $OUT/${TAG}_05_cycles.json 2>/dev/null
 timeout 300 python scripts/tc_mix.py > $OUT/${TAG}_06_mix.log 2>/dev/null
 cd /tmp

@@ -297,3 +297,55 @@ def test_batch_argmax_count_matches_the_torch_rule(g, oracle, rng):
     want = (pred == torch.from_numpy(labels.astype(np.int64))[None, :]).sum(1).numpy()
     # exact ties between two soft-max probabilities that differ before rounding are the only legitimate difference
     assert np.abs(got - want).max() <= 2 and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())
+
+
+def test_sr_fitness_repeated_calls_streams_and_graph_replay(g, oracle, rng):
+    """The call chain's scratch block alternates per stream and is zeroed by the previous call's first kernel; a call
+    recorded into a HIP graph carries its own memset.  Repeated calls, calls on a side stream, calls that take the
+    fallback kernels in between, and graph replays must all give the same fitness."""
+    import torch
+
+    rou, d2l = roulette_uniform(ARITH), depth2leaf(6)
+    v, t, s = g.generate(3000, 64, 4, 1, 0.5, 0.3, [5, 6], d2l, rou, CS3)
+    X = rng.standard_normal((1024, 4)).astype(np.float32)
+    y = rng.standard_normal((1024, 1)).astype(np.float32)
+    want = oracle.sr_fitness(v, t, s, X, y)
+    a = [g.dev(v, np.float32), g.dev(t, np.int16), g.dev(s, np.int16), g.dev(X, np.float32), g.dev(y, np.float32)]
+
+    def call(out, stream):
+        rc = g.L.evogp_hip_sr_fitness(3000, 1024, 64, 4, 1, 1, *[x.data_ptr() for x in a], out.data_ptr(), 0, stream.cuda_stream)
+        assert rc == 0, g.L.evogp_hip_error_string(rc)
+
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(7):
+        out = torch.full((3000,), 777.0, dtype=torch.float32, device=g.DEV)
+        call(out, side if i % 3 == 2 else main)
+        if i == 3:  # a call of another shape (fallback kernels, different scratch use) in between
+            g.sr_fitness(v[:50], t[:50], s[:50], X[:100], np.tile(y[:100], (1, 1)), use_mse=False, kernel_type=2)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for i, out in enumerate(outs):
+        assert_close_classes(out.cpu().numpy(), want, RTOL_ARITH, 0.0, f"call {i}")
+
+    gout = torch.full((3000,), 777.0, dtype=torch.float32, device=g.DEV)
+    cap = torch.cuda.Stream()
+    cap.wait_stream(main)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap):
+        call(gout, cap)  # warm-up outside the capture
+        cap.synchronize()
+        with torch.cuda.graph(graph, stream=cap):
+            call(gout, torch.cuda.current_stream())
+    for i in range(3):
+        gout.fill_(555.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert_close_classes(gout.cpu().numpy(), want, RTOL_ARITH, 0.0, f"replay {i}")
+    # eager calls after the capture still work
+    out = torch.full((3000,), 777.0, dtype=torch.float32, device=g.DEV)
+    call(out, cap); call(out, main)
+    torch.cuda.synchronize()
+    assert_close_classes(out.cpu().numpy(), want, RTOL_ARITH, 0.0, "after capture")
