@@ -2,8 +2,8 @@
 tournament / truncation selections, the diversity and leaf-biased crossovers, the structural and point mutations."""
 from .selection import (BaseSelection, BaseSelector, DefaultSelection, RankSelection, RankSelector, RouletteSelection,
                         RouletteSelector, TournamentSelection, TournamentSelector, TruncationSelection, TruncationSelector)
-from .crossover import BaseCrossover, DefaultCrossover, DiversityCrossover, LeafBiasedCrossover
-from .mutation import (BaseMutation, CombinedMutation, DefaultMutation, DeleteMutation, HoistMutation, InsertMutation,
+from .crossover import BaseCrossover, CombinedDefaultCrossover, DefaultCrossover, DiversityCrossover, LeafBiasedCrossover
+from .mutation import (BaseMutation, CombinedDefaultMutation, CombinedMutation, DefaultMutation, DeleteMutation, HoistMutation, InsertMutation,
                        MultiConstMutation, MultiPointMutation, SingleConstMutation, SinglePointMutation)
 from .genetic_programming import GeneticProgramming, ParetoFront
 
@@ -11,5 +11,6 @@ __all__ = ["BaseSelection", "DefaultSelection", "RankSelection", "RouletteSelect
            "TruncationSelection", "BaseSelector", "RankSelector", "RouletteSelector", "TournamentSelector",
            "TruncationSelector", "BaseCrossover", "DefaultCrossover", "DiversityCrossover", "LeafBiasedCrossover", "BaseMutation",
            "DefaultMutation", "HoistMutation", "InsertMutation", "DeleteMutation", "SinglePointMutation",
-           "MultiPointMutation", "SingleConstMutation", "MultiConstMutation", "CombinedMutation", "GeneticProgramming",
+           "MultiPointMutation", "SingleConstMutation", "MultiConstMutation", "CombinedMutation", "CombinedDefaultCrossover",
+           "CombinedDefaultMutation", "GeneticProgramming",
            "ParetoFront"]

@@ -88,3 +88,24 @@ class LeafBiasedCrossover(DiversityCrossover):
         leaf = torch.rand(recipients.shape[0], device=recipients.device) < self.leaf_bias
         return (torch.where(leaf, self._leaf_pos(sizes[recipients]), rpos),
                 torch.where(leaf, self._leaf_pos(sizes[donors]), dpos))
+
+
+class CombinedDefaultCrossover(BaseCrossover):
+    """DefaultCrossover on every sub-forest of a CombinedForest: ONE draw of parent pairs shared by all sub-forests (an
+    offspring takes all of its expressions from the same two parents), independent cut points per sub-forest
+    (crossover/combined_dafault.py:8-54)."""
+
+    def __call__(self, forest, survivor_indices: torch.Tensor, target_cnt: int, fitness: torch.Tensor):
+        from ..tree import CombinedForest
+
+        survivors = forest[survivor_indices]
+        dev = survivors.forests[0].batch_node_value.device
+        left, right = torch.randint(0, len(survivors), (2, target_cnt), dtype=torch.int32, device=dev)
+        children = []
+        for sub in survivors.forests:
+            sizes = sub.batch_subtree_size[:, 0].to(torch.int64)
+            raw = torch.randint(0, 2**31 - 1, (2, target_cnt), device=dev)
+            lpos = (raw[0] % sizes[left.long()]).to(torch.int32)
+            rpos = (raw[1] % sizes[right.long()]).to(torch.int32)
+            children.append(sub.crossover(left, right, lpos, rpos))
+        return CombinedForest(children, forest.data_info)

@@ -246,3 +246,25 @@ class CombinedMutation(BaseMutation):
         for op in self.mutation_operator:
             forest = op(forest)
         return forest
+
+
+class CombinedDefaultMutation(BaseMutation):
+    """DefaultMutation on every sub-forest of a CombinedForest, each with ``mutation_rate / number of sub-forests`` so that
+    an individual is touched about as often as with a single forest (mutation/combined_default.py:9-51)."""
+
+    def __init__(self, mutation_rate: float, descriptors):
+        self.mutation_rate = mutation_rate
+        self.descriptors = descriptors
+        self._per_forest = None
+
+    def __call__(self, combined_forest):
+        from ..tree import CombinedForest
+
+        n = len(combined_forest.forests)
+        if self._per_forest is None:
+            ds = [self.descriptors] * n if isinstance(self.descriptors, GenerateDescriptor) else list(self.descriptors)
+            assert len(ds) == n, f"the length of descriptors should be {n}, but got {len(ds)}"
+            self._per_forest = [DefaultMutation(self.mutation_rate / n, d) for d in ds]
+        assert len(self._per_forest) == n, f"the pattern_num should be {len(self._per_forest)}, but got {n}"
+        return CombinedForest([mut(f) for mut, f in zip(self._per_forest, combined_forest.forests)],
+                              combined_forest.data_info)

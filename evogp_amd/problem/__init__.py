@@ -2,6 +2,8 @@
 from .base import BaseProblem
 from .symbolic_regression import SymbolicRegression
 from .classification import Classification
+from .transformation import Transformation
+from .custom_loss import CustomLoss
 from .rollout import LinearTrackingEnv, PendulumEnv, RolloutProblem
 
-__all__ = ["BaseProblem", "SymbolicRegression", "Classification", "RolloutProblem", "LinearTrackingEnv", "PendulumEnv"]
+__all__ = ["BaseProblem", "SymbolicRegression", "Classification", "Transformation", "CustomLoss", "RolloutProblem", "LinearTrackingEnv", "PendulumEnv"]
