@@ -144,6 +144,22 @@ def main():
     else:
         all_nodes = total_nodes
 
+    # the same launch in the other division modes of the fitness path (include/evogp_hip.h), for the record
+    div_ms = {}
+    default_mode = evogp_amd.get_sr_division()
+    for mode in ("ieee", "short", "fast"):
+        evogp_amd.set_sr_division(mode)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib.evogp_hip_timer_begin(stream), "timer_begin")
+        for _ in range(10):
+            step()
+        ms = ctypes.c_float(0)
+        _lib.check(_lib.lib.evogp_hip_timer_end(stream, ctypes.byref(ms)), "timer_end")
+        div_ms[mode] = ms.value / 10
+    evogp_amd.set_sr_division(default_mode)
+
     # one generation of the default GP loop on this shard (fitness + selection + crossover + mutation)
     from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
     from evogp_amd.tree import GenerateDescriptor
@@ -221,8 +237,11 @@ def main():
                 "kernel": "tree_SR_fitness = tc_compile_kernel + sr_tc_kernel<8> (+ the two marked-tree follow-ups); launch_ms covers "
                           "the whole call, HIP events on the launch stream",
                 "launch_ms": launch_s * 1000.0, "algorithmic_bytes": alg_bytes,
+                "division": {"mode": default_mode, "launch_ms_by_mode": div_ms,
+                             "what": "short = IEEE range/special handling with one residual correction (default; bit-identical "
+                                     "fitness to ieee on this workload), ieee = correctly rounded always, fast = no range scaling"},
                 "note": "threaded-code interpreter: ~0.16 algorithmic B per tree-eval at D=1024, bound by the VALU work of the "
-                        "IEEE divisions (~54 clocks per row) and per-instruction latency, not by HBM (DESIGN.md section 5); "
+                        "divisions (~37 clocks per 64 rows in the default short sequence, 54 in the IEEE one) and per-instruction latency, not by HBM (DESIGN.md section 5); "
                         "traffic = FETCH_SIZE + WRITE_SIZE of the call from profiles/pmc_latest.json",
             },
         }

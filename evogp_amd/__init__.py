@@ -5,3 +5,22 @@ from . import ops  # noqa: F401  (loads evogp_amd/lib/libevogp_hip.so and regist
 from . import tree, algorithm, problem, pipeline  # noqa: F401
 
 __version__ = "0.1.0"
+
+
+def set_sr_division(mode: str) -> None:
+    """Division in the threaded-code ``tree_SR_fitness`` path (include/evogp_hip.h ``evogp_hip_set_sr_division``):
+    ``"short"`` (default) — the IEEE sequence with its range scaling and special-case fix-up but one residual correction:
+    faithfully rounded, the correctly rounded quotient for all but ~1 operand pair in 4e9; ``"ieee"`` — always the
+    correctly rounded quotient (+20 % time); ``"fast"`` — no range scaling.  The reference fixes this at build time
+    (``-use_fast_math``, setup.py:55: CUDA's approximate division)."""
+    from . import _lib
+
+    codes = {"ieee": 0, "fast": 1, "short": 2}
+    assert mode in codes, f"mode should be one of {list(codes)}, but got {mode}"
+    _lib.check(_lib.lib.evogp_hip_set_sr_division(codes[mode]), "set_sr_division")
+
+
+def get_sr_division() -> str:
+    from . import _lib
+
+    return ("ieee", "fast", "short")[_lib.lib.evogp_hip_get_sr_division()]

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
     "evogp_hip_debug_set_stats": [_vp],
+    "evogp_hip_set_sr_division": [C.c_int],
+    "evogp_hip_get_sr_division": [],
     "evogp_hip_abi_version": [],
 }
 

@@ -2,6 +2,7 @@
 #include "launch.hpp"
 
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -155,5 +156,29 @@ extern "C" const char *evogp_hip_error_string(int code) {
     default: return hipGetErrorString((hipError_t)code);
     }
 }
+
+// ---- division mode of the SR-fitness fast path ---------------------------------------------------------------------------
+static std::atomic<int> g_sr_division{-1};
+namespace evogp {
+int sr_division_mode() {
+    int m = g_sr_division.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char *e = getenv("EVOGP_SR_DIV");
+        m = EVOGP_DIV_SHORT;
+        if (e && (e[0] == 'i' || e[0] == 'I' || e[0] == '0')) m = EVOGP_DIV_IEEE;
+        if (e && (e[0] == 'f' || e[0] == 'F' || e[0] == '1')) m = EVOGP_DIV_FAST;
+        g_sr_division.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+}  // namespace evogp
+
+extern "C" int evogp_hip_set_sr_division(int mode) {
+    if (mode != EVOGP_DIV_IEEE && mode != EVOGP_DIV_FAST && mode != EVOGP_DIV_SHORT) return EVOGP_E_BADARG;
+    g_sr_division.store(mode, std::memory_order_relaxed);
+    return EVOGP_OK;
+}
+
+extern "C" int evogp_hip_get_sr_division(void) { return evogp::sr_division_mode(); }
 
 extern "C" int evogp_hip_abi_version(void) { return 1; }

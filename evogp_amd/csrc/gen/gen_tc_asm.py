@@ -52,7 +52,7 @@ SLOT = 256  # bytes per handler slot
 NHF = 36    # handlers per flavour
 
 
-def gen(K, DEPTH, stats=False):
+def gen(K, DEPTH, stats=False, fast=0):
     assert K % 4 == 0
     G = K // 4
     P = [24, 24 + K]
@@ -378,12 +378,46 @@ def gen(K, DEPTH, stats=False):
                 a(f"v_mov_b32 v{y + k}, s{sBop}")
         a(f"s_branch {lab(f'divbody_{kind}{fl}')}")
 
-    def div_rows(xs, ys, qs):
+    def div_rows(xs, ys, qs, nanfix=True):
         """IEEE division rows: q = (y == 0) ? NaN : x / y  up to (not including) v_div_fixup (forward.cu:183-187)"""
         d3, d4, d6, d7, d8 = DT
+        if fast == 2:
+            # "short" division: the IEEE sequence with its range scaling (v_div_scale / v_div_fmas / v_div_fixup) but ONE
+            # residual correction instead of a refined reciprocal and two corrections: 9 instead of 13 operations.  Range-
+            # safe like the full sequence; the quotient is the correctly rounded one except when the exact quotient lies
+            # within ~2^-30 ulp of a rounding boundary (measured: 1 of 2^32 random mantissa pairs, ubench/div_faithful.hip).
+            for x, y, q in zip(xs, ys, qs):
+                if nanfix:
+                    a(f"v_cmp_neq_f32 vcc, 0, v{y}")
+                    a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")
+                a(f"v_div_scale_f32 v{d3}, vcc, v{y}, v{y}, v{x}")
+                a(f"v_rcp_f32 v{d4}, v{d3}")
+                a(f"v_div_scale_f32 v{d6}, vcc, v{x}, v{y}, v{x}")
+                a(f"v_mul_f32 v{d7}, v{d6}, v{d4}")
+                a(f"v_fma_f32 v{d8}, -v{d3}, v{d7}, v{d6}")
+                a("s_nop 1")  # v_div_fmas reads the VCC of the second v_div_scale: 4 wait states
+                a(f"v_div_fmas_f32 v{q}, v{d8}, v{d4}, v{d7}")
+            return
+        if fast:
+            # "fast" division (opt-in): reciprocal, quotient, ONE residual correction -- faithfully rounded (the result is
+            # the correctly rounded quotient unless the exact quotient lies within ~2^-23 ulp of a rounding boundary),
+            # no range scaling: |y| > 2^126 gives 0, a quotient beyond 2^128 gives NaN.  Special operands are still put
+            # right by v_div_fixup.  5 instead of 11 dependent operations per row.
+            for x, y, q in zip(xs, ys, qs):
+                a(f"v_rcp_f32 v{d4}, v{y}")
+                if nanfix:
+                    a(f"v_cmp_neq_f32 vcc, 0, v{y}")
+                    a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")
+                else:
+                    a("s_nop 0")  # gfx940+: one wait state between a transcendental and the VALU that reads its result
+                a(f"v_mul_f32 v{d7}, v{x}, v{d4}")
+                a(f"v_fma_f32 v{d8}, -v{y}, v{d7}, v{x}")
+                a(f"v_fma_f32 v{q}, v{d8}, v{d4}, v{d7}")
+            return
         for x, y, q in zip(xs, ys, qs):
-            a(f"v_cmp_neq_f32 vcc, 0, v{y}")
-            a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")  # a NaN numerator makes the quotient NaN
+            if nanfix:
+                a(f"v_cmp_neq_f32 vcc, 0, v{y}")
+                a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")  # a NaN numerator makes the quotient NaN
             a(f"v_div_scale_f32 v{d3}, vcc, v{y}, v{y}, v{x}")
             a(f"v_rcp_f32 v{d4}, v{d3}")
             a(f"v_div_scale_f32 v{d6}, vcc, v{x}, v{y}, v{x}")
@@ -435,11 +469,28 @@ def gen(K, DEPTH, stats=False):
         for kind in ("Tc", "cT"):
             x, y = (T, P[fl]) if kind == "Tc" else (P[fl], T)
             a(f"{lab(f'divbody_{kind}{fl}')}:")
-            div_rows([x + k for k in range(K)], [y + k for k in range(K)], [Q + k for k in range(K)])
-            a(f"s_mov_b32 m0, s{sDST}")
-            for k in range(K):
-                a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
-            epilogue()
+            # `b == 0 ? NaN : a / b` (forward.cu:183-187): ONE test for a zero divisor anywhere in the K x 64 block -- the
+            # smallest |b| -- instead of a compare and a select per row; only a block with a zero takes the rows that
+            # turn the numerator into NaN.  (A NaN divisor drops out of the minimum and makes its quotient NaN anyway.)
+            ys_ = [y + k for k in range(K)]
+            acc = DT[0]
+            a(f"v_min3_f32 v{acc}, |v{ys_[0]}|, |v{ys_[1]}|, |v{ys_[2]}|")
+            rest = ys_[3:]
+            while len(rest) >= 2:
+                a(f"v_min3_f32 v{acc}, v{acc}, |v{rest[0]}|, |v{rest[1]}|")
+                rest = rest[2:]
+            if rest:
+                a(f"v_min_f32 v{acc}, v{acc}, |v{rest[0]}|")
+            a(f"v_cmp_eq_f32 vcc, 0, v{acc}")
+            a(f"s_cbranch_vccnz {lab(f'divzero_{kind}{fl}')}")
+            for variant in (False, True):
+                if variant:
+                    a(f"{lab(f'divzero_{kind}{fl}')}:")
+                div_rows([x + k for k in range(K)], ys_, [Q + k for k in range(K)], nanfix=variant)
+                a(f"s_mov_b32 m0, s{sDST}")
+                for k in range(K):
+                    a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
+                epilogue()
 
     # end of the program: fold this tile's errors into the accumulator.  The labels of the tile were prefetched by the
     # last instruction of the program (the compiler gives END the LDS offset of y as its "variable"), so they sit in
@@ -562,10 +613,10 @@ def gen(K, DEPTH, stats=False):
     body = "\n".join(f'    "{line}\\n\\t"' for line in L)
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV)]
     clob_txt = ", ".join(clob)
-    name = f"K{K}" + ("S" if stats else "")
+    name = f"K{K}" + ("S" if stats else "") + ("", "F", "H")[fast]
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
-    if K == 8 and not stats:
+    if K == 8 and not stats and not fast:
         out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
@@ -586,4 +637,6 @@ if __name__ == "__main__":
             f.write(gen(K, depth))
             if K == 8:
                 f.write(gen(K, depth, stats=True))  # cycle-accounting build (its top stack slot holds the counters)
+            f.write(gen(K, depth, fast=1))          # fast division (no range scaling)
+            f.write(gen(K, depth, fast=2))          # short division (range-safe, one correction)
         print("wrote", f"{outdir}/tc_interp_k{K}.inc")

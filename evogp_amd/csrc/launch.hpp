@@ -33,6 +33,10 @@ const DeviceInfo &device_info();
 // ordered by the stream.  Returns nullptr and sets *err on failure.
 unsigned *acquire_counter(hipStream_t stream, hipError_t *err);
 
+// 0 = IEEE division in every kernel (default), 1 = the threaded-code fitness path uses the fast division
+// (evogp_hip_set_sr_division / EVOGP_SR_DIV=fast)
+int sr_division_mode();
+
 // Four zeroed words for one SR-fitness call on `stream`, without a memset in the steady state: *zero_for_next is the block
 // the NEXT call on this stream will get; a kernel of this call zeroes it and the caller then reports that with
 // call_scratch_next_is_clean (otherwise the next acquire memsets it).

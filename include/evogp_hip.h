@@ -168,6 +168,27 @@ int evogp_hip_debug_set_stats(unsigned long long *device_counters);
 /* Human-readable text for a return code of any function above. */
 const char *evogp_hip_error_string(int code);
 
+/* Division in the threaded-code SR-fitness path (no counterpart in the reference's ABI: the reference fixes its division
+ * at BUILD time -- setup.py:55 compiles the kernels with -use_fast_math, i.e. CUDA's approximate 2-ulp division).
+ *   EVOGP_DIV_SHORT (default)  the IEEE sequence with all of its range and special-case handling (v_div_scale,
+ *                   v_div_fmas, v_div_fixup) but ONE residual correction instead of a refined reciprocal plus two: 9
+ *                   operations per quotient instead of 13.  Faithfully rounded; it is the correctly rounded quotient
+ *                   except for about 1 operand pair in 4e9 (1 of 2^32 random mantissa pairs, scripts/ubench/
+ *                   div_faithful.hip), where it is the neighbouring float.  Fitness vectors of 200 k trees x 1024 rows
+ *                   were bit-identical to the IEEE mode (scripts/div_modes.py).
+ *   EVOGP_DIV_IEEE  every quotient is the correctly rounded IEEE-754 quotient, as the CPU oracle computes it (+20 % time).
+ *   EVOGP_DIV_FAST  reciprocal, quotient, one residual correction, no range scaling: |b| > 2^126 gives 0 and
+ *                   |a/b| >= 2^128 gives NaN instead of inf (-4 % time against SHORT).
+ * Affects only tree_SR_fitness with one output on the + - * / function set (the threaded-code path); every other
+ * kernel (evaluate, batch_evaluate, the register interpreters) divides with the IEEE sequence.
+ * Environment: EVOGP_SR_DIV=ieee|short|fast selects the mode of a process that never calls the setter. */
+#define EVOGP_OK 0
+#define EVOGP_DIV_IEEE 0
+#define EVOGP_DIV_FAST 1
+#define EVOGP_DIV_SHORT 2
+int evogp_hip_set_sr_division(int mode);
+int evogp_hip_get_sr_division(void);
+
 /* ABI version of this header: bumped when a signature changes. */
 int evogp_hip_abi_version(void);
 

@@ -30,7 +30,7 @@ i=0
 for set in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$TAG$i -o pmc -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-  python $R/scripts/rocpd_summary.py $(find $OUT/pmc_$TAG$i -name "*.db" | head -1) 2>&1 | grep -A40 "counter" | grep -i "counter\|---\|sr_tc\|tc_compile\|breed\|generate" > $OUT/${TAG}_08_pmc$i.md
+  python $R/scripts/rocpd_summary.py $(find $OUT/pmc_$TAG$i -name "*.db" | head -1) 2>&1 | grep -A400 "counter" | grep -i "counter\|---\|sr_tc\|tc_compile\|breed\|generate" > $OUT/${TAG}_08_pmc$i.md
   rm -rf $OUT/pmc_$TAG$i
 done
 tail -2 $OUT/${TAG}_00_smoke.log; tail -1 $OUT/${TAG}_01_tc_smoke_8.log; tail -2 $OUT/${TAG}_02_pytest_gpu.log; cut -c1-400 $OUT/${TAG}_03_bench.json; head -6 $OUT/${TAG}_07_kernel_stats.md | cut -c1-160

@@ -349,3 +349,37 @@ def test_sr_fitness_repeated_calls_streams_and_graph_replay(g, oracle, rng):
     call(out, cap); call(out, main)
     torch.cuda.synchronize()
     assert_close_classes(out.cpu().numpy(), want, RTOL_ARITH, 0.0, "after capture")
+
+
+@pytest.mark.parametrize("D", [1, 300])
+def test_sr_fitness_division_modes_on_special_operands(g, oracle, D):
+    """Every ordered pair of special operands through `x_i / x_j` in the threaded-code path, in the three division modes
+    (include/evogp_hip.h: evogp_hip_set_sr_division).  IEEE and SHORT must reproduce the oracle's |quotient| — classes
+    exactly, values to the last bit for D = 1 — over the whole range; FAST on the pairs inside its documented range."""
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 3.0, -7.5, 0.1, np.inf, -np.inf, np.nan, 1e-45, -3e-39, 1.1754944e-38, 2e-38,
+                     1e-30, 4e-20, 1e20, -6e29, 8.5e37, 1.7e38, -3.4e38, 3.4028235e38, 2.0**-126, 2.0**126, 2.0**127,
+                     5e-324, 1.0000001, 0.99999994, 16777216.0, 1.0 / 3.0], dtype=np.float32)
+    n = len(vals)
+    assert n <= 32
+    pop, L = n * n, 8
+    v = np.zeros((pop, L), np.float32); t = np.zeros((pop, L), np.int16); s = np.zeros((pop, L), np.int16)
+    ii, jj = np.divmod(np.arange(pop), n)
+    v[:, 0] = 4.0; t[:, 0] = 3; s[:, 0] = 3          # DIV, binary function
+    v[:, 1] = ii; t[:, 1] = 0; s[:, 1] = 1           # left operand  x_i
+    v[:, 2] = jj; t[:, 2] = 0; s[:, 2] = 1           # right operand x_j
+    X = np.tile(vals[None, :], (D, 1)).astype(np.float32)
+    y = np.zeros((D, 1), np.float32)
+    want = oracle.sr_fitness(v, t, s, X, y, use_mse=False)
+    with np.errstate(all="ignore"):
+        q = np.where(vals[jj] == 0, np.float32(np.nan), vals[ii] / vals[jj]).astype(np.float32)
+    in_range = np.isfinite(q) & (np.abs(vals[jj]) <= 2.0**126) & (np.abs(vals[jj]) >= 2.0**-126) & \
+        ((np.abs(q) >= 2.0**-126) | (q == 0)) & (np.abs(vals[ii]) >= 2.0**-126)
+    try:
+        for mode, code in (("ieee", 0), ("short", 2), ("fast", 1)):
+            assert g.L.evogp_hip_set_sr_division(code) == 0 and g.L.evogp_hip_get_sr_division() == code
+            got = g.sr_fitness(v, t, s, X, y, use_mse=False)
+            sel = np.ones(pop, bool) if mode != "fast" else in_range
+            assert_close_classes(got[sel], want[sel], 0.0 if D == 1 else 1e-6, 0.0, f"{mode} division, D={D}")
+    finally:
+        assert g.L.evogp_hip_set_sr_division(2) == 0
+    assert g.L.evogp_hip_set_sr_division(7) < 0
