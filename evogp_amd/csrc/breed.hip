@@ -22,6 +22,8 @@
 #include "evogp_defs.hpp"
 #include "launch.hpp"
 #include "replace_row.hpp"
+#include <cstdint>
+#include <cstdlib>
 
 namespace evogp {
 
@@ -141,6 +143,118 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
     }
 }
 
+// ---- four rows per wave -------------------------------------------------------------------------------------------------
+// Same two phases, but BUILD works in groups of 16 lanes (replace_row.hpp): the workgroup's 16 groups build 16 rows at a
+// time, so a chunk of 64 rows is four steps of dependent memory round trips instead of sixteen.  A mutated child is staged
+// in the group's own LDS row (8 bytes per node) between the two replacements.
+__global__ __launch_bounds__(kRepBlock) void breed_group_kernel(BreedParams a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char breed_lds[];
+    constexpr int kGroups = kRepBlock / kGroupLanes;
+    const int w = uni((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int g = threadIdx.x / kGroupLanes;           // group in the workgroup
+    const int gl = threadIdx.x & (kGroupLanes - 1);
+    unsigned char *mine = breed_lds + (size_t)g * a.gp_len * 8;
+    float *cv = (float *)mine;
+    int16_t *ct = (int16_t *)(mine + (size_t)a.gp_len * 4);
+    int16_t *cs = ct + a.gp_len;
+    __shared__ int dec_s[10][64];
+    const int nchunks = (a.row_count + 63) >> 6;
+    const int row_end = a.row_begin + a.row_count;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int n0 = a.row_begin + (c << 6);
+        // ---- DECIDE (wave 0), as in breed_kernel ----
+        const int n = n0 + lane;
+        int li = 0, ri = 0, S = 0, p = 0, q = 0, m = 0, o = 0, dm = 0;
+        unsigned r5 = 0;
+        bool fallback = true, mutating = false;
+        if (w == 0 && n < row_end) {
+            if (n < a.n_elite) {
+                li = a.order[n];
+                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
+                ri = li;
+                S = (int)a.s[(size_t)li * a.gp_len];
+                S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+            } else {
+                const int i = n - a.n_elite;
+                const unsigned r0 = (unsigned)a.rnd[i], r1 = (unsigned)a.rnd[a.n_new + i], r2 = (unsigned)a.rnd[2 * a.n_new + i],
+                               r3 = (unsigned)a.rnd[3 * a.n_new + i], r4 = (unsigned)a.rnd[4 * a.n_new + i];
+                r5 = (unsigned)a.rnd[5 * a.n_new + i];
+                li = a.order[r0 % (unsigned)a.n_surv];
+                ri = a.order[r1 % (unsigned)a.n_surv];
+                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
+                ri = ri < 0 ? 0 : (ri >= a.pop ? a.pop - 1 : ri);
+                const int16_t *ls = a.s + (size_t)li * a.gp_len, *rs = a.s + (size_t)ri * a.gp_len;
+                S = (int)ls[0];
+                int RS = (int)rs[0];
+                S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+                RS = RS < 0 ? 0 : (RS > a.gp_len ? a.gp_len : RS);
+                p = S > 0 ? (int)(r2 % (unsigned)S) : 0;
+                q = RS > 0 ? (int)(r3 % (unsigned)RS) : 0;
+                fallback = S <= 0 || RS <= 0;
+                if (!fallback) {
+                    m = (int)rs[q];
+                    o = (int)ls[p];
+                    fallback = m < 1 || q + m > a.gp_len || S + (m - o) > a.gp_len;  // mutation.cu:279-289
+                }
+                mutating = r4 < a.mutate_below;
+                if (mutating) dm = (int)a.ds[(size_t)(n - a.row_begin) * a.gp_len];
+            }
+        }
+        if (w == 0) {
+            dec_s[0][lane] = li; dec_s[1][lane] = ri; dec_s[2][lane] = S; dec_s[3][lane] = p; dec_s[4][lane] = q;
+            dec_s[5][lane] = m; dec_s[6][lane] = o; dec_s[7][lane] = dm; dec_s[8][lane] = (int)r5;
+            dec_s[9][lane] = (fallback ? 1 : 0) | (mutating ? 2 : 0);
+        }
+        __syncthreads();
+        // ---- BUILD: 16 rows per step ----
+        const int rows = row_end - n0 < 64 ? row_end - n0 : 64;
+        for (int l0 = 0; l0 < rows; l0 += kGroups) {
+            const int l = l0 + g;
+            const bool active = l < rows;
+            const int lc = active ? l : 0;
+            const int nn = n0 + lc;
+            const size_t off = (size_t)(nn - a.row_begin) * a.gp_len;
+            const int li_ = dec_s[0][lc], ri_ = dec_s[1][lc], S_ = dec_s[2][lc], p_ = dec_s[3][lc], q_ = dec_s[4][lc],
+                      m_ = dec_s[5][lc], o_ = dec_s[6][lc], flags = dec_s[9][lc];
+            const size_t lo = (size_t)li_ * a.gp_len, ro = (size_t)ri_ * a.gp_len;
+            const bool fb = (flags & 1) != 0, mu = active && (flags & 2) != 0;
+            // the child of the crossover goes straight to its row, or to the group's LDS row when it mutates next
+            float *tv = mu ? cv : a.ov + off;
+            int16_t *tt = mu ? ct : a.ot + off, *ts = mu ? cs : a.os + off;
+            build_row_group(a.v + lo, a.t + lo, a.s + lo, a.v + ro, a.t + ro, a.s + ro, S_, p_, q_, m_, o_, fb, active,
+                            a.gp_len, tv, tt, ts);
+            int pm = -1;
+            if (__any(mu)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (mu) {
+                    int CS = (int)cs[0];
+                    CS = CS < 0 ? 0 : (CS > a.gp_len ? a.gp_len : CS);
+                    const unsigned r5_ = (unsigned)dec_s[8][lc];
+                    pm = CS > 0 ? (int)((r5_ % (unsigned)kMaxStack) % (unsigned)CS) : 0;  // mutation/default.py:59-66
+                    const int dm_ = dec_s[7][lc];
+                    bool mfall = CS <= 0 || dm_ < 1 || dm_ > a.gp_len;                   // mutation.cu:150-160 (+ donor sanity)
+                    int co = 0;
+                    if (!mfall) {
+                        co = (int)cs[pm];
+                        mfall = CS + (dm_ - co) > a.gp_len;                              // :170-180
+                    }
+                    build_row_group(cv, ct, cs, a.dv + off, a.dt + off, a.ds + off, CS, pm, 0, dm_, co, mfall, true, a.gp_len,
+                                    a.ov + off, a.ot + off, a.os + off);
+                }
+                __builtin_amdgcn_wave_barrier();  // the staging rows are rewritten in the next step
+            }
+            if (a.decisions && active && gl == 0 && nn >= a.n_elite) {
+                int *d = a.decisions + (size_t)(nn - a.row_begin) * 6;
+                d[0] = li_; d[1] = ri_; d[2] = p_; d[3] = q_; d[4] = mu ? 1 : 0; d[5] = pm;
+            }
+        }
+        __syncthreads();  // the next chunk's decisions overwrite dec_s
+    }
+}
+
 } // namespace evogp
 
 using namespace evogp;
@@ -176,6 +290,13 @@ extern "C" int evogp_hip_breed_default_rows(int pop_size, int gp_len, int n_elit
     long blocks = ((long)row_count + 63) / 64;  // one workgroup per 64 rows
     const long cap = (long)dev.num_cus * 8 * 4;
     if (blocks > cap) blocks = cap;
+    static const bool groups_on = [] { const char *e = getenv("EVOGP_REPLACE_GROUPS"); return !(e && e[0] == '0'); }();
+    const size_t lds_groups = (size_t)(kRepBlock / kGroupLanes) * gp_len * 8;
+    if (groups_on && gp_len % 4 == 0 && lds_groups <= 48 * 1024 && (uintptr_t)value_res % 16 == 0 && (uintptr_t)type_res % 8 == 0 &&
+        (uintptr_t)size_res % 8 == 0) {
+        hipLaunchKernelGGL(breed_group_kernel, dim3((unsigned)blocks), dim3(kRepBlock), lds_groups, (hipStream_t)stream_, a);
+        return (int)hipGetLastError();
+    }
     const size_t lds = (size_t)(kRepBlock / 64) * gp_len * 8;
     hipLaunchKernelGGL(breed_kernel, dim3((unsigned)blocks), dim3(kRepBlock), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();

@@ -22,6 +22,8 @@
 #include "evogp_defs.hpp"
 #include "launch.hpp"
 #include "replace_row.hpp"
+#include <cstdint>
+#include <cstdlib>
 
 namespace evogp {
 
@@ -86,6 +88,75 @@ __global__ __launch_bounds__(kRepBlock) void crossover_kernel(CrossParams a) {
     }
 }
 
+// ---- group variants: four output trees per wave (replace_row.hpp) ----------------------------------------------------
+__global__ __launch_bounds__(kRepBlock) void mutate_group_kernel(MutateParams a) {
+    constexpr int kGroups = kRepBlock / kGroupLanes;
+    const int g = threadIdx.x / kGroupLanes;
+    for (int base = blockIdx.x * kGroups; base < a.pop; base += gridDim.x * kGroups) {
+        const int n = base + g;
+        const bool active = n < a.pop;
+        const size_t off = (size_t)(active ? n : 0) * a.gp_len;
+        const float *Lv = a.ov + off; const int16_t *Lt = a.ot + off, *Ls = a.os + off;
+        const float *Rv = a.nv + off; const int16_t *Rt = a.nt + off, *Rs = a.ns + off;
+        int S = (int)Ls[0];
+        S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+        const int p = a.idx[active ? n : 0];
+        const int m = (int)Rs[0];
+        bool fallback = p < 0 || p >= S || m < 1 || m > a.gp_len;  // mutation.cu:150-160 (+ donor sanity)
+        int o = 0;
+        if (!fallback) {
+            o = (int)Ls[p];
+            fallback = S + (m - o) > a.gp_len;  // :170-180
+        }
+        build_row_group(Lv, Lt, Ls, Rv, Rt, Rs, S, p, 0, m, o, fallback, active, a.gp_len, a.rv + off, a.rt + off, a.rs + off);
+    }
+}
+
+__global__ __launch_bounds__(kRepBlock) void crossover_group_kernel(CrossParams a) {
+    constexpr int kGroups = kRepBlock / kGroupLanes;
+    const int g = threadIdx.x / kGroupLanes;
+    for (int base = blockIdx.x * kGroups; base < a.pop_new; base += gridDim.x * kGroups) {
+        const int n = base + g;
+        const bool active = n < a.pop_new;
+        const int nn = active ? n : 0;
+        int li = a.left_idx[nn];
+        li = li < 0 ? 0 : (li >= a.pop_ori ? a.pop_ori - 1 : li);  // the reference does not check (mutation.cu:246-248)
+        const int ri = a.right_idx[nn];
+        const int p = a.left_node[nn], q = a.right_node[nn];
+        bool fallback = ri < 0 || ri >= a.pop_ori;  // mutation.cu:256-266
+        const size_t lo = (size_t)li * a.gp_len, ro = (size_t)(fallback ? li : ri) * a.gp_len, off = (size_t)nn * a.gp_len;
+        const float *Lv = a.v + lo; const int16_t *Lt = a.t + lo, *Ls = a.s + lo;
+        const float *Rv = a.v + ro; const int16_t *Rt = a.t + ro, *Rs = a.s + ro;
+        int S = (int)Ls[0];
+        S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+        const int RS = (int)Rs[0];
+        int m = 0, o = 0;
+        // node indices outside the live trees are undefined in the reference; here: copy left
+        fallback = fallback || p < 0 || p >= S || q < 0 || q >= RS || q >= a.gp_len;
+        if (!fallback) {
+            m = (int)Rs[q];
+            o = (int)Ls[p];
+            fallback = m < 1 || q + m > a.gp_len || S + (m - o) > a.gp_len;  // :279-289
+        }
+        build_row_group(Lv, Lt, Ls, Rv, Rt, Rs, S, p, q, m, o, fallback, active, a.gp_len, a.rv + off, a.rt + off, a.rs + off);
+    }
+}
+
+// the group kernels store 16 / 8 bytes at a time: rows must start on such boundaries
+static bool group_ok(int gp_len, const void *rv, const void *rt, const void *rs) {
+    static const bool enabled = [] { const char *e = getenv("EVOGP_REPLACE_GROUPS"); return !(e && e[0] == '0'); }();
+    return enabled && gp_len % 4 == 0 && (uintptr_t)rv % 16 == 0 && (uintptr_t)rt % 8 == 0 && (uintptr_t)rs % 8 == 0;
+}
+
+static unsigned grid_for_groups(long trees) {
+    const DeviceInfo &dev = device_info();
+    const long per_block = kRepBlock / kGroupLanes;
+    long blocks = (trees + per_block - 1) / per_block;
+    const long cap = (long)dev.num_cus * 8 * 4;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
 static unsigned grid_for(long trees) {
     const DeviceInfo &dev = device_info();
     long blocks = (trees + (kRepBlock / 64) - 1) / (kRepBlock / 64);
@@ -108,7 +179,8 @@ extern "C" int evogp_hip_mutate(int pop_size, int gp_len, const float *value_ori
         return EVOGP_E_NULLPTR;
     MutateParams a{value_ori, type_ori, size_ori, mutate_indices, value_new, type_new, size_new,
                    value_res, type_res, size_res, pop_size, gp_len};
-    hipLaunchKernelGGL(mutate_kernel, dim3(grid_for(pop_size)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
+    if (group_ok(gp_len, value_res, type_res, size_res)) hipLaunchKernelGGL(mutate_group_kernel, dim3(grid_for_groups(pop_size)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(mutate_kernel, dim3(grid_for(pop_size)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
 
@@ -122,6 +194,7 @@ extern "C" int evogp_hip_crossover(int pop_size_ori, int pop_size_new, int gp_le
         return EVOGP_E_NULLPTR;
     CrossParams a{value_ori, type_ori, size_ori, left_idx, right_idx, left_node_idx, right_node_idx,
                   value_res, type_res, size_res, pop_size_ori, pop_size_new, gp_len};
-    hipLaunchKernelGGL(crossover_kernel, dim3(grid_for(pop_size_new)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
+    if (group_ok(gp_len, value_res, type_res, size_res)) hipLaunchKernelGGL(crossover_group_kernel, dim3(grid_for_groups(pop_size_new)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(crossover_kernel, dim3(grid_for(pop_size_new)), dim3(kRepBlock), 0, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
