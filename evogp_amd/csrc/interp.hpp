@@ -176,8 +176,9 @@ struct RegVars {
     __device__ inline float get(int k, uint32_t var) const { return v[k][var]; }
 };
 struct LdsVars {
-    const float *base;  // this wave's block, already offset by the lane
-    __device__ inline float get(int, uint32_t var) const { return base[var * 64]; }
+    const float *base;  // the workgroup's [variable][row] block, already offset to this lane's first row
+    int stride;         // rows per variable; a lane's K rows are consecutive
+    __device__ inline float get(int k, uint32_t var) const { return base[var * stride + k]; }
 };
 
 template <bool MO, bool LEAN, int K, int DEPTH, class VA>

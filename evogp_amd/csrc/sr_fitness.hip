@@ -341,7 +341,8 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         if (!p.marks) return (int)me;
     }
     const bool forced = getenv("EVOGP_SR_FORCE_GENERAL") != nullptr;
-    if (STORE && !forced && p.out_len <= kMaxOutRegs && (size_t)p.var_len * 256 <= 150 * 1024 && (p.var_len > 32 || p.D > 1024)) {
+    if (STORE && !forced && p.out_len <= kMaxOutRegs && ((size_t)p.var_len + (p.out_len > 1 ? 8 * (size_t)p.out_len : 0)) * 256 <= 150 * 1024 &&
+        (p.var_len > 32 || p.D > 1024)) {
         // more variables than a register tuple holds, or more rows than one workgroup keeps resident: tile-group kernel
         hipError_t we = launch_wide_store(p, stream);
         if (we != hipSuccess) return (int)we;

@@ -3,11 +3,14 @@
 // results[t][d][:] = tree_t(X[d][:])  for every tree t and every row d of a shared dataset, like
 // evogp_hip_batch_evaluate (src/evogp/tree/forest.py:143-176), for the shapes the register kernels of
 // sr_fitness.hip cannot keep resident: more than 32 variables, or a dataset too large for one workgroup (the classifier
-// config: 1797 rows x 64 variables = 460 KB).  The dataset is cut into GROUPS of W tiles of 64 rows; a workgroup owns
-// one group for its whole life: wave w stages its tile's rows into LDS as [variable][lane] (any number of variables up
-// to the LDS size) and then walks the workgroup's share of the trees with the wave-uniform register-stack interpreter
-// of interp.hpp (variables are read from LDS instead of a register tuple).  Waves never synchronise: there is nothing
-// to reduce across rows.  Workgroup (g, i) takes trees i, i + n, i + 2n, ... on group g.
+// config: 1797 rows x 64 variables = 460 KB).  The dataset is cut into GROUPS of R = 64 K rows; a workgroup owns one
+// group for its whole life: it stages the group's rows ONCE into LDS as [variable][row] (any number of variables up to
+// the LDS size) and its eight waves then walk DIFFERENT trees over the SAME rows — lane l holds rows K l .. K l + K - 1 —
+// with the wave-uniform register-stack interpreter of interp.hpp (variables are read from LDS instead of a register
+// tuple).  Sharing the rows between the waves is what makes K > 1 affordable (one copy of 64 variables x 256 rows is
+// 64 KB) and K rows per dispatch is what amortises the interpreter: the first version (a private tile per wave, K = 1,
+// two waves per SIMD) ran at 1.4 node-rows per clock and CU.  Waves never synchronise after the staging.
+// Workgroup (g, i) of n takes trees 8 i + w, 8 (i + n) + w, ... on group g.
 //
 // MODE 0 stores the outputs; MODE 1 is the epilogue of the Classification problem (src/evogp/problem/classification.py
 // :62-75): per (tree, row) the arg-max of the outputs is compared with the row's label and only the COUNT of matches
@@ -20,6 +23,7 @@
 #include "interp.hpp"
 #include "launch.hpp"
 #include "sr_params.hpp"
+#include <cstdlib>
 
 namespace evogp {
 
@@ -36,60 +40,104 @@ struct WideParams {
     int ngroups, workers;  // grid = ngroups * workers workgroups
 };
 
-constexpr int kWideDepth = 32;
+constexpr int kWideWaves = 8;
+struct __attribute__((packed, aligned(4))) Unaligned4 { float x, y, z, w; };  // 16-byte store at 4-byte alignment
+constexpr unsigned kDeepCountBit = 0x80000000u;  // MODE 1: set in counts[t] for a tree the register stack cannot hold
 
-template <bool MO, int MODE>
-__global__ __launch_bounds__(512) void sr_wide_kernel(WideParams p) {
-    extern __shared__ float wide_lds[];  // [wave][variable][lane]
+// MODE 1 follow-up: trees marked deep are counted with the scratch-stack interpreter, one wave per tree, lanes over rows
+__global__ __launch_bounds__(64) void wide_deep_count_kernel(WideParams p) {
+    if (p.marks && p.marks[1] == 0u) return;
+    const int lane = threadIdx.x;
+    float stk[kMaxStack + 2];
+    float o16[kMaxOutRegs];
+    for (int t = blockIdx.x; t < p.pop; t += gridDim.x) {
+        if ((uni(p.counts[t]) & kDeepCountBit) == 0u) continue;
+        const size_t row = (size_t)t * p.gp_len;
+        int len = uni((int)p.size[row]);
+        len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
+        unsigned hits = 0;
+        for (int d0 = 0; d0 < p.D; d0 += 64) {
+            const int d = d0 + lane, dc = d < p.D ? d : p.D - 1;
+            (void)run_general<true>(p.type + row, p.value + row, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, o16, stk);
+            int best = 0;
+            float m = o16[0];
+            bool poisoned = m != m;
+            for (int o = 1; o < p.out_len; ++o) {
+                const float x = o16[o];
+                poisoned |= x != x;
+                if (x > m) { m = x; best = o; }
+            }
+            if (poisoned || __builtin_isinf(m)) best = 0;
+            hits += (unsigned)__popcll(__ballot(d < p.D && best == p.labels[dc]));
+        }
+        if (lane == 0) p.counts[t] = hits;
+    }
+}
+
+template <bool MO, int MODE, int K, int DEPTH>
+__global__ __launch_bounds__(kWideWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void sr_wide_kernel(WideParams p) {
+    extern __shared__ float wide_lds[];  // [variable][R]
+    constexpr int R = K * 64;
     const int lane = threadIdx.x & 63;
     const int w = uni((int)(threadIdx.x >> 6));
-    const int W = blockDim.x >> 6;
     const int group = blockIdx.x % p.ngroups, worker = blockIdx.x / p.ngroups;
-    const int d = (group * W + w) * 64 + lane;          // this lane's row
-    const int dc = d < p.D ? d : p.D - 1;
-    const bool tile_live = (group * W + w) * 64 < p.D;  // a wave whose tile lies past the dataset has nothing to do
-    float *mine = wide_lds + (size_t)w * p.var_len * 64;
-    for (int v = 0; v < p.var_len; ++v) mine[v * 64 + lane] = p.X[(size_t)dc * p.var_len + v];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (!tile_live) return;
-    const LdsVars vars{mine + lane};
-    const int label = MODE == 1 ? p.labels[dc] : 0;
+    const int row0 = group * R;
+    for (int e = threadIdx.x; e < R * p.var_len; e += blockDim.x) {
+        const int dl = e / p.var_len, v = e - dl * p.var_len;
+        const int d = row0 + dl < p.D ? row0 + dl : p.D - 1;
+        wide_lds[v * R + dl] = p.X[(size_t)d * p.var_len + v];
+    }
+    __syncthreads();
+    const LdsVars vars{wide_lds + lane * K, R};
+    float *out_s = wide_lds + (size_t)p.var_len * R;  // MODE 0, multi-output: [wave][row][output] transposition blocks
+    const int d0 = row0 + lane * K;  // this lane's first row
+    int label[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) label[k] = MODE == 1 ? p.labels[d0 + k < p.D ? d0 + k : p.D - 1] : 0;
 
-    for (int t = worker; t < p.pop; t += p.workers) {
+    for (int t = worker * kWideWaves + w; t < p.pop; t += p.workers * kWideWaves) {
         const size_t row = (size_t)t * p.gp_len;
         const float *tv = p.value + row;
         const int16_t *tt = p.type + row;
         int len = uni((int)p.size[row]);
         len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
-        const int cls = uni(classify_tree(tt, tv, len, MO, p.var_len, p.out_len, kWideDepth));
-        float *res = MODE == 0 ? p.results + ((size_t)t * p.D + d) * p.out_len : nullptr;
+        const int cls = uni(classify_tree(tt, tv, len, MO, p.var_len, p.out_len, DEPTH));
         if (cls != TREE_OK) {
             if (MODE == 0) {
                 if (cls == TREE_DEEP) {  // redone by sr_general_kernel (every group writes the same mark)
                     if (lane == 0) { p.results[(size_t)t * p.D * p.out_len] = bits2f(kSentinelDeep); if (p.marks) p.marks[1] = 1u; }
-                } else if (d < p.D) {
-                    for (int o = 0; o < p.out_len; ++o) res[o] = __builtin_nanf("");
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        if (d0 + k < p.D)
+                            for (int o = 0; o < p.out_len; ++o) p.results[((size_t)t * p.D + d0 + k) * p.out_len + o] = __builtin_nanf("");
                 }
                 continue;
             }
-            if (cls != TREE_DEEP) {
-                // malformed tree: all outputs NaN -> arg-max 0
-                const unsigned long long hit = __ballot(d < p.D && label == 0);
-                if (lane == 0 && hit) atomicAdd(p.counts + t, (unsigned)__popcll(hit));
+            if (cls == TREE_DEEP) {  // recounted by wide_deep_count_kernel
+                if (lane == 0) { atomicOr(p.counts + t, kDeepCountBit); if (p.marks) p.marks[1] = 1u; }
                 continue;
             }
+            // malformed tree: all outputs NaN -> arg-max 0
+            unsigned hits = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) hits += (unsigned)__popcll(__ballot(d0 + k < p.D && label[k] == 0));
+            if (lane == 0 && hits) atomicAdd(p.counts + t, hits);
+            continue;
         }
-        v16f outs[1];
-        float top;
-        if (MODE == 0 || cls == TREE_OK) {
+        v16f outs[K];
+        float top[K];
+        {
             if (MO) {
 #pragma unroll
-                for (int o = 0; o < kMaxOutRegs; ++o) outs[0][o] = 0.0f;
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int o = 0; o < kMaxOutRegs; ++o) outs[k][o] = 0.0f;
             }
-            RegStack<1, kWideDepth> st;
+            RegStack<K, DEPTH> st;
             st.h = 0;
-            st.tos[0] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) st.tos[k] = 0.0f;
             for (int base = 0; base < len; base += kWave) {
                 const int r = base + lane;
                 uint32_t opv = 0, payv = 0;
@@ -98,76 +146,123 @@ __global__ __launch_bounds__(512) void sr_wide_kernel(WideParams p) {
                     opv = dn.op; payv = dn.pay;
                 }
                 const int n = len - base < kWave ? len - base : kWave;
-                run_chunk<MO, false, 1, kWideDepth>(opv, payv, n, st, vars, outs);
+                run_chunk<MO, false, K, DEPTH>(opv, payv, n, st, vars, outs);
             }
-            top = st.tos[0];
-        } else {
-            // MODE 1, deep tree: scratch-stack interpreter on this lane's row (rare)
-            float stk[kMaxStack + 2];
-            float o16[MO ? kMaxOutRegs : 1];
-            top = run_general<MO>(tt, tv, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, o16, stk);
-            if (MO) {
 #pragma unroll
-                for (int o = 0; o < kMaxOutRegs; ++o) outs[0][o] = o < p.out_len ? o16[o] : 0.0f;
-            }
+            for (int k = 0; k < K; ++k) top[k] = st.tos[k];
         }
-        if (MODE == 0) {
-            if (d < p.D) {
-                if (!MO) res[0] = top;
-                else {
+        if (MODE == 0 && !MO) {
 #pragma unroll
-                    for (int o = 0; o < kMaxOutRegs; ++o)
-                        if (o < p.out_len) res[o] = outs[0][o];
+            for (int k = 0; k < K; ++k)
+                if (d0 + k < p.D) p.results[(size_t)t * p.D + d0 + k] = top[k];
+        } else if (MODE == 0) {
+            // The wave's rows x outputs are ONE contiguous block of the result tensor, but a lane holds out_len values
+            // of each of its K rows: transpose through LDS and store 16 bytes per lane instead of out_len x K scalars at
+            // a stride of out_len floats.
+            float *mine = out_s + (size_t)w * R * p.out_len;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int o = 0; o < kMaxOutRegs; ++o)
+                    if (o < p.out_len) mine[(lane * K + k) * p.out_len + o] = outs[k][o];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int rows_here = p.D - row0 < R ? p.D - row0 : R;
+            const int nvalid = rows_here * p.out_len;
+            float *gbase = p.results + ((size_t)t * p.D + row0) * p.out_len;
+            for (int e = lane * 4; e < nvalid; e += 256) {
+                if (e + 4 <= nvalid) {
+                    Unaligned4 q;
+                    q.x = mine[e]; q.y = mine[e + 1]; q.z = mine[e + 2]; q.w = mine[e + 3];
+                    *reinterpret_cast<Unaligned4 *>(gbase + e) = q;
+                } else {
+                    for (int i = e; i < nvalid; ++i) gbase[i] = mine[i];
                 }
             }
+            __builtin_amdgcn_wave_barrier();  // the block is rewritten for the wave's next tree
         } else {
             // arg-max as torch.argmax(clip(softmax(x))) sees it
-            int best = 0;
-            float m = outs[0][0];
-            bool poisoned = m != m;
+            unsigned hits = 0;
 #pragma unroll
-            for (int o = 1; o < kMaxOutRegs; ++o) {
-                if (o < p.out_len) {
-                    const float x = outs[0][o];
-                    poisoned |= x != x;
-                    if (x > m) { m = x; best = o; }
+            for (int k = 0; k < K; ++k) {
+                int best = 0;
+                float m = outs[k][0];
+                bool poisoned = m != m;
+#pragma unroll
+                for (int o = 1; o < kMaxOutRegs; ++o) {
+                    if (o < p.out_len) {
+                        const float x = outs[k][o];
+                        poisoned |= x != x;
+                        if (x > m) { m = x; best = o; }
+                    }
                 }
+                if (poisoned || __builtin_isinf(m)) best = 0;
+                hits += (unsigned)__popcll(__ballot(d0 + k < p.D && best == label[k]));
             }
-            if (poisoned || __builtin_isinf(m)) best = 0;
-            const unsigned long long hit = __ballot(d < p.D && best == label);
-            if (lane == 0 && hit) atomicAdd(p.counts + t, (unsigned)__popcll(hit));
+            if (lane == 0 && hits) atomicAdd(p.counts + t, hits);
         }
     }
 }
 
-template <bool MO, int MODE>
-static hipError_t launch_wide(WideParams p, hipStream_t stream) {
+template <bool MO, int MODE, int K, int DEPTH>
+static hipError_t launch_wide_k(WideParams p, hipStream_t stream) {
     const DeviceInfo &dev = device_info();
-    // waves per workgroup: as many tiles as the LDS of a CU holds (<= 8), never more than the dataset has
-    const int tiles = (p.D + 63) / 64;
-    const size_t per_wave = (size_t)p.var_len * 64 * 4;
-    int W = (int)((dev.lds_per_cu - 2048) / per_wave);
-    W = W > 8 ? 8 : W;
-    W = W > tiles ? tiles : W;
-    if (W < 1) return hipErrorInvalidValue;
-    p.ngroups = (tiles + W - 1) / W;
-    int workers = dev.num_cus / p.ngroups;
+    constexpr int R = K * 64;
+    const size_t lds = ((size_t)p.var_len * R + (MO && MODE == 0 ? (size_t)kWideWaves * R * p.out_len : 0)) * 4;
+    p.ngroups = (p.D + R - 1) / R;
+    int per_cu = (int)((dev.lds_per_cu - 2048) / lds);
+    per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu);  // 2 x 8 waves = four per SIMD
+    int workers = dev.num_cus * per_cu / p.ngroups;
     workers = workers < 1 ? 1 : workers;
-    // small inputs leave LDS for more than one workgroup per CU
-    const int per_cu = (int)((dev.lds_per_cu - 2048) / (per_wave * W));
-    workers *= per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
-    if (workers > p.pop) workers = p.pop;
+    const int max_workers = (p.pop + kWideWaves - 1) / kWideWaves;
+    if (workers > max_workers) workers = max_workers;
     p.workers = workers;
-    const size_t lds = per_wave * W;
-    auto kern = sr_wide_kernel<MO, MODE>;
+    auto kern = sr_wide_kernel<MO, MODE, K, DEPTH>;
     static bool attr_done = false;
     if (!attr_done || lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { (void)hipGetLastError(); if (lds > 64 * 1024) return e; }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.ngroups * p.workers)), dim3(W * 64), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.ngroups * p.workers)), dim3(kWideWaves * 64), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || MODE != 1) return e;
+    long blocks = (long)dev.num_cus * 4;
+    if (blocks > p.pop) blocks = p.pop;
+    hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
+}
+
+// rows per lane: as many as the variables leave LDS for (two workgroups per CU when possible); EVOGP_WIDE_K overrides
+static int wide_rows_per_lane(const WideParams &p, int kmax) {
+    const DeviceInfo &dev = device_info();
+    int k = kmax;
+    auto bytes = [&](int kk) { return ((size_t)p.var_len + (p.results && p.out_len > 1 ? (size_t)kWideWaves * p.out_len : 0)) * kk * 64 * 4; };
+    while (k > 1 && bytes(k) * 2 > dev.lds_per_cu - 2048) k >>= 1;
+    if (p.D <= 64 * (k >> 1) && k > 1) k >>= 1;  // a short dataset does not fill the rows
+    if (const char *e = getenv("EVOGP_WIDE_K")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) k = v < kmax ? v : kmax; }
+    return k;
+}
+
+template <bool MO, int MODE>
+static hipError_t launch_wide(WideParams p, hipStream_t stream) {
+    if (((size_t)p.var_len + (MO && MODE == 0 ? (size_t)kWideWaves * p.out_len : 0)) * 64 * 4 > device_info().lds_per_cu - 2048)
+        return hipErrorInvalidValue;
+    if (MO) {
+        switch (wide_rows_per_lane(p, 2)) {
+            case 2: return launch_wide_k<true, MODE, 2, 16>(p, stream);
+            default: return launch_wide_k<true, MODE, 1, 32>(p, stream);
+        }
+    }
+    if (MODE == 0) {
+        switch (wide_rows_per_lane(p, 4)) {
+            case 4: return launch_wide_k<false, 0, 4, 16>(p, stream);
+            case 2: return launch_wide_k<false, 0, 2, 32>(p, stream);
+            default: return launch_wide_k<false, 0, 1, 32>(p, stream);
+        }
+    }
+    return hipErrorInvalidValue;  // the arg-max epilogue needs several outputs
 }
 
 // called by run_population<STORE> (sr_fitness.hip) for inputs the register kernels do not take
@@ -194,6 +289,8 @@ extern "C" int evogp_hip_batch_argmax_count(unsigned pop_size, unsigned data_poi
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)pop_size * sizeof(unsigned), stream);
     if (e != hipSuccess) return (int)e;
     WideParams p{};
+    p.marks = acquire_counter(stream, &e);  // [1] != 0: some tree was too deep for the register stack
+    if (!p.marks) return (int)e;
     p.value = value; p.type = type; p.size = size; p.X = variables; p.labels = labels; p.counts = counts;
     p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len; p.out_len = (int)out_len;
     return (int)launch_wide<true, 1>(p, stream);

@@ -108,5 +108,13 @@ def acc():
 us = timed(acc, 5)
 row("batch_argmax_count (C4 shape, pop 20k)", us, 6.0 * cs_[:, 0].to(torch.int64).sum().item() + 4.0 * pc + 4.0 * Dc * 65, f"fused classification epilogue: {pc * Dc / us / 1e3:.1f} G tree-evals/s, only the per-tree counts leave the chip")
 
+# single-output batch evaluation over a long dataset (Transformation / torch-mode SR): pop 50k, L 64, in 10, D 4096
+ps, Ds = 50_000, 4096
+Xs = torch.rand(Ds, 10, device=g.DEV) * 10 - 5; outs_ = torch.empty((ps, Ds, 1), dtype=torch.float32, device=g.DEV)
+def bso():
+    assert L_.evogp_hip_batch_evaluate(ps, Ds, L, 10, 1, v.data_ptr(), t.data_ptr(), s.data_ptr(), Xs.data_ptr(), outs_.data_ptr(), S()) == 0
+us = timed(bso, 5)
+row("batch_evaluate (single output, long dataset)", us, 4.0 * ps * Ds + 6.0 * s[:ps, 0].to(torch.int64).sum().item(), f"pop {ps}, L {L}, in 10, out 1, D {Ds}: {ps * Ds / us / 1e3:.1f} G tree-evals/s")
+
 print("| operator | workload | us per call | algorithmic MB | TB/s | of 8 TB/s |\n|---|---|---|---|---|---|")
 print("\n".join(rows))
