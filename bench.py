@@ -168,10 +168,11 @@ def main():
                                max_layer_cnt=3, const_samples=[-1, 0, 1])
     algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
     gen_ms = []
-    for _ in range(4):
+    neg_inf = torch.full((pop,), float("-inf"), dtype=torch.float32, device=device)
+    for _ in range(6):
         torch.cuda.synchronize(); g0 = time.perf_counter()
         f = -algo.forest.SR_fitness(Xd, yd, True, "auto")
-        f[torch.isnan(f)] = -torch.inf
+        f = torch.where(torch.isnan(f), neg_inf, f)  # no boolean-mask assignment: that one syncs with the host
         algo.step(f)
         torch.cuda.synchronize(); gen_ms.append((time.perf_counter() - g0) * 1000)
 
@@ -186,7 +187,7 @@ def main():
         for _ in range(4):
             barrier(); g0 = time.perf_counter()
             f = -sg.forest.SR_fitness(Xd, yd, True, "auto")
-            f[torch.isnan(f)] = -torch.inf
+            f = torch.where(torch.isnan(f), neg_inf, f)
             sg.step(f)
             barrier(); sharded_ms.append((time.perf_counter() - g0) * 1000)
     except Exception as exc:  # the fitness line must survive a failure of the exchange step

@@ -11,6 +11,7 @@
 // per tree) launched behind the fast one; malformed trees yield NaN rows.
 #include "interp.hpp"
 #include "launch.hpp"
+#include <cstdlib>
 
 namespace evogp {
 
@@ -35,46 +36,52 @@ struct EvalParams {
 // reads are bank-conflict free.  The operand stacks, the input rows and the multi-output accumulators live in LDS as
 // [entry][lane].  Lanes then interpret their own tree in lockstep over the execution index; dispatch diverges by node
 // class only (leaf / arithmetic / other binary / unary / ternary).
+//
+// TPW trees per wave: all 64 lanes stage, lanes 0 .. TPW-1 interpret.  The op is bound by the serial chain of its longest
+// tree, not by throughput (50 k trees are 782 full waves for 1024 SIMDs), so FEWER trees per wave is faster: the staging
+// of a chunk shrinks with TPW (64 lanes load 32 nodes of TPW trees), the longest tree of 16 is shorter than the longest
+// of 64, and the chip holds all the extra waves at once.
 constexpr int kLaneChunk = 32;
-constexpr int kLanePitch = 65;
 constexpr int kLaneDepth = 24;
+constexpr uint32_t kCtlNop = 0xFFu | (2u << 12);  // handler "none", no operands, stack delta 0
 
-template <bool MO>
+template <bool MO, int TPW>
 __global__ __launch_bounds__(64) void eval_lane_kernel(EvalParams p) {
+    constexpr int kLanePitch = TPW + 1;
     extern __shared__ uint32_t lane_lds[];
     uint32_t *op_s = lane_lds;                                 // [kLaneChunk][kLanePitch]
     uint32_t *pay_s = op_s + kLaneChunk * kLanePitch;          // [kLaneChunk][kLanePitch]
-    float *stk = (float *)(pay_s + kLaneChunk * kLanePitch);   // [kLaneDepth][64]
-    float *var_s = stk + kLaneDepth * 64;                      // [var_len][64]
-    float *out_s = var_s + p.var_len * 64;                     // [out_len][64]  (multi-output only)
+    float *stk = (float *)(pay_s + kLaneChunk * kLanePitch);   // [kLaneDepth + 1][TPW]  (last row: sink for non-pushes)
+    float *var_s = stk + (kLaneDepth + 1) * TPW;               // [var_len][TPW]
+    float *out_s = var_s + p.var_len * TPW;                    // [out_len + 1][TPW]  (multi-output only; last row: sink)
     const int lane = threadIdx.x;
-    const int t0 = blockIdx.x * 64;
+    const int t0 = blockIdx.x * TPW;
     const int t = t0 + lane;
-    const bool active = t < p.pop;
+    const bool active = lane < TPW && t < p.pop;
     int len = 0;
     if (active) {
         len = (int)p.size[(size_t)t * p.gp_len];
         len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
     }
     // input rows: the 64 rows of this wave are contiguous in memory; copy them coalesced, store transposed
-    const int nrows = p.pop - t0 < 64 ? p.pop - t0 : 64;
+    const int nrows = p.pop - t0 < TPW ? p.pop - t0 : TPW;
     for (int e = lane; e < nrows * p.var_len; e += 64) {
         const int r = e / p.var_len, v = e - r * p.var_len;
-        var_s[v * 64 + r] = p.vars[(size_t)t0 * p.var_len + e];
+        var_s[v * TPW + r] = p.vars[(size_t)t0 * p.var_len + e];
     }
-    if (MO) for (int o = 0; o < p.out_len; ++o) out_s[o * 64 + lane] = 0.0f;
+    if (MO && lane < TPW) for (int o = 0; o <= p.out_len; ++o) out_s[o * TPW + lane] = 0.0f;
     const int maxlen = wave_max(len);
     int h = 0;
     float tos = 0.0f;
-    bool bad = len <= 0, deep = false;
+    int hmin = 0, hmax = 0;  // lowest "height - operands needed" and greatest height seen: validity is judged at the end
     for (int c0 = 0; c0 < maxlen; c0 += kLaneChunk) {
         // ---- stage the next 32 instructions of every tree: all loads first (64 in flight), then decode + store ----
         const int jj = lane & 31;
         const int k = c0 + jj;
-        int ty_r[32];
-        float vl_r[32];
+        int ty_r[TPW / 2];
+        float vl_r[TPW / 2];
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
+        for (int it = 0; it < TPW / 2; ++it) {
             const int tl = 2 * it + (lane >> 5);
             const int len_t = __shfl(len, tl);
             ty_r[it] = -1; vl_r[it] = 0.0f;
@@ -84,12 +91,15 @@ __global__ __launch_bounds__(64) void eval_lane_kernel(EvalParams p) {
             }
         }
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
+        for (int it = 0; it < TPW / 2; ++it) {
             const int tl = 2 * it + (lane >> 5);
-            uint32_t op = 0xFFFFFFFFu, pay = 0;
+            uint32_t op = kCtlNop, pay = 0;  // past the end of the tree: nothing happens
             if (ty_r[it] != -1) {
                 const Decoded dn = decode_node(ty_r[it], vl_r[it], MO, p.var_len, p.out_len);
-                op = dn.op; pay = dn.pay;
+                // control word: handler id | operands needed << 8 | (stack delta + 2) << 12
+                const uint32_t need = dn.delta > 0 ? 0u : (uint32_t)(1 - dn.delta);
+                op = dn.op | (need << 8) | ((uint32_t)(dn.delta + 2) << 12);
+                pay = dn.pay;
             }
             op_s[jj * kLanePitch + tl] = op;
             pay_s[jj * kLanePitch + tl] = pay;
@@ -100,50 +110,78 @@ __global__ __launch_bounds__(64) void eval_lane_kernel(EvalParams p) {
         // ---- interpret: elements 0 .. h-2 of the operand stack live in LDS, the top element in a register; the next
         // instruction is fetched before the current one executes ----
         const int n = maxlen - c0 < kLaneChunk ? maxlen - c0 : kLaneChunk;
-        uint32_t nop = op_s[lane], npay = pay_s[lane];
+        const int ln = lane < TPW ? lane : 0;  // lanes beyond the wave's trees idle (all-NOP) but must touch valid LDS
+        const bool mine = lane < TPW;  // the other lanes run NOPs (their LDS traffic lands in the sink rows)
+        uint32_t nctl = mine ? op_s[ln] : kCtlNop, npay = pay_s[ln];
+        // ONE straight-line step for every node class.  The lanes of a wave sit on different classes; a branch per class
+        // costs an LDS round trip and a page of mask bookkeeping each, and a lone wave issues one instruction per ~4
+        // clocks, so the step's INSTRUCTION COUNT is the op's running time (first version: ~300 instructions, 1.4 k
+        // clocks per step).  Here every lane forms one operand address (its variable, or the element under the top of
+        // its stack), one push address and one accumulator address — classes that do not push / accumulate aim at a
+        // sink row — and the classes are resolved with selects.  Validity (operand underflow, stack overflow) is
+        // tracked as a running minimum / maximum and judged once at the end; addresses are clamped meanwhile.
+        // Only divisions, the non-arithmetic functions and IF take a wave-uniform branch, when some lane needs them.
+        float *const lds_f = stk;  // stk | var_s | out_s are contiguous
+        constexpr int var_base = (kLaneDepth + 1) * TPW;
+        const int out_base = var_base + p.var_len * TPW;
         for (int j = 0; j < n; ++j) {
-            const uint32_t op = nop, pay = npay;
-            if (j + 1 < n) { nop = op_s[(j + 1) * kLanePitch + lane]; npay = pay_s[(j + 1) * kLanePitch + lane]; }
-            if (c0 + j >= len || bad || deep) continue;
-            if (op < H_ADD) {  // leaf: push
-                if (h > kLaneDepth) { deep = true; continue; }
-                if (h >= 1) stk[(h - 1) * 64 + lane] = tos;
-                tos = op == H_CONST ? bits2f(pay) : var_s[pay * 64 + lane];
-                ++h;
-            } else if (op < H_UN) {  // binary: a = top (left operand), b = next (right operand)
-                if (h < 2) { bad = true; continue; }
-                const float a = tos, b = stk[(h - 2) * 64 + lane];
-                float r;
-                if (op <= H_DIV) r = op == H_ADD ? a + b : op == H_SUB ? a - b : op == H_MUL ? a * b : (b == 0.0f ? __builtin_nanf("") : a / b);
-                else r = op_binary_other<false>(op, a, b);
-                --h;
-                if (MO) {
-                    if (pay != kNoOut) out_s[pay * 64 + lane] += r;
-                    r = b;  // a function node hands its LAST popped operand to its parent (forward.cu:237-243)
-                }
-                tos = r;
-            } else if (op < H_IF) {  // unary
-                if (h < 1) { bad = true; continue; }
-                const float r = op_unary<false>(op, tos);
-                if (MO) { if (pay != kNoOut) out_s[pay * 64 + lane] += r; }
-                else tos = r;
-            } else {  // ternary IF: cond = top, then = next, else = third
-                if (h < 3) { bad = true; continue; }
-                const float b = stk[(h - 2) * 64 + lane], c = stk[(h - 3) * 64 + lane];
-                float r = tos > 0.0f ? b : c;
-                h -= 2;
-                if (MO) { if (pay != kNoOut) out_s[pay * 64 + lane] += r; r = c; }
-                tos = r;
+            const uint32_t ctl = nctl, pay = npay;
+            if (j + 1 < n) { nctl = mine ? op_s[(j + 1) * kLanePitch + ln] : kCtlNop; npay = pay_s[(j + 1) * kLanePitch + ln]; }
+            const uint32_t op = ctl & 0xFFu;
+            const int need = (int)((ctl >> 8) & 3u), delta = (int)((ctl >> 12) & 7u) - 2;
+            hmin = min(hmin, h - need);
+            const bool isleaf = op < H_ADD, isvar = op == H_VAR;
+            int hw = h - 1; hw = hw < 0 ? 0 : (hw > kLaneDepth - 1 ? kLaneDepth - 1 : hw);
+            int hr = h - 2; hr = hr < 0 ? 0 : (hr > kLaneDepth - 1 ? kLaneDepth - 1 : hr);
+            lds_f[(isleaf ? hw : kLaneDepth) * TPW + ln] = tos;  // a leaf pushes the old top
+            const float lda = lds_f[isvar ? var_base + (int)pay * TPW + ln : hr * TPW + ln];
+            const bool hasout = MO && need != 0 && pay != kNoOut;
+            const int io = out_base + (hasout ? (int)pay : p.out_len) * TPW + ln;
+            float ldo = 0.0f, ldc = 0.0f;
+            if (MO) ldo = lds_f[io];
+            const bool anyter = __any(need == 3);
+            if (anyter) { int hc = h - 3; hc = hc < 0 ? 0 : (hc > kLaneDepth - 1 ? kLaneDepth - 1 : hc); ldc = lds_f[hc * TPW + ln]; }
+            const float x = tos, y = lda;
+            float fr = x + y;
+            fr = op == H_SUB ? x - y : fr;
+            fr = op == H_MUL ? x * y : fr;
+            if (__any(op == H_DIV)) { const float q = y == 0.0f ? __builtin_nanf("") : x / y; fr = op == H_DIV ? q : fr; }
+            if (__any(need == 2 && op > H_DIV)) { if (need == 2 && op > H_DIV) fr = op_binary_other<false>(op, x, y); }
+            if (__any(need == 1)) { if (need == 1) fr = op_unary<false>(op, x); }
+            if (anyter) fr = need == 3 ? (x > 0.0f ? lda : ldc) : fr;
+            const float leafval = isvar ? lda : bits2f(pay);
+            float r;
+            if (MO) {
+                // a function node adds its value to its output and hands its LAST popped operand to its parent
+                // (forward.cu:237-243): b for binary, the operand itself for unary, c for IF
+                lds_f[io] = ldo + fr;
+                r = need == 2 ? lda : tos;
+                r = need == 3 ? ldc : r;
+            } else {
+                r = need == 0 ? tos : fr;
             }
+            tos = isleaf ? leafval : r;
+            h += delta;
+            hmax = max(hmax, h);
         }
         __builtin_amdgcn_wave_barrier();  // the next chunk overwrites the staging area
     }
-    if (!active) return;
-    float *res = p.results + (size_t)t * p.out_len;
-    if (deep) { res[0] = bits2f(kSentinelDeepEval); return; }        // redone by eval_general_kernel
-    if (bad || h != 1) { for (int o = 0; o < p.out_len; ++o) res[o] = __builtin_nanf(""); return; }  // forward.cu:298-301 asserts
-    if (!MO) res[0] = tos;
-    else for (int o = 0; o < p.out_len; ++o) res[o] = out_s[o * 64 + lane];
+    if (active) {
+        // one store path for all outcomes: a tree too deep for the LDS stack leaves the sentinel (redone by
+        // eval_general_kernel), a malformed one NaN (forward.cu:298-301 asserts)
+        float *res = p.results + (size_t)t * p.out_len;
+        const bool deep = hmax > kLaneDepth + 1;
+        const bool bad = len <= 0 || hmin < 0 || h != 1;
+        const float nan = __builtin_nanf("");
+        if (!MO) {
+            res[0] = deep ? bits2f(kSentinelDeepEval) : (bad ? nan : tos);
+        } else {
+            for (int o = 0; o < p.out_len; ++o) {
+                const float val = out_s[o * TPW + lane];
+                res[o] = (deep && o == 0) ? bits2f(kSentinelDeepEval) : (bad ? nan : val);
+            }
+        }
+    }
 }
 
 template <bool MO>
@@ -181,12 +219,22 @@ static hipError_t launch_eval_general(const EvalParams &p, int only_marked, hipS
     return hipGetLastError();
 }
 
+template <bool MO, int TPW>
+static hipError_t launch_eval_lane_tpw(const EvalParams &p, hipStream_t stream) {
+    const size_t lds = (size_t)(2 * kLaneChunk * (TPW + 1) + (kLaneDepth + 1 + p.var_len + (MO ? p.out_len + 1 : 0)) * TPW) * 4;
+    const unsigned blocks = (unsigned)((p.pop + TPW - 1) / TPW);
+    hipLaunchKernelGGL((eval_lane_kernel<MO, TPW>), dim3(blocks), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+
 template <bool MO>
 static hipError_t launch_eval_lane(const EvalParams &p, hipStream_t stream) {
-    const size_t lds = (size_t)(2 * kLaneChunk * kLanePitch + kLaneDepth * 64 + p.var_len * 64 + (MO ? p.out_len * 64 : 0)) * 4;
-    const unsigned blocks = (unsigned)((p.pop + 63) / 64);
-    hipLaunchKernelGGL((eval_lane_kernel<MO>), dim3(blocks), dim3(64), lds, stream, p);
-    hipError_t e = hipGetLastError();
+    // trees per wave: 16 until the population exceeds what the chip holds at once (~8 k waves), then 32 / 64
+    static const int forced = [] { const char *e = getenv("EVOGP_EVAL_TPW"); return e ? atoi(e) : 0; }();
+    int tpw = p.pop <= 16 * 8192 ? 16 : (p.pop <= 32 * 8192 ? 32 : 64);
+    if (forced == 16 || forced == 32 || forced == 64) tpw = forced;
+    hipError_t e = tpw == 16 ? launch_eval_lane_tpw<MO, 16>(p, stream)
+                 : tpw == 32 ? launch_eval_lane_tpw<MO, 32>(p, stream) : launch_eval_lane_tpw<MO, 64>(p, stream);
     if (e != hipSuccess) return e;
     return launch_eval_general<MO>(p, 1, stream);
 }

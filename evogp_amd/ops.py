@@ -233,7 +233,9 @@ def tree_batch_argmax_count(pop_size, data_points, gp_len, var_len, out_len, val
 @torch.library.impl("evogp_hip::breed_default_rows", "CUDA")
 def breed_default_rows(pop_size, gp_len, n_elite, n_surv, value, ntype, size, order, rnd, mutate_below, donor_value,
                        donor_type, donor_size, row_begin, row_count):
-    """Rows [row_begin, row_begin + row_count) of the next generation; donor arrays have row_count rows aligned with them."""
+    """Rows [row_begin, row_begin + row_count) of the next generation.  The donor arrays are aligned with the OFFSPRING rows
+    of the range: they may cover the whole range (row_count rows; the rows of elites are never read) or only its
+    offspring (row_count minus the elite rows at the head of the range) — then no padding copy is needed."""
     _check_sizes_common(pop_size, gp_len)
     _check(0 <= n_elite <= pop_size and 0 < n_surv <= pop_size, "n_elite / n_surv out of range")
     _check(0 <= row_begin and 0 < row_count and row_begin + row_count <= pop_size, "row range out of the population")
@@ -241,9 +243,13 @@ def breed_default_rows(pop_size, gp_len, n_elite, n_surv, value, ntype, size, or
     _check(order.is_cuda and order.is_contiguous() and order.dtype == torch.int32 and order.dim() == 1
            and order.shape[0] >= max(n_elite, n_surv), "order must be a contiguous int32 CUDA vector of >= max(n_elite, n_surv) entries")
     _check_tensor(rnd, (6, pop_size - n_elite), "rnd", torch.int32)
+    head = max(0, min(row_begin + row_count, n_elite) - row_begin)  # elite rows at the head of the range
+    drows = donor_value.shape[0] if donor_value.dim() == 2 else -1
+    _check(drows in (row_count, row_count - head), f"donor arrays must have {row_count} or {row_count - head} rows, but got {drows}")
     for t, nm, dt in ((donor_value, "donor_value", torch.float32), (donor_type, "donor_type", torch.int16),
                       (donor_size, "donor_size", torch.int16)):
-        _check_tensor(t, (row_count, gp_len), nm, dt)
+        _check_tensor(t, (drows, gp_len), nm, dt)
+    skip = head if drows == row_count - head else 0  # the engine indexes donors by (row - row_begin)
     dev = value.device
     shp = (row_count, gp_len)
     with torch.cuda.device(dev):
@@ -252,8 +258,9 @@ def breed_default_rows(pop_size, gp_len, n_elite, n_surv, value, ntype, size, or
         osz = torch.empty(shp, dtype=torch.int16, device=dev)
         rc = _lib_h.evogp_hip_breed_default_rows(
             pop_size, gp_len, n_elite, n_surv, value.data_ptr(), ntype.data_ptr(), size.data_ptr(), order.data_ptr(),
-            rnd.data_ptr(), mutate_below, donor_value.data_ptr(), donor_type.data_ptr(), donor_size.data_ptr(),
-            ov.data_ptr(), ot.data_ptr(), osz.data_ptr(), None, row_begin, row_count, _stream(dev))
+            rnd.data_ptr(), mutate_below, donor_value.data_ptr() - skip * gp_len * 4, donor_type.data_ptr() - skip * gp_len * 2,
+            donor_size.data_ptr() - skip * gp_len * 2, ov.data_ptr(), ot.data_ptr(), osz.data_ptr(), None, row_begin, row_count,
+            _stream(dev))
     _lib.check(rc, "breed_default_rows")
     return ov, ot, osz
 

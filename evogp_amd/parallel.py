@@ -76,6 +76,8 @@ class ShardedGeneticProgramming:
 
     # -- the one exchange step ---------------------------------------------------------------------
     def gather(self, local_fitness: torch.Tensor):
+        if self.world == 1:
+            return self.forest, local_fitness  # nothing to exchange
         buf = _pack(self.forest, local_fitness)
         if self.world > 1:
             out = torch.empty((self.world * buf.shape[0], buf.shape[1]), dtype=torch.uint8, device=buf.device)
@@ -112,14 +114,12 @@ class ShardedGeneticProgramming:
         d = self.descriptor
         rows = hi - lo
         o_lo, o_hi = max(lo, n_elite) - n_elite, max(hi, n_elite) - n_elite   # my offspring indices
-        head = rows - (o_hi - o_lo)                                            # elite rows at the head of my slice
         if o_hi > o_lo:
             donors = torch.ops.evogp_hip.tree_generate_masked(
                 o_hi - o_lo, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
                 d.depth2leaf_probs, d.roulette_funcs, d.const_samples, o_lo, rnd[4, o_lo:o_hi].contiguous(), below)
-            if head:
-                donors = tuple(torch.cat([torch.empty((head, L), dtype=t.dtype, device=dev), t]) for t in donors)
-        else:
+            # donors cover my offspring rows only; breed_default_rows skips the elite rows at the head of the range
+        else:  # a slice of elites only: donors are never read
             donors = (torch.empty((rows, L), dtype=torch.float32, device=dev), torch.empty((rows, L), dtype=torch.int16, device=dev),
                       torch.empty((rows, L), dtype=torch.int16, device=dev))
         value, ntype, size = full._tensors()

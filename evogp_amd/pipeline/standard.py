@@ -34,14 +34,19 @@ class StandardPipeline(BasePipeline):
         self.fitness = None
 
     def step(self):
-        fitness = self.problem.evaluate(self.algorithm.forest)
-        fitness[torch.isnan(fitness)] = -torch.inf  # invalid trees never win (standard.py:43)
+        """One generation.  Same result as the reference's loop (standard.py:41-52), but nothing waits on the device
+        before the whole generation is enqueued: the NaN scrub is a select instead of a boolean-mask assignment (which
+        hides a host sync), and the fitness vector is brought to the host AFTER ``algorithm.step`` has queued the
+        selection / breeding kernels, so the copy overlaps them instead of idling the GPU."""
+        forest = self.algorithm.forest  # step() builds a new forest; the best tree comes from this one
+        fitness = self.problem.evaluate(forest)
+        fitness = torch.where(torch.isnan(fitness), torch.full_like(fitness, float("-inf")), fitness)  # standard.py:43
+        self.algorithm.step(fitness)
         host = fitness.cpu()
         best = int(torch.argmax(host))
         if host[best] > self.best_fitness:
             self.best_fitness = host[best]
-            self.best_tree = self.algorithm.forest[best]
-        self.algorithm.step(fitness)
+            self.best_tree = forest[best]
         return host
 
     def run(self):
