@@ -37,6 +37,25 @@ KERNEL(k_cndmask, I4("v_cndmask_b32", "v27, v28, vcc"))
 KERNEL(k_sub_vop2, I4("v_sub_f32", "v28, v30"))
 KERNEL(k_add_u32, I4("v_add_u32", "s20, v28"))
 KERNEL(k_add_sgpr, I4("v_add_f32", "s20, v28"))
+// VGPR indexing (the interpreter's operand stack): the same adds with s_set_gpr_idx_on active
+#define KERNEL_IDX(name, mode, body4)                                                         \
+    __global__ __launch_bounds__(256) void name(unsigned long long *out, float *sink) {       \
+        float f = sink[threadIdx.x & 63];                                                     \
+        unsigned long long t0, t1;                                                            \
+        asm volatile("v_mov_b32 v28, 1.5\n\tv_mov_b32 v29, 1.5\n\tv_mov_b32 v30, 3.0\n\tv_mov_b32 v31, 3.0\n\tv_mov_b32 v32, 1.0\n\tv_mov_b32 v33, 1.0\n\tv_mov_b32 v34, 1.0\n\tv_mov_b32 v35, 1.0\n\t" ::: CLOB); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));                      \
+        asm volatile("s_mov_b32 s20, 0\n\ts_set_gpr_idx_on s20, " mode ::: CLOB, "m0");      \
+        for (int i = 0; i < ITER; ++i) { asm volatile(REP16(body4) ::: CLOB); }               \
+        asm volatile("s_set_gpr_idx_off" ::: CLOB, "m0");                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));                      \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                            \
+        sink[threadIdx.x & 63] = f;                                                           \
+    }
+KERNEL_IDX(k_add_idx_src0, "0x1", I4("v_add_f32", "v28, v30"))
+KERNEL_IDX(k_add_idx_dst, "0x8", I4("v_add_f32", "v28, v30"))
+KERNEL_IDX(k_add_idx_s0s1d, "0xb", I4("v_add_f32", "v28, v30"))
+KERNEL_IDX(k_mov_idx_dst, "0x8", I4("v_mov_b32", "v28"))
+KERNEL_IDX(k_fixup_idx_dst, "0x8", I4("v_div_fixup_f32", "v28, v30, v24"))
 // the full division row as generated (dependent chain), 4 rows
 #define DIVROW(x, y, q) \
     "v_cmp_neq_f32 vcc, 0, " y "\n\tv_cndmask_b32 " x ", v27, " x ", vcc\n\tv_div_scale_f32 v36, s[20:21], " y ", " y ", " x "\n\tv_rcp_f32 v37, v36\n\tv_div_scale_f32 v38, vcc, " x ", " y ", " x "\n\t" \
@@ -63,6 +82,7 @@ int main() {
 #define RUN(k, n) run(#k, k, n, dout, dsink)
     RUN(k_add_vop2, 4); RUN(k_mul_vop2, 4); RUN(k_sub_vop2, 4); RUN(k_mov, 4); RUN(k_add_sgpr, 4); RUN(k_add_u32, 4); RUN(k_fmac_vop2, 4); RUN(k_fma_vop3, 4); RUN(k_fma_neg_const, 4);
     RUN(k_add_vop3_abs, 4); RUN(k_div_scale, 4); RUN(k_div_scale_vcc, 4); RUN(k_div_fmas, 4); RUN(k_div_fixup, 4); RUN(k_rcp, 4); RUN(k_cmp, 4); RUN(k_cndmask, 4);
+    RUN(k_add_idx_src0, 4); RUN(k_add_idx_dst, 4); RUN(k_add_idx_s0s1d, 4); RUN(k_mov_idx_dst, 4); RUN(k_fixup_idx_dst, 4);
     RUN(k_divrow4, 48);
     return 0;
 }

@@ -56,6 +56,8 @@ def _expected(oracle, forest, order, rnd, below, n_elite, n_surv, donors):
     (2500, 128, 5, 4, ALLF, 0.5, 0.1, 0.05),
     (700, 1024, 9, 5, ARITH, 0.3, 0.02, 1.0),
     (64, 16, 3, 2, ARITH, 0.0, 0.5, 0.3),
+    (900, 50, 5, 3, ARITH, 0.4, 0.03, 0.3),    # row length no multiple of 4: the one-row-per-wave kernel
+    (1100, 400, 7, 4, ARITH, 0.3, 0.02, 0.4),  # staging rows of 16 groups would not fit: the one-row-per-wave kernel
 ])
 def test_breed_default_bit_exact(g, oracle, pop, L, mlc, dmlc, funcs, rate, elite_rate, surv_rate):
     rng = np.random.default_rng(pop + L)

@@ -106,7 +106,8 @@ def _assert_mostly_close(got, want, rtol, atol, what, allowed_bad=0.02):
 
 
 # ---- crossover / mutate: bit-exact on fuzzed inputs ----------------------------------------------
-@pytest.mark.parametrize("L,mlc,funcs", [(64, 6, ARITH), (32, 4, ARITH), (128, 5, ALLF), (1024, 9, ARITH), (200, 5, [0, 1, 14])])
+@pytest.mark.parametrize("L,mlc,funcs", [(64, 6, ARITH), (32, 4, ARITH), (128, 5, ALLF), (1024, 9, ARITH), (200, 5, [0, 1, 14]),
+                                         (50, 5, ARITH), (33, 4, ALLF)])  # row lengths that are no multiple of 4: one row per wave
 def test_crossover_mutate_bit_exact(g, oracle, rng, L, mlc, funcs):
     rou = roulette_uniform(funcs)
     pop = 3000
@@ -383,3 +384,37 @@ def test_sr_fitness_division_modes_on_special_operands(g, oracle, D):
     finally:
         assert g.L.evogp_hip_set_sr_division(2) == 0
     assert g.L.evogp_hip_set_sr_division(7) < 0
+
+
+def test_wide_kernel_deep_multi_output_trees_are_redone(g, oracle, rng):
+    """Trees whose operand stack exceeds the register stack of the tile-group kernel (16 entries for multi-output): the
+    store mode leaves a sentinel for the scratch-stack kernel, the fused accuracy flags the count word and recounts in
+    its follow-up kernel.  Left-deep chains mixed into a generated multi-output forest."""
+    import torch
+
+    pop, L, var_len, out_len, D = 400, 128, 40, 4, 700
+    v, t, s = (a.copy() for a in oracle.generate(pop, L, var_len, out_len, 0.5, 0.5, [8, 9], depth2leaf(5), roulette_uniform(ARITH), [-1, 0, 1, 0.5]))
+    for r, n_nodes in ((3, 41), (57, 127), (399, 75)):   # operand stack of (n + 1) / 2 = 21, 64, 38 entries
+        k = (n_nodes - 1) // 2
+        v[r] = 0; t[r] = 0; s[r] = 0
+        t[r, :k] = 3 | 0x80                                                     # output-flagged binary functions
+        ids = 1 + (np.arange(k) + r) % 3                                        # + - *
+        oi = np.arange(k) % out_len
+        v[r, :k] = ((oi.astype(np.uint32) << 16) | ids.astype(np.uint32)).view(np.float32)
+        s[r, :k] = n_nodes - 2 * np.arange(k)
+        leaves = np.arange(k, n_nodes)
+        t[r, leaves] = np.where(leaves % 2 == 0, 0, 1); v[r, leaves] = np.where(leaves % 2 == 0, leaves % var_len, 0.25 * (1 + r % 3))
+        s[r, leaves] = 1
+        assert oracle.validate_tree(t[r], s[r]) == 0
+    X = rng.uniform(-2, 2, (D, var_len)).astype(np.float32)
+    want = oracle.batch_evaluate(v, t, s, X, out_len)
+    got = g.batch_evaluate(v, t, s, X, out_len)
+    assert np.array_equal(fbits(got), fbits(want))
+    labels = rng.integers(0, out_len, D).astype(np.int32)
+    cnt = g.batch_argmax_count(v, t, s, X, labels, out_len)
+    outs = torch.from_numpy(want)
+    pred = torch.argmax(torch.clip(torch.softmax(outs, dim=2), 1e-15, 1 - 1e-15), dim=2)
+    ref = (pred == torch.from_numpy(labels.astype(np.int64))[None, :]).sum(1).numpy()
+    assert (cnt >= 0).all() and (cnt <= D).all()
+    assert np.abs(cnt - ref).max() <= 2, (np.abs(cnt - ref).max(), np.argmax(np.abs(cnt - ref)))
+    assert np.array_equal(cnt[[3, 57, 399]], ref[[3, 57, 399]])
