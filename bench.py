@@ -176,7 +176,7 @@ def main():
         algo.step(f)
         torch.cuda.synchronize(); gen_ms.append((time.perf_counter() - g0) * 1000)
 
-    # the sharded generation step: fitness of the local shard, ONE all-gather of the packed shards,
+    # the sharded generation step: fitness of the local shard, all-gathers of the fitness values and of the survivor rows,
     # identical selection / random words on every rank, every rank builds its own rows of the next generation
     sharded_ms, sharded_err = [], None
     try:
@@ -230,8 +230,8 @@ def main():
                               "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
             "generation_ms_sharded": {"median": float(np.median(sharded_ms[1:])) if len(sharded_ms) > 1 else None,
                                       "global_pop": pop * n, "error": sharded_err,
-                                      "what": "whole population: local fitness + one all-gather of the packed shards (RCCL) + "
-                                              "sort + breeding pass for the local rows, max over ranks via barriers"},
+                                      "what": "whole population: local fitness + all-gather of the fitness values + all-gather of the "
+                                              "survivor rows (RCCL) + sort + breeding pass for the local rows, max over ranks via barriers"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,

@@ -35,6 +35,7 @@ struct BreedParams {
     float *ov; int16_t *ot; int16_t *os;                    // next generation [pop][gp_len]
     int *decisions;                                          // optional [n_new][6]: left, right, p, q, mutated, mutate position
     int pop, gp_len, n_elite, n_surv, n_new;
+    int table_rows;  // rows of v/t/s: the whole population, or only the trees `order` can name (a sharded run's survivor table)
     unsigned mutate_below;
     int row_begin, row_count;  // rows [row_begin, row_begin + row_count) of the next generation are built; output and donor
                                // arrays hold exactly these rows (donor row k belongs to next-generation row row_begin + k)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
         if (w == 0 && n < row_end) {
             if (n < a.n_elite) {
                 li = a.order[n];
-                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
+                li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
                 ri = li;
                 S = (int)a.s[(size_t)li * a.gp_len];
                 S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
                 r5 = (unsigned)a.rnd[5 * a.n_new + i];
                 li = a.order[r0 % (unsigned)a.n_surv];
                 ri = a.order[r1 % (unsigned)a.n_surv];
-                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
-                ri = ri < 0 ? 0 : (ri >= a.pop ? a.pop - 1 : ri);
+                li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
+                ri = ri < 0 ? 0 : (ri >= a.table_rows ? a.table_rows - 1 : ri);
                 const int16_t *ls = a.s + (size_t)li * a.gp_len, *rs = a.s + (size_t)ri * a.gp_len;
                 S = (int)ls[0];
                 int RS = (int)rs[0];
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kRepBlock) void breed_group_kernel(BreedParams a) {
         if (w == 0 && n < row_end) {
             if (n < a.n_elite) {
                 li = a.order[n];
-                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
+                li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
                 ri = li;
                 S = (int)a.s[(size_t)li * a.gp_len];
                 S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(kRepBlock) void breed_group_kernel(BreedParams a) {
                 r5 = (unsigned)a.rnd[5 * a.n_new + i];
                 li = a.order[r0 % (unsigned)a.n_surv];
                 ri = a.order[r1 % (unsigned)a.n_surv];
-                li = li < 0 ? 0 : (li >= a.pop ? a.pop - 1 : li);
-                ri = ri < 0 ? 0 : (ri >= a.pop ? a.pop - 1 : ri);
+                li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
+                ri = ri < 0 ? 0 : (ri >= a.table_rows ? a.table_rows - 1 : ri);
                 const int16_t *ls = a.s + (size_t)li * a.gp_len, *rs = a.s + (size_t)ri * a.gp_len;
                 S = (int)ls[0];
                 int RS = (int)rs[0];
@@ -277,7 +278,19 @@ extern "C" int evogp_hip_breed_default_rows(int pop_size, int gp_len, int n_elit
                                             const int16_t *donor_size, float *value_res, int16_t *type_res,
                                             int16_t *size_res, int *decisions, int row_begin, int row_count,
                                             evogp_stream_t stream_) {
-    if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0 || n_surv > pop_size)
+    return evogp_hip_breed_default_table(pop_size, pop_size, gp_len, n_elite, n_surv, value, type, size, order, rnd, mutate_below,
+                                         donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions, row_begin,
+                                         row_count, stream_);
+}
+
+extern "C" int evogp_hip_breed_default_table(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv,
+                                             const float *value, const int16_t *type, const int16_t *size, const int *order,
+                                             const int *rnd, unsigned mutate_below, const float *donor_value,
+                                             const int16_t *donor_type, const int16_t *donor_size, float *value_res,
+                                             int16_t *type_res, int16_t *size_res, int *decisions, int row_begin, int row_count,
+                                             evogp_stream_t stream_) {
+    if (pop_size <= 0 || table_rows <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0 ||
+        n_surv > pop_size)
         return EVOGP_E_BADARG;
     if (!value || !type || !size || !order || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
     const int n_new = pop_size - n_elite;
@@ -285,7 +298,7 @@ extern "C" int evogp_hip_breed_default_rows(int pop_size, int gp_len, int n_elit
     if (mutate_below != 0 && n_new > 0 && (!donor_value || !donor_type || !donor_size)) return EVOGP_E_NULLPTR;
     if (row_begin < 0 || row_count <= 0 || row_begin + row_count > pop_size) return EVOGP_E_BADARG;
     BreedParams a{value, type, size, order, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
-                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, mutate_below, row_begin, row_count};
+                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, table_rows, mutate_below, row_begin, row_count};
     const DeviceInfo &dev = device_info();
     long blocks = ((long)row_count + 63) / 64;  // one workgroup per 64 rows
     const long cap = (long)dev.num_cus * 8 * 4;

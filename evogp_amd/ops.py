@@ -239,7 +239,10 @@ def breed_default_rows(pop_size, gp_len, n_elite, n_surv, value, ntype, size, or
     _check_sizes_common(pop_size, gp_len)
     _check(0 <= n_elite <= pop_size and 0 < n_surv <= pop_size, "n_elite / n_surv out of range")
     _check(0 <= row_begin and 0 < row_count and row_begin + row_count <= pop_size, "row range out of the population")
-    _check_forest(pop_size, gp_len, value, ntype, size)
+    # value / type / size: the whole population, or only the trees `order` names (a sharded run's survivor table)
+    table_rows = value.shape[0] if value.dim() == 2 else 0
+    _check(table_rows > 0, "value must be a (rows, gp_len) tensor")
+    _check_forest(table_rows, gp_len, value, ntype, size)
     _check(order.is_cuda and order.is_contiguous() and order.dtype == torch.int32 and order.dim() == 1
            and order.shape[0] >= max(n_elite, n_surv), "order must be a contiguous int32 CUDA vector of >= max(n_elite, n_surv) entries")
     _check_tensor(rnd, (6, pop_size - n_elite), "rnd", torch.int32)
@@ -256,8 +259,8 @@ def breed_default_rows(pop_size, gp_len, n_elite, n_surv, value, ntype, size, or
         ov = torch.empty(shp, dtype=torch.float32, device=dev)
         ot = torch.empty(shp, dtype=torch.int16, device=dev)
         osz = torch.empty(shp, dtype=torch.int16, device=dev)
-        rc = _lib_h.evogp_hip_breed_default_rows(
-            pop_size, gp_len, n_elite, n_surv, value.data_ptr(), ntype.data_ptr(), size.data_ptr(), order.data_ptr(),
+        rc = _lib_h.evogp_hip_breed_default_table(
+            pop_size, table_rows, gp_len, n_elite, n_surv, value.data_ptr(), ntype.data_ptr(), size.data_ptr(), order.data_ptr(),
             rnd.data_ptr(), mutate_below, donor_value.data_ptr() - skip * gp_len * 4, donor_type.data_ptr() - skip * gp_len * 2,
             donor_size.data_ptr() - skip * gp_len * 2, ov.data_ptr(), ot.data_ptr(), osz.data_ptr(), None, row_begin, row_count,
             _stream(dev))

@@ -6,16 +6,20 @@ data-parallel axis the workload has for free:
 * fitness evaluation, tree generation and mutation are independent per tree  -> every rank works
   on its own contiguous block of ``pop / G`` trees, no communication;
 * selection ranks the WHOLE population and crossover draws parents from the global survivor set
-  -> exactly one exchange per generation: an all-gather of a packed per-rank buffer
-  ``uint8[(pop/G) x (8*L + 4)]`` = {value, type, size, fitness} of every local tree (64.5 MB per rank
-  at pop = 1M, L = 64: bandwidth-trivial on xGMI, one collective instead of four).
+  -> two collectives per generation: an all-gather of the local FITNESS values (4 B per tree), after which every rank
+  knows the global ranking, and an all-gather of the rows of the trees that can still be read — the survivors and elites,
+  ``max(survival_rate, elite_rate) * pop`` of them — packed as ``uint8[cap x 8 L]`` = {value, type, size} per rank
+  (``cap`` = the largest number of kept trees on any rank).  At pop = 1 M, L = 64 and 30 % survivors that is ~20 MB per
+  rank instead of the 64.5 MB of the whole shard.  On the xGMI mesh every rank sends its block to its 7 peers over 7
+  direct links, so one large collective per array kind is the right granularity.
 
-After the gather every rank holds the identical full population, runs the identical selection
-(stable sort) and draws the identical index tensors from a generator seeded identically on all
-ranks, then materialises ONLY its own slice ``[r*pop/G, (r+1)*pop/G)`` of the next generation with
-``tree_crossover`` / ``tree_generate`` (tree-index offset = global mutation rank) / ``tree_mutate``.
-By construction the union of the shards is bit-identical for every world size, G = 1 included
-(tests/test_sharded_gloo.py checks G = 2 against G = 1 on the gloo backend).
+After the exchange every rank holds the identical table of parents, the identical ranking (stable sort) and draws the
+identical index tensors from a generator seeded identically on all ranks, then materialises ONLY its own slice
+``[r*pop/G, (r+1)*pop/G)`` of the next generation: with the fused breeding pass (``evogp_hip_generate_masked`` +
+``evogp_hip_breed_default_rows``) on a GPU, or with ``tree_crossover`` / ``tree_generate`` (tree-index offset = global
+mutation rank) / ``tree_mutate`` otherwise.  By construction the union of the shards is bit-identical for every world
+size, G = 1 included (tests/test_sharded_gloo.py checks G = 2 against G = 1 on the gloo backend;
+tests/test_gpu_breed.py builds the shards of G = 1, 2, 3, 8 on one GPU).
 
 Operator semantics are those of DefaultSelection / DefaultCrossover / DefaultMutation
 (src/evogp/algorithm/{selection,crossover,mutation}/default.py): same distributions, drawn from an
@@ -33,22 +37,45 @@ from .algorithm.selection import DefaultSelection
 from .tree import MAX_STACK, Forest, GenerateDescriptor
 
 
-def _pack(forest: Forest, fitness: torch.Tensor) -> torch.Tensor:
-    n = forest.pop_size
-    parts = [forest.batch_node_value.contiguous().view(torch.uint8).view(n, -1),
-             forest.batch_node_type.contiguous().view(torch.uint8).view(n, -1),
-             forest.batch_subtree_size.contiguous().view(torch.uint8).view(n, -1),
-             fitness.to(torch.float32).contiguous().view(torch.uint8).view(n, 4)]
+def _pack(forest: Forest, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8[n x 8 L]: value | type | size of the given rows (all rows when ``rows`` is None)"""
+    v, t, s = forest.batch_node_value, forest.batch_node_type, forest.batch_subtree_size
+    if rows is not None:
+        v, t, s = v[rows], t[rows], s[rows]
+    n = v.shape[0]
+    parts = [v.contiguous().view(torch.uint8).view(n, -1), t.contiguous().view(torch.uint8).view(n, -1),
+             s.contiguous().view(torch.uint8).view(n, -1)]
     return torch.cat(parts, dim=1).contiguous()
 
 
-def _unpack(buf: torch.Tensor, L: int, input_len: int, output_len: int):
+def _unpack(buf: torch.Tensor, L: int, input_len: int, output_len: int) -> Forest:
     n = buf.shape[0]
     value = buf[:, : 4 * L].contiguous().view(torch.float32).view(n, L)
     ntype = buf[:, 4 * L: 6 * L].contiguous().view(torch.int16).view(n, L)
     size = buf[:, 6 * L: 8 * L].contiguous().view(torch.int16).view(n, L)
-    fitness = buf[:, 8 * L:].contiguous().view(torch.float32).view(n)
-    return Forest(input_len, output_len, value, ntype, size), fitness
+    return Forest(input_len, output_len, value, ntype, size)
+
+
+def plan_exchange(fit_all: torch.Tensor, n_keep: int, world: int):
+    """From the gathered fitness of the whole population (rank-major): which trees are kept (the best ``n_keep`` in stable
+    descending order), where each lands in the gathered table, and the ranking expressed in table positions.
+    -> (per_rank bool[world][n_local], cap, order int32[n_keep] of table rows).  ``cap`` is the one host sync."""
+    pop = fit_all.shape[0]
+    n_local = pop // world
+    dev = fit_all.device
+    order_g = torch.sort(fit_all, descending=True, stable=True).indices[:n_keep]
+    keep = torch.zeros(pop, dtype=torch.bool, device=dev)
+    keep[order_g] = True
+    per_rank = keep.view(world, n_local)
+    cap = int(per_rank.sum(1).max())
+    within = torch.cumsum(per_rank.to(torch.int64), dim=1) - 1
+    pos = (torch.arange(world, device=dev)[:, None] * cap + within).view(pop)
+    return per_rank, cap, pos[order_g].to(torch.int32).contiguous()
+
+
+def kept_rows(mine: torch.Tensor, cap: int) -> torch.Tensor:
+    """local indices of this rank's kept trees in ascending order, padded with other local trees up to ``cap`` rows"""
+    return torch.argsort((~mine).to(torch.int8), stable=True)[:cap]
 
 
 class ShardedGeneticProgramming:
@@ -74,39 +101,57 @@ class ShardedGeneticProgramming:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)  # identical on every rank: all index draws agree
 
-    # -- the one exchange step ---------------------------------------------------------------------
-    def gather(self, local_fitness: torch.Tensor):
-        if self.world == 1:
-            return self.forest, local_fitness  # nothing to exchange
-        buf = _pack(self.forest, local_fitness)
-        if self.world > 1:
-            out = torch.empty((self.world * buf.shape[0], buf.shape[1]), dtype=torch.uint8, device=buf.device)
-            dist.all_gather_into_tensor(out, buf, group=self.group)
-            buf = out
+    # -- the exchange step -------------------------------------------------------------------------
+    def exchange(self, local_fitness: torch.Tensor):
+        """-> (table Forest, order int32[n_keep] of table rows in descending fitness order, global pop)"""
+        n_elite, n_surv = self.selection.counts(self.pop_size)
+        n_keep = max(n_elite, n_surv, 1)
         f = self.forest
-        return _unpack(buf, f.max_tree_len, f.input_len, f.output_len)
+        fit = local_fitness.to(torch.float32).contiguous()
+        if self.world == 1:
+            order = torch.sort(fit, descending=True, stable=True).indices[:n_keep].to(torch.int32).contiguous()
+            return f, order, self.pop_size
+        fit_all = torch.empty(self.pop_size, dtype=torch.float32, device=fit.device)
+        dist.all_gather_into_tensor(fit_all, fit, group=self.group)
+        per_rank, cap, order = plan_exchange(fit_all, n_keep, self.world)
+        send = _pack(f, kept_rows(per_rank[self.rank], cap))
+        table = torch.empty((self.world * cap, send.shape[1]), dtype=torch.uint8, device=send.device)
+        dist.all_gather_into_tensor(table, send, group=self.group)
+        return _unpack(table, f.max_tree_len, f.input_len, f.output_len), order, self.pop_size
 
     def step(self, local_fitness: torch.Tensor) -> Forest:
         assert local_fitness.shape == (self.n_local,)
-        full, fitness = self.gather(local_fitness)
+        table, order, pop = self.exchange(local_fitness)
         lo, hi = self.rank * self.n_local, (self.rank + 1) * self.n_local
-        if fitness.is_cuda and self.descriptor.max_tree_len == full.max_tree_len \
+        if local_fitness.is_cuda and self.descriptor.max_tree_len == table.max_tree_len \
                 and os.environ.get("EVOGP_NATIVE_STEP", "1") != "0":
-            self.forest = self.next_slice_native(full, fitness, lo, hi)
+            self.forest = self.slice_native(table, order, pop, lo, hi)
         else:
-            self.forest = self.next_slice_torch(full, fitness, lo, hi)
+            self.forest = self.slice_torch(table, order, pop, lo, hi)
         return self.forest
 
+    def _order_of(self, full: Forest, fitness: torch.Tensor) -> torch.Tensor:
+        n_elite, n_surv = self.selection.counts(full.pop_size)
+        return torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv, 1)].to(torch.int32).contiguous()
+
     def next_slice_native(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
-        """Rows [lo, hi) of the next generation with the fused breeding pass (csrc/breed.hip): every rank sorts the
-        gathered fitness, draws the SAME six random words per offspring and the same generation keys from its generator,
-        generates donors only for its own mutating offspring (tree index = global offspring index) and builds only its
-        own rows.  The union over the ranks is the single-device result for the same generator state."""
-        dev = fitness.device
-        pop, L = full.pop_size, full.max_tree_len
+        """rows [lo, hi) of the next generation from the WHOLE population and its fitness (tests, single-table use)"""
+        return self.slice_native(full, self._order_of(full, fitness), full.pop_size, lo, hi)
+
+    def next_slice_torch(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
+        return self.slice_torch(full, self._order_of(full, fitness), full.pop_size, lo, hi)
+
+    def slice_native(self, table: Forest, order: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:
+        """Rows [lo, hi) of the next generation with the fused breeding pass (csrc/breed.hip).  ``table`` holds the trees
+        that can be parents or elites, ``order`` ranks them (table rows, best first), ``pop`` is the size of the WHOLE
+        population.  Every rank draws the SAME six random words per offspring and the same generation keys from its
+        generator, generates donors only for its own mutating offspring (tree index = global offspring index) and builds
+        only its own rows.  The union over the ranks is the single-device result for the same generator state."""
+        full = table
+        dev = order.device
+        L = full.max_tree_len
         n_elite, n_surv = self.selection.counts(pop)
         n_new = pop - n_elite
-        order = torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv)].to(torch.int32).contiguous()
         g = self.gen
         rnd = torch.randint(0, 2**31 - 1, (6, n_new), generator=g, device=dev, dtype=torch.int32)
         keys = torch.randint(0, 1000000, (2,), generator=g, device=dev).to(torch.uint32)
@@ -127,11 +172,12 @@ class ShardedGeneticProgramming:
                                                             *donors, lo, rows)
         return Forest(full.input_len, full.output_len, nv, nt, ns)
 
-    def next_slice_torch(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
-        dev = fitness.device
-        pop = self.pop_size
-        elite_idx, surv_idx = self.selection(full, fitness)       # identical on every rank
-        n_elite = elite_idx.shape[0]
+    def slice_torch(self, table: Forest, order: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:
+        """The same slice composed from the reference's operators (any device)."""
+        full = table
+        dev = order.device
+        n_elite, n_surv = self.selection.counts(pop)
+        elite_idx, surv_idx = order[:n_elite], order[:n_surv]     # identical on every rank
         target = pop - n_elite
         parents = full[surv_idx.to(torch.int64)]
         sizes = parents.batch_subtree_size[:, 0].to(torch.int64)

@@ -135,6 +135,15 @@ int evogp_hip_breed_default_rows(int pop_size, int gp_len, int n_elite, int n_su
                                  float *value_res, int16_t *type_res, int16_t *size_res,
                                  int *decisions, int row_begin, int row_count, evogp_stream_t stream);
 
+/* The same pass when value / type / size hold only the trees that `order` can name — `table_rows` rows, e.g. the
+ * survivor table a sharded run gathers (evogp_amd/parallel.py) — instead of the whole population of `pop_size` trees;
+ * `order` then holds table rows.  evogp_hip_breed_default_rows is this call with table_rows = pop_size. */
+int evogp_hip_breed_default_table(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
+                                  const int16_t *type, const int16_t *size, const int *order, const int *rnd,
+                                  unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                                  const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
+                                  int *decisions, int row_begin, int row_count, evogp_stream_t stream);
+
 /* Non-replicating batch evaluation (replaces the repeat_interleave + tree_evaluate
  * composition of src/evogp/tree/forest.py:143-176): results[t][d][:] = tree_t(variables[d][:]),
  * variables: f32[D][var_len], results: f32[pop][D][out_len]. */

@@ -217,6 +217,25 @@ def test_sharded_native_step_union_equals_single_device(g):
         for a, b in zip(got, ref):
             assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
                                b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), f"G = {G}"
+    # the exchange of a sharded run gathers only the trees that can be parents or elites: the slices built from that
+    # compact table (ranking expressed in table rows) are the same rows again
+    from evogp_amd.parallel import _pack, _unpack, kept_rows, plan_exchange
+
+    for G in (2, 8):
+        n_local = pop // G
+        sel = DefaultSelection(0.3, elite_rate=0.01)
+        n_elite, n_surv = sel.counts(pop)
+        per_rank, cap, order = plan_exchange(fitness, max(n_elite, n_surv), G)
+        assert cap < n_local
+        table = _unpack(torch.cat([_pack(full[r * n_local:(r + 1) * n_local], kept_rows(per_rank[r], cap)) for r in range(G)]), 64, 5, 1)
+        parts = []
+        for r in range(G):
+            sg = ShardedGeneticProgramming(full[:n_local], 0.2, desc.update(max_layer_cnt=3), sel, seed=5)
+            parts.append(sg.slice_native(table, order, pop, r * n_local, (r + 1) * n_local))
+        got = [torch.cat([getattr(p, n) for p in parts]) for n in ("batch_node_value", "batch_node_type", "batch_subtree_size")]
+        for a, b in zip(got, ref):
+            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
+                               b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), f"compact table, G = {G}"
     # and the torch composition of the same step is a valid population of the same shape (different random words)
     sg = ShardedGeneticProgramming(full, 0.2, desc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=5)
     nxt = sg.next_slice_torch(full, fitness, 0, pop)

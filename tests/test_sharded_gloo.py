@@ -84,12 +84,26 @@ def test_pack_unpack_roundtrip():
 
 
 def _roundtrip(Forest, GenerateDescriptor, set_default_device, _pack, _unpack):
+    from evogp_amd.parallel import kept_rows, plan_exchange
+
     set_default_device("cpu")
     desc = GenerateDescriptor(max_tree_len=L, input_len=3, output_len=2, using_funcs=["+", "*", "sin"], max_layer_cnt=4,
                               const_samples=[-1, 0, 1])
-    f = Forest.random_generate(50, desc, keys=torch.tensor([1, 2]))
-    fit = torch.randn(50)
-    g, fit2 = _unpack(_pack(f, fit), L, 3, 2)
-    assert torch.equal(fit, fit2) and torch.equal(f.batch_node_type, g.batch_node_type)
+    f = Forest.random_generate(60, desc, keys=torch.tensor([1, 2]))
+    g = _unpack(_pack(f), L, 3, 2)
+    assert torch.equal(f.batch_node_type, g.batch_node_type)
     assert torch.equal(f.batch_node_value.view(torch.int32), g.batch_node_value.view(torch.int32))
     assert torch.equal(f.batch_subtree_size, g.batch_subtree_size)
+    # the exchange plan: the best n_keep trees, wherever they live, land in the gathered table where `order` says
+    torch.manual_seed(4)
+    fit = torch.randn(60)
+    fit[7] = fit[31]  # a tie: the stable sort prefers the lower index on every rank
+    world, n_keep = 3, 17
+    per_rank, cap, order = plan_exchange(fit, n_keep, world)
+    assert per_rank.shape == (3, 20) and int(per_rank.sum()) == n_keep and cap == int(per_rank.sum(1).max())
+    sends = [_pack(f[r * 20:(r + 1) * 20], kept_rows(per_rank[r], cap)) for r in range(world)]
+    table = _unpack(torch.cat(sends), L, 3, 2)
+    assert table.pop_size == world * cap
+    best = torch.sort(fit, descending=True, stable=True).indices[:n_keep]
+    assert torch.equal(table.batch_node_value[order.long()].view(torch.int32), f.batch_node_value[best].view(torch.int32))
+    assert torch.equal(table.batch_subtree_size[order.long()], f.batch_subtree_size[best])
