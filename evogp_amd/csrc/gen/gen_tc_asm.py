@@ -52,6 +52,9 @@ SLOT = 256  # bytes per handler slot
 NHF = 36    # handlers per flavour
 
 
+KWARM = True  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=0 at generation time disables it)
+
+
 def gen(K, DEPTH, stats=False, fast=0):
     assert K % 4 == 0
     G = K // 4
@@ -235,6 +238,14 @@ def gen(K, DEPTH, stats=False, fast=0):
     tick_end(A_REC)
     if stats:
         a(f"v_add_u32 v{A_TREES}, 1, v{A_TREES}")
+    elif KWARM:
+        # pull the NEXT tree's record into the scalar cache while this tree runs: four one-line loads whose result nobody
+        # reads (the kernarg pointer pair is dead after the prologue and serves as the sink).  A record is 256 bytes
+        # (asserted on the host), the next tree of the batch is the next record; the slack behind the last record
+        # covers the last tree.  Handlers count LDS completions with s_waitcnt lgkmcnt(n): scalar loads in flight can only
+        # make such a wait longer, never shorter, because LDS operations complete in order.
+        for i in range(4):
+            a(f"s_load_dwordx2 %[karg], s[{sREC}:{sREC + 1}], {hex(256 + 64 * i)}")
     # ------------------------------------------------------------------ tile loop (one pass of the program)
     a(f"{lab('tile')}:")
     a(f"s_mul_i32 s{T1}, s{sTILE}, {G * 1024}")
@@ -631,6 +642,8 @@ def gen(K, DEPTH, stats=False, fast=0):
 
 
 if __name__ == "__main__":
+    import os
+    KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     for K, depth in ((8, 9), (4, 15)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:
