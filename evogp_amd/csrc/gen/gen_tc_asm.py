@@ -121,12 +121,13 @@ def gen(K, DEPTH, stats=False, fast=0):
         read_bank(nxt, 4)
 
     def warm(sreg):
-        """pull the first block of the four records starting at tree `sreg` into L2 (result discarded)"""
+        """pull the eight records starting at tree `sreg` into L2 (results discarded)"""
         a(f"s_mul_hi_u32 s{T2}, {sreg}, s19")
         a(f"s_mul_i32 s{T1}, {sreg}, s19")
         a(f"s_add_u32 s{T1}, s{T1}, s8")
         a(f"s_addc_u32 s{T2}, s{T2}, s9")
         a(f"global_load_dwordx4 v[14:17], v13, s[{T1}:{T2}]")
+        a(f"global_load_dwordx4 v[14:17], v13, s[{T1}:{T2}] offset:1024")
 
     def grab():
         a("s_mov_b64 exec, 1")
