@@ -52,6 +52,7 @@ SLOT = 256  # bytes per handler slot
 NHF = 36    # handlers per flavour
 
 
+NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
 KWARM = True  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=0 at generation time disables it)
 
 
@@ -117,6 +118,8 @@ def gen(K, DEPTH, stats=False, fast=0):
         a(f"s_andn2_b32 {PF}, {PF}, 15")
 
     def prefetch(nxt):
+        if NOPF:  # timing experiment only: wrong results
+            return
         a(f"v_add_u32 v4, {PF}, v2")
         read_bank(nxt, 4)
 
@@ -645,6 +648,7 @@ def gen(K, DEPTH, stats=False, fast=0):
 if __name__ == "__main__":
     import os
     KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "1") != "0"
+    NOPF = os.environ.get("EVOGP_TC_GEN_NOPF", "0") == "1"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     for K, depth in ((8, 9), (4, 15)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:

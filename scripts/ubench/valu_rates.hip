@@ -37,6 +37,11 @@ KERNEL(k_cndmask, I4("v_cndmask_b32", "v27, v28, vcc"))
 KERNEL(k_sub_vop2, I4("v_sub_f32", "v28, v30"))
 KERNEL(k_add_u32, I4("v_add_u32", "s20, v28"))
 KERNEL(k_add_sgpr, I4("v_add_f32", "s20, v28"))
+// packed fp32: two rows per instruction (even-aligned register pairs)
+KERNEL(k_pk_add, "v_pk_add_f32 v[32:33], v[28:29], v[30:31]\n\tv_pk_add_f32 v[34:35], v[28:29], v[30:31]\n\tv_pk_add_f32 v[36:37], v[28:29], v[30:31]\n\tv_pk_add_f32 v[38:39], v[28:29], v[30:31]\n\t")
+KERNEL(k_pk_mul, "v_pk_mul_f32 v[32:33], v[28:29], v[30:31]\n\tv_pk_mul_f32 v[34:35], v[28:29], v[30:31]\n\tv_pk_mul_f32 v[36:37], v[28:29], v[30:31]\n\tv_pk_mul_f32 v[38:39], v[28:29], v[30:31]\n\t")
+KERNEL(k_pk_fma, "v_pk_fma_f32 v[32:33], v[28:29], v[30:31], v[24:25]\n\tv_pk_fma_f32 v[34:35], v[28:29], v[30:31], v[24:25]\n\tv_pk_fma_f32 v[36:37], v[28:29], v[30:31], v[24:25]\n\tv_pk_fma_f32 v[38:39], v[28:29], v[30:31], v[24:25]\n\t")
+KERNEL(k_pk_mov, "v_pk_mov_b32 v[32:33], v[28:29], v[30:31]\n\tv_pk_mov_b32 v[34:35], v[28:29], v[30:31]\n\tv_pk_mov_b32 v[36:37], v[28:29], v[30:31]\n\tv_pk_mov_b32 v[38:39], v[28:29], v[30:31]\n\t")
 // VGPR indexing (the interpreter's operand stack): the same adds with s_set_gpr_idx_on active
 #define KERNEL_IDX(name, mode, body4)                                                         \
     __global__ __launch_bounds__(256) void name(unsigned long long *out, float *sink) {       \
@@ -82,7 +87,9 @@ int main() {
 #define RUN(k, n) run(#k, k, n, dout, dsink)
     RUN(k_add_vop2, 4); RUN(k_mul_vop2, 4); RUN(k_sub_vop2, 4); RUN(k_mov, 4); RUN(k_add_sgpr, 4); RUN(k_add_u32, 4); RUN(k_fmac_vop2, 4); RUN(k_fma_vop3, 4); RUN(k_fma_neg_const, 4);
     RUN(k_add_vop3_abs, 4); RUN(k_div_scale, 4); RUN(k_div_scale_vcc, 4); RUN(k_div_fmas, 4); RUN(k_div_fixup, 4); RUN(k_rcp, 4); RUN(k_cmp, 4); RUN(k_cndmask, 4);
+    RUN(k_pk_add, 4); RUN(k_pk_mul, 4); RUN(k_pk_fma, 4); RUN(k_pk_mov, 4);
     RUN(k_add_idx_src0, 4); RUN(k_add_idx_dst, 4); RUN(k_add_idx_s0s1d, 4); RUN(k_mov_idx_dst, 4); RUN(k_fixup_idx_dst, 4);
     RUN(k_divrow4, 48);
+    RUN(k_add_vop2, 4); RUN(k_pk_add, 4); RUN(k_add_vop2, 4); RUN(k_pk_fma, 4); RUN(k_fma_vop3, 4);
     return 0;
 }
