@@ -20,6 +20,8 @@ timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_03_bench.json 2>
 # functional check of the N>1 code path of bench.py on this 1-GPU box: two ranks share the GPU over gloo (not a measurement)
 EVOGP_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 5 --warmup 1 --pop-per-gpu 20000 > $OUT/${TAG}_04b_two_ranks_shared_gpu.log 2>&1
 timeout 300 python scripts/bench_ops.py > $OUT/${TAG}_09_ops.md 2>&1
+timeout 300 python scripts/div_modes.py > $OUT/${TAG}_10_div_modes.log 2>&1
+{ timeout 100 scripts/ubench/div_faithful; timeout 100 scripts/ubench/valu_rates; } > $OUT/${TAG}_11_ubench.log 2>&1
 timeout 200 python scripts/tc_cycles.py > $OUT/${TAG}_05_cycles.json 2>/dev/null
 timeout 300 python scripts/tc_mix.py > $OUT/${TAG}_06_mix.log 2>/dev/null
 cd /tmp
