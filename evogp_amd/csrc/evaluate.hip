@@ -189,9 +189,8 @@ __global__ __launch_bounds__(64) void eval_general_kernel(EvalParams p, int only
     const int lane = threadIdx.x & 63;
     float stk[kMaxStack + 2];
     float outs[MO ? kGeneralOuts : 1];
-    for (int t = blockIdx.x; t < p.pop; t += gridDim.x) {
+    auto process = [&](int t) {
         float *res = p.results + (size_t)t * p.out_len;
-        if (only_marked && uni(f2bits(res[0])) != kSentinelDeepEval) continue;
         const size_t row = (size_t)t * p.gp_len;
         const float *tv = p.value + row;
         const int16_t *tt = p.type + row;
@@ -200,12 +199,27 @@ __global__ __launch_bounds__(64) void eval_general_kernel(EvalParams p, int only
         const int cls = uni(classify_tree(tt, tv, len, MO, p.var_len, p.out_len, kMaxStack));
         if (cls != TREE_OK) {
             for (int o = lane; o < p.out_len; o += kWave) res[o] = __builtin_nanf("");
-            continue;
+            return;
         }
         const float r = run_general<MO>(tt, tv, len, p.vars + (size_t)t * p.var_len, p.var_len, p.out_len, outs, stk);
         if (lane == 0) {
             if (!MO) res[0] = r;
             else for (int o = 0; o < p.out_len; ++o) res[o] = outs[o];
+        }
+    };
+    if (!only_marked) {
+        for (int t = blockIdx.x; t < p.pop; t += gridDim.x) process(t);
+        return;
+    }
+    // behind the lane kernel: the wave looks at 64 result words at a time (one tree per lane) and redoes the marked ones
+    for (int base = blockIdx.x * kWave; base < p.pop; base += gridDim.x * kWave) {
+        const int t = base + lane;
+        const bool marked = t < p.pop && f2bits(p.results[(size_t)t * p.out_len]) == kSentinelDeepEval;
+        unsigned long long mask = __ballot(marked);
+        while (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            process(base + b);
         }
     }
 }
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(64) void eval_general_kernel(EvalParams p, int only
 template <bool MO>
 static hipError_t launch_eval_general(const EvalParams &p, int only_marked, hipStream_t stream) {
     const DeviceInfo &dev = device_info();
-    long blocks = (long)dev.num_cus * 16;
+    long blocks = (long)dev.num_cus * (only_marked ? 2 : 16);  // behind the lane kernel only the (rare) deep trees are left
     if (blocks > p.pop) blocks = p.pop;
     hipLaunchKernelGGL(eval_general_kernel<MO>, dim3((unsigned)blocks), dim3(64), 0, stream, p, only_marked);
     return hipGetLastError();
