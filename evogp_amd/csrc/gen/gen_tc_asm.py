@@ -132,9 +132,16 @@ def gen(K, DEPTH, stats=False, fast=0):
         a(f"global_load_dwordx4 v[14:17], v13, s[{T1}:{T2}]")
         a(f"global_load_dwordx4 v[14:17], v13, s[{T1}:{T2}] offset:1024")
 
+    def dyn_batch(dst):
+        """trees per DYNAMIC batch = batch >> flags[9:8] (at least 1): the tail is handed out in smaller pieces"""
+        a(f"s_bfe_u32 s{T2}, s17, 0x20008")
+        a(f"s_lshr_b32 s{dst}, s16, s{T2}")
+        a(f"s_max_u32 s{dst}, s{dst}, 1")
+
     def grab():
+        dyn_batch(T1)
         a("s_mov_b64 exec, 1")
-        a("v_mov_b32 v9, s16")
+        a(f"v_mov_b32 v9, s{T1}")
         a("global_atomic_add v12, v[10:11], v9, off sc0")
         a("s_mov_b64 exec, -1")
 
@@ -221,7 +228,8 @@ def gen(K, DEPTH, stats=False, fast=0):
     grab()                                         # the next batch, consumed at the end of this one
     warm(f"s{sT0}")
     a(f"s_sub_u32 s{sNB}, s12, s{sT0}")
-    a(f"s_min_u32 s{sNB}, s{sNB}, s16")
+    dyn_batch(T1)
+    a(f"s_min_u32 s{sNB}, s{sNB}, s{T1}")
     a(f"{lab('have_batch')}:")
     a(f"s_mov_b32 s{sB}, 0")
     a(f"s_mov_b64 s[{sOK}:{sOK + 1}], 0")
@@ -250,6 +258,21 @@ def gen(K, DEPTH, stats=False, fast=0):
         # make such a wait longer, never shorter, because LDS operations complete in order.
         for i in range(4):
             a(f"s_load_dwordx2 %[karg], s[{sREC}:{sREC + 1}], {hex(256 + 64 * i)}")
+        # ... and, on the last tree of a STATIC batch, the first record of the wave's next batch (CUR already points at it)
+        a(f"s_add_u32 s{T1}, s{sB}, 1")
+        a(f"s_cmp_lt_u32 s{T1}, s{sNB}")
+        a(f"s_cbranch_scc1 {lab('kwarm_done')}")
+        a("s_cmp_eq_u32 s18, 1")
+        a(f"s_cbranch_scc0 {lab('kwarm_done')}")
+        a(f"s_cmp_lt_u32 {CUR}, {END_}")
+        a(f"s_cbranch_scc0 {lab('kwarm_done')}")
+        a(f"s_mul_hi_u32 s{T2}, {CUR}, s19")
+        a(f"s_mul_i32 s{T1}, {CUR}, s19")
+        a(f"s_add_u32 s{T1}, s{T1}, s8")
+        a(f"s_addc_u32 s{T2}, s{T2}, s9")
+        for i in range(4):
+            a(f"s_load_dwordx2 %[karg], s[{T1}:{T2}], {hex(64 * i)}")
+        a(f"{lab('kwarm_done')}:")
     # ------------------------------------------------------------------ tile loop (one pass of the program)
     a(f"{lab('tile')}:")
     a(f"s_mul_i32 s{T1}, s{sTILE}, {G * 1024}")
