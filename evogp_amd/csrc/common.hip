@@ -62,7 +62,7 @@ unsigned *acquire_counter(hipStream_t stream, hipError_t *err) {
 // block a call uses was zeroed by the PREVIOUS call's first kernel on the same stream (stream order makes that safe), so
 // the steady state needs no hipMemsetAsync in front of every call.
 struct StreamScratch {
-    unsigned *blocks = nullptr;  // 2 x 4 words
+    unsigned *blocks = nullptr;  // 2 x kCallScratchWords
     int cur = 0;
     bool next_clean = false;     // the other block was zeroed by the last call's kernel
 };
@@ -79,7 +79,7 @@ unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hip
     if (!s) {
         g_scratch[dev].emplace_back(stream, StreamScratch{});
         s = &g_scratch[dev].back().second;
-        hipError_t e = hipMalloc((void **)&s->blocks, 8 * sizeof(unsigned));
+        hipError_t e = hipMalloc((void **)&s->blocks, 2 * kCallScratchWords * sizeof(unsigned));
         if (e != hipSuccess) { g_scratch[dev].pop_back(); *err = e; return nullptr; }
     }
     const int use = s->cur ^ 1;  // alternate
@@ -88,23 +88,23 @@ unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hip
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     if (capturing) {
-        hipError_t e = hipMemsetAsync(s->blocks + 4 * use, 0, 4 * sizeof(unsigned), stream);
+        hipError_t e = hipMemsetAsync(s->blocks + kCallScratchWords * use, 0, kCallScratchWords * sizeof(unsigned), stream);
         if (e != hipSuccess) { *err = e; return nullptr; }
         s->cur = use;
         s->next_clean = false;
         *zero_for_next = nullptr;
         *err = hipSuccess;
-        return s->blocks + 4 * use;
+        return s->blocks + kCallScratchWords * use;
     }
     if (!s->next_clean) {
-        hipError_t e = hipMemsetAsync(s->blocks + 4 * use, 0, 4 * sizeof(unsigned), stream);
+        hipError_t e = hipMemsetAsync(s->blocks + kCallScratchWords * use, 0, kCallScratchWords * sizeof(unsigned), stream);
         if (e != hipSuccess) { *err = e; return nullptr; }
     }
     s->cur = use;
     s->next_clean = false;
-    *zero_for_next = s->blocks + 4 * (use ^ 1);
+    *zero_for_next = s->blocks + kCallScratchWords * (use ^ 1);
     *err = hipSuccess;
-    return s->blocks + 4 * use;
+    return s->blocks + kCallScratchWords * use;
 }
 
 void call_scratch_next_is_clean(hipStream_t stream) {

@@ -29,7 +29,7 @@ profiles/r01_issue_model_ubench.log; PMC counters in profiles/):
 
 The block is ONE `asm volatile` statement that never returns (it ends the wave).  Register map (fixed):
 
-  SGPR  s[8:9] records  s[10:11] fitness  s12 pop  s13 D  s14 LDS distance X->y  s15 tiles  s16 batch  s17 flags
+  SGPR  s[8:9] records  s[10:11] fitness  s12 pop, then end of this XCD's dynamic region  s13 D  s14 LDS distance X->y  s15 tiles  s16 batch  s17 flags
         s18 static phase  s19 record stride  s[20:21] jump target  s22 J = dword offset of the current instruction
         s23 H = K * stack height  s24 scatter M0 of the division / scratch  s25 tile  s26 b (tree in batch)
         s27 trees in batch  s28 t0  s29 next dynamic t0 / program block  s[30:31] mask of evaluated trees
@@ -171,6 +171,17 @@ def gen(K, DEPTH, stats=False, fast=0):
     a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")        # this wave's first static batch
     a(f"s_mul_i32 {STRIDE}, s{P3_}, s16")         # distance between two batches of one wave
     a(f"s_mov_b32 {DYN}, s{P2_}")                 # first tree of the dynamic region
+    # one dynamic region and one counter line per XCD: region = XCC_ID & flags[15:12], s18 still holds trees per region
+    a(f"s_getreg_b32 s{P1_}, hwreg(HW_REG_XCC_ID, 0, 4)")
+    a(f"s_bfe_u32 s{P2_}, s17, 0x4000c")
+    a(f"s_and_b32 s{P1_}, s{P1_}, s{P2_}")
+    a(f"s_mul_i32 s{P2_}, s{P1_}, s18")
+    a(f"s_add_u32 {DYN}, {DYN}, s{P2_}")          # first tree of this XCD's region
+    a(f"s_add_u32 s{P2_}, {DYN}, s18")
+    a(f"s_min_u32 s12, s12, s{P2_}")              # s12: end of this XCD's region (the population size is not needed again)
+    a(f"s_lshl_b32 s{P1_}, s{P1_}, 7")            # this XCD's counter: 128 bytes per region
+    a(f"v_add_co_u32 v10, vcc, s{P1_}, v10")
+    a("v_addc_co_u32 v11, vcc, 0, v11, vcc")
     a(f"s_getpc_b64 s[{T1}:{T2}]")
     a(f"{lab('pc')}:")
     a(f"s_add_u32 s{T1}, s{T1}, {lab('hbase')}-{lab('pc')}")

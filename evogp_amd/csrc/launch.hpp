@@ -37,9 +37,13 @@ unsigned *acquire_counter(hipStream_t stream, hipError_t *err);
 // (evogp_hip_set_sr_division / EVOGP_SR_DIV=fast)
 int sr_division_mode();
 
-// Four zeroed words for one SR-fitness call on `stream`, without a memset in the steady state: *zero_for_next is the block
+// A zeroed scratch block (kCallScratchWords words) for one SR-fitness call on `stream`, without a memset in the steady state: *zero_for_next is the block
 // the NEXT call on this stream will get; a kernel of this call zeroes it and the caller then reports that with
 // call_scratch_next_is_clean (otherwise the next acquire memsets it).
+// Layout of a block: words 0..3 = pending-marks flags and work counters (sr_params.hpp), then one work counter per XCD of
+// the threaded-code kernel's dynamic tail, each on its own 128-byte line (word 32 * (1 + xcd)).
+constexpr int kCallScratchXcds = 8;
+constexpr int kCallScratchWords = 32 * (1 + kCallScratchXcds);
 unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hipError_t *err);
 void call_scratch_next_is_clean(hipStream_t stream);
 
