@@ -23,8 +23,7 @@ for g in range(gens):
     e0.record()
     fit = algo.forest.SR_fitness(Xd, yd)
     e1.record()
-    f = -fit
-    f[torch.isnan(f)] = -torch.inf
+    f = torch.where(torch.isnan(fit), torch.full_like(fit, float('-inf')), -fit)
     sizes = algo.forest.batch_subtree_size[:, 0].float()
     algo.step(f)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
