@@ -3,8 +3,10 @@ committed golden vectors.
 
 Bars (BASELINE.json north_star): tree encodings from generate / crossover / mutate are BIT-EXACT;
 SR fitness and evaluation agree within 1e-5 relative (fp32) on the arithmetic function set —
-in fact bit-exact per datapoint there (IEEE + - * / on both sides; only the order of the final
-summation differs) — and within the transcendental-library tolerance stated below for the
+tree_evaluate / batch_evaluate are bit-exact per datapoint there (IEEE + - * / on both sides); in
+tree_SR_fitness the order of the final summation differs and the default division is the
+faithfully rounded short sequence (the ieee mode is tested as well) — and within
+the transcendental-library tolerance stated below for the
 sin/cos/exp/pow families (device OCML vs host glibc: a few ulp per call, amplified by the tree).
 """
 import glob
