@@ -157,6 +157,13 @@ extern "C" const char *evogp_hip_error_string(int code) {
     }
 }
 
+namespace evogp {
+int env_int(const char *name, int def) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : def;
+}
+}  // namespace evogp
+
 // ---- division mode of the SR-fitness fast path ---------------------------------------------------------------------------
 static std::atomic<int> g_sr_division{-1};
 namespace evogp {

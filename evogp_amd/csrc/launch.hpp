@@ -33,6 +33,9 @@ const DeviceInfo &device_info();
 // ordered by the stream.  Returns nullptr and sets *err on failure.
 unsigned *acquire_counter(hipStream_t stream, hipError_t *err);
 
+// integer value of an environment switch, or `def` when it is not set
+int env_int(const char *name, int def);
+
 // 0 = IEEE division in every kernel (default), 1 = the threaded-code fitness path uses the fast division
 // (evogp_hip_set_sr_division / EVOGP_SR_DIV=fast)
 int sr_division_mode();

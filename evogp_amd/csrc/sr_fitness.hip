@@ -340,7 +340,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         p.marks = acquire_call_scratch(stream, &p.zero_next, &me);
         if (!p.marks) return (int)me;
     }
-    const bool forced = getenv("EVOGP_SR_FORCE_GENERAL") != nullptr;
+    static const bool forced = getenv("EVOGP_SR_FORCE_GENERAL") != nullptr;  // A/B switches are read once per process
     if (STORE && !forced && p.out_len <= kMaxOutRegs && ((size_t)p.var_len + (p.out_len > 1 ? 8 * (size_t)p.out_len : 0)) * 256 <= 150 * 1024 &&
         (p.var_len > 32 || p.D > 1024)) {
         // more variables than a register tuple holds, or more rows than one workgroup keeps resident: tile-group kernel
@@ -353,8 +353,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     const bool mo = p.out_len > 1;
     hipError_t e;
     // EVOGP_SR_ASM: 0 = C++ interpreter only, 3 = threaded code (default)
-    int asm_depth = EVOGP_SR_DEFAULT_ASM;
-    if (const char *env = getenv("EVOGP_SR_ASM")) asm_depth = atoi(env);
+    static const int asm_depth = env_int("EVOGP_SR_ASM", EVOGP_SR_DEFAULT_ASM);
     bool tc_done = false;
     if (!STORE && !mo && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
