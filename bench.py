@@ -199,13 +199,15 @@ def main():
         launch_s = kernel_ms.value / 1000.0 / args.steps   # average duration of one fitness launch (rank 0)
         alg_bytes = 6.0 * total_nodes + 2.0 * pop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * pop
         achieved = alg_bytes / launch_s / 1e9
-        traffic = None
+        traffic, valu_busy = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("sr_fitness_hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("sr_fitness_hbm_bytes_per_launch")
+                valu_busy = pj.get("valu", {}).get("short_division", {}).get("valu_pipe_busy_frac")
             except Exception:
-                traffic = None
+                traffic, valu_busy = None, None
         out = {
             "metric": "tree_evals_per_s",
             "value": evals / elapsed,
@@ -235,6 +237,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "valu_pipe_busy": valu_busy,  # what actually bounds the kernel (profiles/pmc_latest.json: SQ counters)
                 "kernel": "tree_SR_fitness = tc_compile_kernel + sr_tc_kernel<8> (+ the two marked-tree follow-ups); launch_ms covers "
                           "the whole call, HIP events on the launch stream",
                 "launch_ms": launch_s * 1000.0, "algorithmic_bytes": alg_bytes,
