@@ -48,8 +48,9 @@ import sys
 
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 OPS = ("add", "sub", "mul", "div")
+UNARY = ("neg", "abs")  # unary functions with handlers, in the compiler kernel's numbering (sr_tc.hip: neg abs sin cos tan)
 SLOT = 256  # bytes per handler slot
-NHF = 36    # handlers per flavour
+NHF = 36 + 2 * len(UNARY)  # handlers per flavour
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
@@ -83,7 +84,9 @@ def gen(K, DEPTH, stats=False, fast=0):
         for f, form in enumerate(FORMS):
             hid[f"{op}_{form}"] = o * 8 + f
     hid["push_c"], hid["push_v"], hid["end"], hid["skip"] = 32, 33, 34, 35
-    assert NHF == 36
+    for u, uop in enumerate(UNARY):
+        hid[f"{uop}_S"], hid[f"{uop}_V"] = 36 + 2 * u, 37 + 2 * u
+    assert NHF == 36 + 2 * len(UNARY)
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -511,6 +514,25 @@ def gen(K, DEPTH, stats=False, fast=0):
         begin("skip", fl)
         a("s_set_gpr_idx_off")
         a(f"s_branch {lab('next_tree')}")
+        # unary functions: the operand is the top of the stack (S: replaced in place) or a variable (V: pushed)
+        for uop in UNARY:
+            bit = {"neg": ("v_xor_b32", "0x80000000"), "abs": ("v_and_b32", "0x7fffffff")}.get(uop)
+            begin(f"{uop}_S", fl)
+            entry()
+            prefetch(nxt)
+            m0_stack(MODE["SRC1"] | MODE["DST"], -K)
+            for k in range(K):
+                a(f"{bit[0]} v{S0 + k}, {bit[1]}, v{S0 + k}")
+            epilogue()
+            begin(f"{uop}_V", fl)
+            entry()
+            prefetch(nxt)
+            m0_stack(MODE["DST"], 0)
+            wait_cur()
+            for k in range(K):
+                a(f"{bit[0]} v{S0 + k}, {bit[1]}, v{cur + k}")
+            a(f"s_add_u32 s{sH}, s{sH}, {K}")
+            epilogue()
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # shared division bodies: K rows, then the scatter through v_div_fixup with an indexed destination
@@ -666,7 +688,7 @@ def gen(K, DEPTH, stats=False, fast=0):
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
     if K == 8 and not stats and not fast:
-        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n"
+        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n#define EVOGP_TC_UNARY_MASK {(1 << len(UNARY)) - 1}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
     out += f"#define EVOGP_TC_ASM_{name}(karg_, wgid_, ldsx_, wave_, dyn_, pf_, base_) \\\n  asm volatile( \\\n"

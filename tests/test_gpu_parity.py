@@ -420,3 +420,29 @@ def test_wide_kernel_deep_multi_output_trees_are_redone(g, oracle, rng):
     assert (cnt >= 0).all() and (cnt <= D).all()
     assert np.abs(cnt - ref).max() <= 2, (np.abs(cnt - ref).max(), np.argmax(np.abs(cnt - ref)))
     assert np.array_equal(cnt[[3, 57, 399]], ref[[3, 57, 399]])
+
+
+@pytest.mark.parametrize("D", [100, 1024, 1500])
+def test_sr_fitness_unary_functions_in_the_threaded_code(g, oracle, rng, D):
+    """neg / abs (and, where the build carries them, sin / cos / tan) have handlers in the threaded-code interpreter:
+    operand on the stack (replaced in place) or a variable (pushed); a function of a constant is folded by the compiler
+    kernel; chains of more than 31 instructions fall back to the register kernels."""
+    funcs = [1, 2, 3, 4, 25, 26]
+    f = oracle.generate(4000, 64, 6, 1, 0.0, 0.4, [31, 7], depth2leaf(6), roulette_uniform(funcs), [-1, 0, 1, 0.5, -2.5])
+    v, t, s = (a.copy() for a in f)
+    # hand-made rows: neg(abs(neg(x0))) chains of growing length (the longest exceed 31 program words), abs of a
+    # constant, neg of a constant inside a division
+    for r, n in enumerate((1, 2, 5, 30, 31, 32, 40, 63)):
+        v[r] = 0; t[r] = 0; s[r] = 0
+        v[r, :n] = np.where(np.arange(n) % 2 == 0, 25, 26); t[r, :n] = 2; s[r, :n] = n + 1 - np.arange(n)
+        v[r, n] = 3; t[r, n] = 0; s[r, n] = 1                                # x3
+    v[8, :3] = [26, 25, -1.5]; t[8, :3] = [2, 2, 1]; s[8, :3] = [3, 2, 1]     # abs(neg(-1.5))
+    v[9, :4] = [4, 0, 25, 0.0]; t[9, :4] = [3, 0, 2, 1]; s[9, :4] = [4, 1, 2, 1]  # x0 / neg(0.0): division by -0 -> NaN
+    for r in range(10):
+        assert oracle.validate_tree(t[r], s[r]) == 0
+    X = rng.uniform(-3, 3, (D, 6)).astype(np.float32)
+    X[0, :] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1.0][:6]
+    y = rng.uniform(-1, 1, (D, 1)).astype(np.float32)
+    for use_mse in (True, False):
+        assert_close_classes(g.sr_fitness(v, t, s, X, y, use_mse), oracle.sr_fitness(v, t, s, X, y, use_mse), RTOL_ARITH,
+                             what=f"unary D={D} mse={use_mse}")
