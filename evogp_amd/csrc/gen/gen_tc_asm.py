@@ -47,8 +47,9 @@ M0 = (mode << 12) | index directly (s_add_u32 m0, H, imm), which replaces s_set_
 import sys
 
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
+SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the FULL register kernel"
 OPS = ("add", "sub", "mul", "div")
-UNARY = ("neg", "abs")  # unary functions with handlers, in the compiler kernel's numbering (sr_tc.hip: neg abs sin cos tan)
+UNARY = ("neg", "abs", "sin", "cos", "tan")  # unary functions with handlers, in the compiler kernel's numbering (sr_tc.hip: neg abs sin cos tan)
 SLOT = 256  # bytes per handler slot
 NHF = 36 + 2 * len(UNARY)  # handlers per flavour
 
@@ -517,6 +518,27 @@ def gen(K, DEPTH, stats=False, fast=0):
         # unary functions: the operand is the top of the stack (S: replaced in place) or a variable (V: pushed)
         for uop in UNARY:
             bit = {"neg": ("v_xor_b32", "0x80000000"), "abs": ("v_and_b32", "0x7fffffff")}.get(uop)
+            if bit is None:
+                # sin / cos / tan: gather the operand into the T bank, remember where the result goes, run the shared body
+                begin(f"{uop}_S", fl)
+                entry()
+                prefetch(nxt)
+                m0_stack(MODE["SRC0"], -K)
+                for k in range(K):
+                    a(f"v_mov_b32 v{T + k}, v{S0 + k}")
+                a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
+                a("s_mov_b32 m0, 0")
+                a(f"s_branch {lab(f'trigbody_{uop}')}")
+                begin(f"{uop}_V", fl)
+                entry()
+                prefetch(nxt)
+                wait_cur()
+                for k in range(K):
+                    a(f"v_mov_b32 v{T + k}, v{cur + k}")
+                a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
+                a(f"s_add_u32 s{sH}, s{sH}, {K}")
+                a(f"s_branch {lab(f'trigbody_{uop}')}")
+                continue
             begin(f"{uop}_S", fl)
             entry()
             prefetch(nxt)
@@ -562,6 +584,113 @@ def gen(K, DEPTH, stats=False, fast=0):
                 for k in range(K):
                     a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
                 epilogue()
+
+    # ---- sin / cos / tan: the small-argument path of the device math library (|x| < 2^17), transcribed from the ISA that
+    # hipcc emits for sinf / cosf / tanf (three-term Cody-Waite reduction by pi/2, the library's polynomials, quadrant
+    # selection, NaN for non-finite operands).  A block with a finite operand of 2^17 or more would need the library's
+    # Payne-Hanek reduction: the tree is handed to the register kernels instead (runtime bail-out below).
+    tx, tn, tr, ts2, tp, tq, tu = 18, 19, 20, 21, 22, 9, 4   # per-row temporaries (v4 / v9 are free inside a body)
+    for uop in ("sin", "cos", "tan"):
+        if uop not in UNARY:
+            continue
+        a(f"{lab(f'trigbody_{uop}')}:")
+        xs = [T + k for k in range(K)]
+        a(f"v_max3_f32 v{tx}, |v{xs[0]}|, |v{xs[1]}|, |v{xs[2]}|")
+        rest = xs[3:]
+        while len(rest) >= 2:
+            a(f"v_max3_f32 v{tx}, v{tx}, |v{rest[0]}|, |v{rest[1]}|")
+            rest = rest[2:]
+        if rest:
+            a(f"v_max_f32 v{tx}, v{tx}, |v{rest[0]}|")
+        a(f"s_mov_b32 s{T1}, 0x48000000")             # 2^17
+        a(f"v_cmp_le_f32 vcc, s{T1}, v{tx}")
+        a(f"s_cbranch_vccnz {lab('bail')}")
+        for k in range(K):
+            x, res = T + k, Q + k
+            a(f"s_mov_b32 s{T1}, 0x3f22f983")         # 2 / pi
+            a(f"v_mul_f32_e64 v{tn}, |v{x}|, s{T1}")
+            a(f"v_rndne_f32 v{tn}, v{tn}")
+            a(f"s_mov_b32 s{T1}, 0xbfc90fda")         # -pi/2, high part
+            a(f"v_cvt_i32_f32 v{tu}, v{tn}")          # quadrant
+            a(f"v_fma_f32 v{tr}, v{tn}, s{T1}, |v{x}|")
+            a(f"v_fmamk_f32 v{tr}, v{tn}, 0xb3a22168, v{tr}")
+            a(f"v_fmamk_f32 v{tr}, v{tn}, 0xa7c234c4, v{tr}")
+            a(f"v_mul_f32 v{ts2}, v{tr}, v{tr}")
+            if uop in ("sin", "cos"):
+                a(f"v_mov_b32 v{tp}, 0x3c0881c4")
+                a(f"v_fmac_f32 v{tp}, 0xb94c1982, v{ts2}")
+                a(f"v_fmaak_f32 v{tp}, v{ts2}, v{tp}, 0xbe2aaa9d")
+                a(f"v_mul_f32 v{tp}, v{ts2}, v{tp}")
+                a(f"v_fmac_f32 v{tr}, v{tr}, v{tp}")                 # sin(r)
+                a(f"v_mov_b32 v{tq}, 0xbab64f3b")
+                a(f"v_fmac_f32 v{tq}, 0x37d75334, v{ts2}")
+                a(f"v_fmaak_f32 v{tq}, v{ts2}, v{tq}, 0x3d2aabf7")
+                a(f"v_fmaak_f32 v{tq}, v{ts2}, v{tq}, 0xbf000004")
+                a(f"v_fma_f32 v{tq}, v{ts2}, v{tq}, 1.0")            # cos(r)
+                a(f"v_and_b32 v{tp}, 1, v{tu}")
+                a(f"v_lshlrev_b32 v{tu}, 30, v{tu}")
+                a(f"v_cmp_eq_u32 vcc, 0, v{tp}")
+                a(f"v_and_b32 v{tu}, 0x80000000, v{tu}")             # sign from bit 1 of the quadrant
+                if uop == "sin":
+                    a(f"v_and_b32 v{tp}, 0x80000000, v{x}")          # sin is odd: the sign of x
+                    a(f"v_cndmask_b32 v{tq}, v{tq}, v{tr}, vcc")     # even quadrant: sin(r), odd: cos(r)
+                    a(f"v_xor_b32 v{tu}, v{tp}, v{tu}")
+                    a(f"v_xor_b32 v{res}, v{tu}, v{tq}")
+                else:
+                    a(f"v_cndmask_b32_e64 v{tq}, -v{tr}, v{tq}, vcc")  # even quadrant: cos(r), odd: -sin(r)
+                    a(f"v_xor_b32 v{res}, v{tu}, v{tq}")
+            else:
+                a(f"v_mov_b32 v{tp}, 0xbf039337")
+                a(f"v_fmac_f32 v{tp}, 0x3c971480, v{ts2}")
+                a(f"v_fmaak_f32 v{tp}, v{ts2}, v{tp}, 0x3f93f425")
+                a(f"v_rcp_f32 v{tp}, v{tp}")
+                a(f"v_mov_b32 v{tq}, 0x3ec54587")
+                a(f"v_fmac_f32 v{tq}, 0xbc8cedd3, v{ts2}")
+                a(f"v_and_b32 v{tu}, 1, v{tu}")
+                a(f"v_mul_f32 v{tp}, v{tq}, v{tp}")
+                a(f"v_mul_f32 v{ts2}, v{ts2}, v{tp}")                # z
+                a(f"v_fma_f32 v{tp}, v{ts2}, v{tr}, v{tr}")          # t = tan(r)
+                a(f"v_rcp_f32 v{tq}, v{tp}")
+                a(f"v_sub_f32 v{tn}, v{tp}, v{tr}")
+                a(f"v_fma_f32 v{tr}, v{ts2}, v{tr}, -v{tn}")
+                a(f"v_cmp_eq_u32 vcc, 0, v{tu}")
+                a(f"v_fma_f32 v{ts2}, v{tp}, -v{tq}, 1.0")
+                a(f"v_fma_f32 v{tr}, v{tr}, -v{tq}, v{ts2}")
+                a(f"v_fma_f32 v{tr}, v{tr}, -v{tq}, -v{tq}")         # -cot(r)
+                a(f"v_cndmask_b32 v{tr}, v{tr}, v{tp}, vcc")
+                a(f"v_and_b32 v{tu}, 0x80000000, v{x}")              # tan is odd
+                a(f"v_xor_b32 v{res}, v{tu}, v{tr}")
+            # (the library's final "NaN for a non-finite operand" select is not needed: infinities never get past the
+            # range test above, and a NaN operand makes every step of the sequence NaN)
+        a(f"s_mov_b32 m0, s{sDST}")
+        for k in range(K):
+            a(f"v_mov_b32 v{S0 + k}, v{Q + k}")
+        epilogue()
+    # runtime bail-out: this tree needs something the handlers do not carry.  Its fitness word gets the sentinel of the
+    # register kernels, their pending flag is raised (flags bit 16: the call has a marks block, 128 bytes in front of the
+    # first counter line), and the wave goes on with its next tree.
+    a(f"{lab('bail')}:")
+    a("s_set_gpr_idx_off")
+    a(f"s_add_u32 s{T1}, s{sT0}, s{sB}")
+    a(f"s_lshl_b32 s{T1}, s{T1}, 2")
+    a(f"v_mov_b32 v4, s{T1}")
+    a(f"v_mov_b32 v5, {hex(SENTINEL_HEAVY)}")
+    a("s_mov_b64 exec, 1")
+    a("global_store_dword v4, v5, s[10:11]")
+    a("s_bitcmp1_b32 s17, 16")
+    a(f"s_cbranch_scc0 {lab('bail_done')}")
+    a(f"s_getreg_b32 s{T1}, hwreg(HW_REG_XCC_ID, 0, 4)")
+    a(f"s_bfe_u32 s{T2}, s17, 0x4000c")
+    a(f"s_and_b32 s{T1}, s{T1}, s{T2}")
+    a(f"s_lshl_b32 s{T1}, s{T1}, 7")
+    a(f"s_add_u32 s{T1}, s{T1}, 128")                 # this XCD's counter line -> word 0 of the scratch block
+    a(f"v_sub_co_u32 v4, vcc, v10, s{T1}")
+    a("v_subbrev_co_u32 v5, vcc, 0, v11, vcc")
+    a("v_mov_b32 v9, 1")
+    a("global_store_dword v[4:5], v9, off")
+    a(f"{lab('bail_done')}:")
+    a("s_mov_b64 exec, -1")
+    a(f"s_branch {lab('next_tree')}")
 
     # end of the program: fold this tile's errors into the accumulator.  The labels of the tile were prefetched by the
     # last instruction of the program (the compiler gives END the LDS offset of y as its "variable"), so they sit in

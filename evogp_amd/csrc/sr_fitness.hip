@@ -57,6 +57,10 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     __shared__ int next_s[2];
 
     if (p.only_marked && p.marks && uni((int)p.marks[0]) == 0) return;  // nothing was marked for this build
+    // Behind another kernel the batch size follows the share of marked trees the marking kernel sampled: few marked
+    // trees -> full 64-tree batches (the work is one mark word per lane), many -> the launcher's load-balancing size.
+    int batch = p.batch;
+    if (p.only_marked && p.marks && p.mark_sample > 0 && uni((int)p.marks[2]) * 8 < p.mark_sample) batch = kMaxBatch;
     using VARS = typename VecOf<VL>::type;
     constexpr int TILE = kWave * K;
     const int lane = threadIdx.x & 63;
@@ -82,24 +86,32 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     };
     if (single) load_tile(w < p.ntiles ? w : 0);
 
-    if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)p.batch);
+    if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)batch);
     __syncthreads();
     int par = 0;
     for (;;) {
         const int t0 = uni(next_s[par]);
         if (t0 >= p.pop) break;
-        const int nb = p.pop - t0 < p.batch ? p.pop - t0 : p.batch;
-        if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)p.batch); // prefetch
+        const int nb = p.pop - t0 < batch ? p.pop - t0 : batch;
+        if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)batch); // prefetch
 
         // ---- phase 1: classify the batch, trees split between the waves ----
+        if (p.only_marked) {
+            // behind another kernel: wave 0 reads the mark words of the whole batch at once (one tree per lane); only the
+            // marked trees are classified below -- a wave that walks the marks one dependent load at a time spends
+            // ~1 us per UNMARKED tree
+            if (w == 0 && lane < nb) {
+                const float *mark = STORE ? p.results + (size_t)(t0 + lane) * p.D * p.out_len : p.fitness + (t0 + lane);
+                cls_s[par][lane] = f2bits(*mark) == kSentinelHeavy ? TREE_OK : TREE_SKIP;
+            }
+            __syncthreads();
+        }
         for (int b = w; b < nb; b += W) {
+            if (p.only_marked && uni(cls_s[par][b]) == TREE_SKIP) continue;
             const size_t row = (size_t)(t0 + b) * p.gp_len;
             int len = uni((int)p.size[row]);
             len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
-            int c;
-            const float *mark = STORE ? p.results + (size_t)(t0 + b) * p.D * p.out_len : p.fitness + (t0 + b);
-            if (p.only_marked && uni(f2bits(*mark)) != kSentinelHeavy) c = TREE_SKIP;
-            else c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH, LEAN ? 1 : 0);
+            const int c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH, LEAN ? 1 : 0);
             if (lane == 0) cls_s[par][b] = c;
         }
         __syncthreads();
@@ -358,7 +370,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     if (!STORE && !mo && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
         p.stats = g_stats;
-        e = launch_threaded_code(p, stream, &tc_done);
+        e = launch_threaded_code(p, stream, &tc_done, &p.mark_sample);
         p.stats = nullptr;
         if (e != hipSuccess) return (int)e;
     }

@@ -446,3 +446,40 @@ def test_sr_fitness_unary_functions_in_the_threaded_code(g, oracle, rng, D):
     for use_mse in (True, False):
         assert_close_classes(g.sr_fitness(v, t, s, X, y, use_mse), oracle.sr_fitness(v, t, s, X, y, use_mse), RTOL_ARITH,
                              what=f"unary D={D} mse={use_mse}")
+
+
+@pytest.mark.parametrize("D", [64, 1024])
+def test_sr_fitness_trigonometric_handlers_match_the_register_kernels(g, oracle, rng, D):
+    """sin / cos / tan in the threaded code are the device math library's small-argument path, instruction for
+    instruction: the fitness must agree with the per-datapoint outputs of batch_evaluate (the C++ interpreter calling the
+    library) to summation order, operands of 2^17 and more (Payne-Hanek territory) hand the tree to the register kernels
+    at RUN time, and non-finite operands give NaN."""
+    funcs = [1, 2, 3, 4, 14, 15, 16]
+    f = oracle.generate(3000, 64, 5, 1, 0.0, 0.4, [77, 5], depth2leaf(6), roulette_uniform(funcs), [-1, 0, 1, 0.5, 3.0])
+    v, t, s = (a.copy() for a in f)
+    # sin / cos / tan of one variable (V form), of a product (S form), of a large constant (folded), nested
+    rows = {0: ([14, 2], [2, 0]), 1: ([15, 2], [2, 0]), 2: ([16, 2], [2, 0]),
+            3: ([14, 3, 0, 1], [2, 3, 0, 0]), 4: ([15, 3, 0, 1], [2, 3, 0, 0]), 5: ([16, 3, 0, 1], [2, 3, 0, 0]),
+            6: ([1, 14, 1.0e6, 0], [3, 2, 1, 0]), 7: ([14, 15, 16, 4], [2, 2, 2, 0]), 8: ([16, 16, 3], [2, 2, 0])}
+    for r, (vals, types) in rows.items():
+        n = len(vals)
+        v[r] = 0; t[r] = 0; s[r] = 0
+        v[r, :n] = vals; t[r, :n] = types
+        s[r, :n] = {2: [2, 1], 3: [3, 2, 1], 4: [4, 3, 2, 1]}[n] if types[1] != 3 and types[0] != 3 else 0
+    s[3, :4] = [4, 3, 1, 1]; s[4, :4] = [4, 3, 1, 1]; s[5, :4] = [4, 3, 1, 1]; s[6, :4] = [4, 2, 1, 1]
+    for r in rows:
+        assert oracle.validate_tree(t[r], s[r]) == 0, r
+    X = rng.uniform(-4, 4, (D, 5)).astype(np.float32)
+    X[:, 2] = rng.uniform(-1.3e5, 1.3e5, D)        # straddles 2^17 = 131072: run-time bail-out for trees that feed it to sin
+    X[:, 3] = rng.uniform(-300, 300, D)
+    X[1, :] = [0.0, -0.0, 131071.9, np.inf, np.nan]
+    X[2, :] = [1e-30, -1e-42, -131072.0, -np.inf, 3.0]
+    y = rng.uniform(-1, 1, (D, 1)).astype(np.float32)
+    got = g.sr_fitness(v, t, s, X, y, True)
+    outs = g.batch_evaluate(v, t, s, X, 1)[:, :, 0]
+    with np.errstate(all="ignore"):
+        d = outs - y[:, 0][None, :]
+        ref = (d * d).astype(np.float64).mean(1).astype(np.float32)
+    assert_close_classes(got, ref, 1e-4, what=f"trig vs batch_evaluate, D={D}")
+    # and against the CPU oracle (glibc): the usual tolerance for transcendental trees
+    _assert_mostly_close(got, oracle.sr_fitness(v, t, s, X, y, True), RTOL_TRANS, ATOL_TRANS, "trig vs oracle", allowed_bad=0.03)
