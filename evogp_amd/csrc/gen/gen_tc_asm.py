@@ -51,7 +51,7 @@ SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the
 OPS = ("add", "sub", "mul", "div")
 UNARY = ("neg", "abs", "sin", "cos", "tan")  # unary functions with handlers, in the compiler kernel's numbering (sr_tc.hip: neg abs sin cos tan)
 SLOT = 256  # bytes per handler slot
-NHF = 36 + 2 * len(UNARY)  # handlers per flavour
+NHF = 37 + 2 * len(UNARY)  # handlers per flavour
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
@@ -87,7 +87,8 @@ def gen(K, DEPTH, stats=False, fast=0):
     hid["push_c"], hid["push_v"], hid["end"], hid["skip"] = 32, 33, 34, 35
     for u, uop in enumerate(UNARY):
         hid[f"{uop}_S"], hid[f"{uop}_V"] = 36 + 2 * u, 37 + 2 * u
-    assert NHF == 36 + 2 * len(UNARY)
+    hid["next"] = 36 + 2 * len(UNARY)
+    assert NHF == 37 + 2 * len(UNARY)
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -555,6 +556,23 @@ def gen(K, DEPTH, stats=False, fast=0):
                 a(f"{bit[0]} v{S0 + k}, {bit[1]}, v{cur + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
             epilogue()
+        # NEXT: the program continues in the tree's overflow block (word 0).  Refill the window, then do what every
+        # handler does at its entry for the instruction that follows: handler address, operand prefetch into the other bank.
+        begin("next", fl)
+        a(f"s_movrels_b32 s{sA}, s{W + 1}")                  # byte distance to the overflow block
+        a(f"s_add_u32 s{sREC}, s{sREC}, s{sA}")
+        a(f"s_addc_u32 s{sREC + 1}, s{sREC + 1}, 0")
+        for i in range(4):
+            a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+        # (sREC now points at the overflow block: the tile loop sees that and reloads the first block for the next pass)
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"s_pack_lh_b32_b16 s{sPC}, s{W}, {BASE}")
+        a(f"s_lshr_b32 {PF}, s{W}, 12")
+        a(f"s_andn2_b32 {PF}, {PF}, 15")
+        prefetch(nxt)
+        a(f"s_mov_b32 s{sJ}, 0")
+        a(f"s_mov_b32 m0, s{sJ}")
+        a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # shared division bodies: K rows, then the scatter through v_div_fixup with an indexed destination
@@ -742,7 +760,22 @@ def gen(K, DEPTH, stats=False, fast=0):
     a(f"{lab('end_acc')}:")
     a(f"s_mov_b32 s{sTILE}, s{T1}")
     a(f"s_cmp_lt_u32 s{sTILE}, s15")
+    a(f"s_cbranch_scc0 {lab('tree_done')}")
+    # another pass over the next tile: a two-block program left its overflow block in the window (NEXT moved sREC)
+    a(f"s_add_u32 s{T1}, s{sT0}, s{sB}")
+    a(f"s_mul_hi_u32 s{T2}, s{T1}, s19")
+    a(f"s_mul_i32 s{T1}, s{T1}, s19")
+    a(f"s_add_u32 s{T1}, s{T1}, s8")
+    a(f"s_addc_u32 s{T2}, s{T2}, s9")
+    a(f"s_cmp_eq_u32 s{T1}, s{sREC}")
     a(f"s_cbranch_scc1 {lab('tile')}")
+    a(f"s_mov_b32 s{sREC}, s{T1}")
+    a(f"s_mov_b32 s{sREC + 1}, s{T2}")
+    for i in range(4):
+        a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+    a("s_waitcnt lgkmcnt(0)")
+    a(f"s_branch {lab('tile')}")
+    a(f"{lab('tree_done')}:")
     # the tree is finished: fixed-order sum of the 64 lanes, lane b of v7 receives it
     for ctl in ("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0",
                 "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0",
