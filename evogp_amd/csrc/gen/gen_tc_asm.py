@@ -49,7 +49,7 @@ import sys
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the FULL register kernel"
 OPS = ("add", "sub", "mul", "div")
-UNARY = ("neg", "abs", "sin", "cos", "tan")  # unary functions with handlers, in the compiler kernel's numbering (sr_tc.hip: neg abs sin cos tan)
+UNARY = ("neg", "abs", "sin", "cos", "tan", "sqrt", "lsqrt", "exp", "log", "llog")  # unary functions with handlers, in the compiler kernel's numbering (sr_tc.hip: neg abs sin cos tan)
 SLOT = 256  # bytes per handler slot
 NHF = 37 + 2 * len(UNARY)  # handlers per flavour
 
@@ -520,25 +520,34 @@ def gen(K, DEPTH, stats=False, fast=0):
         for uop in UNARY:
             bit = {"neg": ("v_xor_b32", "0x80000000"), "abs": ("v_and_b32", "0x7fffffff")}.get(uop)
             if bit is None:
-                # sin / cos / tan: gather the operand into the T bank, remember where the result goes, run the shared body
+                # functions with a shared body: gather the operand (its magnitude for the loose variants) into the T bank,
+                # remember where the result goes, run the body
+                body = {"lsqrt": "sqrt"}.get(uop, uop)
+                mag = uop in ("lsqrt", "llog")
                 begin(f"{uop}_S", fl)
                 entry()
                 prefetch(nxt)
-                m0_stack(MODE["SRC0"], -K)
+                m0_stack(MODE["SRC1"] if mag else MODE["SRC0"], -K)
                 for k in range(K):
-                    a(f"v_mov_b32 v{T + k}, v{S0 + k}")
+                    if mag:
+                        a(f"v_and_b32 v{T + k}, 0x7fffffff, v{S0 + k}")
+                    else:
+                        a(f"v_mov_b32 v{T + k}, v{S0 + k}")
                 a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
                 a("s_mov_b32 m0, 0")
-                a(f"s_branch {lab(f'trigbody_{uop}')}")
+                a(f"s_branch {lab(f'trigbody_{body}')}")
                 begin(f"{uop}_V", fl)
                 entry()
                 prefetch(nxt)
                 wait_cur()
                 for k in range(K):
-                    a(f"v_mov_b32 v{T + k}, v{cur + k}")
+                    if mag:
+                        a(f"v_and_b32 v{T + k}, 0x7fffffff, v{cur + k}")
+                    else:
+                        a(f"v_mov_b32 v{T + k}, v{cur + k}")
                 a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
                 a(f"s_add_u32 s{sH}, s{sH}, {K}")
-                a(f"s_branch {lab(f'trigbody_{uop}')}")
+                a(f"s_branch {lab(f'trigbody_{body}')}")
                 continue
             begin(f"{uop}_S", fl)
             entry()
@@ -680,6 +689,88 @@ def gen(K, DEPTH, stats=False, fast=0):
                 a(f"v_xor_b32 v{res}, v{tu}, v{tr}")
             # (the library's final "NaN for a non-finite operand" select is not needed: infinities never get past the
             # range test above, and a NaN operand makes every step of the sequence NaN)
+        a(f"s_mov_b32 m0, s{sDST}")
+        for k in range(K):
+            a(f"v_mov_b32 v{S0 + k}, v{Q + k}")
+        epilogue()
+    # ---- sqrt / exp / log: the device math library's sequences for sqrtf / expf / logf, transcribed like the trigonometric
+    # ones (full range: no bail-out).  llog = the reference's LOOSE_LOG: log|x|, and -1e9 for x = 0 (forward.cu:139-144).
+    t1, t2, t3, t4, t5 = 18, 19, 20, 21, 22
+    for uop in ("sqrt", "exp", "log", "llog"):
+        if uop not in UNARY:
+            continue
+        a(f"{lab(f'trigbody_{uop}')}:")
+        if uop == "llog":
+            a("v_mov_b32 v9, 0xce6e6b28")                           # -1e9
+        if uop == "exp":
+            a("v_mov_b32 v9, 0x7f800000")
+        for k in range(K):
+            x, res = T + k, Q + k
+            if uop == "sqrt":
+                a(f"v_mul_f32 v{t2}, 0x4f800000, v{x}")
+                a(f"s_mov_b32 s{T1}, 0xf800000")
+                a(f"v_cmp_gt_f32 vcc, s{T1}, v{x}")                 # tiny operand: scale by 2^32
+                a(f"v_cndmask_b32 v{t1}, v{x}, v{t2}, vcc")
+                a(f"v_sqrt_f32 v{t2}, v{t1}")
+                a("s_nop 0")
+                a(f"v_add_u32 v{t3}, -1, v{t2}")
+                a(f"v_add_u32 v{t4}, 1, v{t2}")
+                a(f"v_fma_f32 v{t5}, -v{t3}, v{t2}, v{t1}")
+                a(f"v_fma_f32 v4, -v{t4}, v{t2}, v{t1}")
+                a(f"v_cmp_ge_f32_e64 s[{T1}:{T2}], 0, v{t5}")
+                a("s_nop 1")
+                a(f"v_cndmask_b32_e64 v{t2}, v{t2}, v{t3}, s[{T1}:{T2}]")
+                a(f"v_cmp_lt_f32_e64 s[{T1}:{T2}], 0, v4")
+                a("s_nop 1")
+                a(f"v_cndmask_b32_e64 v{t2}, v{t2}, v{t4}, s[{T1}:{T2}]")
+                a(f"v_mul_f32 v{t3}, 0x37800000, v{t2}")
+                a(f"v_cndmask_b32 v{t2}, v{t2}, v{t3}, vcc")
+                a(f"s_movk_i32 s{T1}, 0x260")                       # +inf, +0, -0: the operand itself
+                a(f"v_cmp_class_f32_e64 vcc, v{t1}, s{T1}")
+                a("s_nop 1")
+                a(f"v_cndmask_b32 v{res}, v{t2}, v{t1}, vcc")
+            elif uop == "exp":
+                a(f"v_mul_f32 v{t2}, 0x3fb8aa3b, v{x}")
+                a(f"s_mov_b32 s{T1}, 0x3fb8aa3b")
+                a(f"v_fma_f32 v{t3}, v{x}, s{T1}, -v{t2}")
+                a(f"v_rndne_f32 v{t4}, v{t2}")
+                a(f"v_fmamk_f32 v{t3}, v{x}, 0x32a5705f, v{t3}")
+                a(f"v_sub_f32 v{t2}, v{t2}, v{t4}")
+                a(f"v_add_f32 v{t2}, v{t2}, v{t3}")
+                a(f"v_cvt_i32_f32 v{t4}, v{t4}")
+                a(f"v_exp_f32 v{t2}, v{t2}")
+                a(f"s_mov_b32 s{T1}, 0xc2ce8ed0")
+                a(f"v_cmp_ngt_f32 vcc, s{T1}, v{x}")
+                a(f"v_ldexp_f32 v{t2}, v{t2}, v{t4}")
+                a(f"v_cndmask_b32 v{t2}, 0, v{t2}, vcc")
+                a(f"s_mov_b32 s{T1}, 0x42b17218")
+                a(f"v_cmp_nlt_f32 vcc, s{T1}, v{x}")
+                a("s_nop 1")
+                a(f"v_cndmask_b32 v{res}, v9, v{t2}, vcc")
+            else:
+                a(f"s_mov_b32 s{T1}, 0x800000")
+                a(f"v_cmp_gt_f32 vcc, s{T1}, v{x}")                 # denormal operand: scale by 2^32
+                a(f"v_cndmask_b32_e64 v{t2}, 0, 32, vcc")
+                a(f"v_ldexp_f32 v{t1}, v{x}, v{t2}")
+                a(f"v_log_f32 v{t1}, v{t1}")
+                a(f"v_mov_b32 v{t2}, 0x41b17218")
+                a(f"v_cndmask_b32 v{t2}, 0, v{t2}, vcc")
+                a(f"v_mul_f32 v{t3}, 0x3f317217, v{t1}")
+                a(f"s_mov_b32 s{T1}, 0x3f317217")
+                a(f"v_fma_f32 v{t4}, v{t1}, s{T1}, -v{t3}")
+                a(f"v_fmamk_f32 v{t4}, v{t1}, 0x3377d1cf, v{t4}")
+                a(f"v_add_f32 v{t3}, v{t3}, v{t4}")
+                a(f"s_mov_b32 s{T1}, 0x7f800000")
+                a(f"v_cmp_lt_f32_e64 vcc, |v{t1}|, s{T1}")
+                a("s_nop 1")
+                a(f"v_cndmask_b32 v{t1}, v{t1}, v{t3}, vcc")
+                if uop == "log":
+                    a(f"v_sub_f32 v{res}, v{t1}, v{t2}")
+                else:
+                    a(f"v_sub_f32 v{t1}, v{t1}, v{t2}")
+                    a(f"v_cmp_eq_f32 vcc, 0, v{x}")
+                    a("s_nop 1")
+                    a(f"v_cndmask_b32 v{res}, v{t1}, v9, vcc")      # LOOSE_LOG(0) = -MAX_VAL
         a(f"s_mov_b32 m0, s{sDST}")
         for k in range(K):
             a(f"v_mov_b32 v{S0 + k}, v{Q + k}")

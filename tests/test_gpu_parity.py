@@ -483,3 +483,39 @@ def test_sr_fitness_trigonometric_handlers_match_the_register_kernels(g, oracle,
     assert_close_classes(got, ref, 1e-4, what=f"trig vs batch_evaluate, D={D}")
     # and against the CPU oracle (glibc): the usual tolerance for transcendental trees
     _assert_mostly_close(got, oracle.sr_fitness(v, t, s, X, y, True), RTOL_TRANS, ATOL_TRANS, "trig vs oracle", allowed_bad=0.03)
+
+
+@pytest.mark.parametrize("D", [64, 1024])
+def test_sr_fitness_sqrt_exp_log_inv_handlers_match_the_register_kernels(g, oracle, rng, D):
+    """sqrt / loose sqrt / exp / log / loose log in the threaded code are the device math library's sequences (full range,
+    no bail-out); inv is the division handler with a constant numerator.  Same comparison as for sin / cos / tan: against
+    the per-datapoint outputs of batch_evaluate, and against the CPU oracle with the transcendental tolerance."""
+    funcs = [1, 2, 3, 4, 20, 21, 22, 23, 25, 26, 27, 28]
+    f = oracle.generate(3000, 64, 5, 1, 0.0, 0.4, [12, 99], depth2leaf(6), roulette_uniform(funcs), [-1, 0, 1, 0.5, 3.0, -2.0])
+    v, t, s = (a.copy() for a in f)
+    # one function of one variable each (V form), of a product (S form), of a constant (folded)
+    r = 0
+    for fid in (20, 21, 22, 23, 27, 28):
+        for child in ("var", "prod", "const"):
+            v[r] = 0; t[r] = 0; s[r] = 0
+            if child == "var":
+                v[r, :2] = [fid, r % 5]; t[r, :2] = [2, 0]; s[r, :2] = [2, 1]
+            elif child == "prod":
+                v[r, :4] = [fid, 3, 0, 1]; t[r, :4] = [2, 3, 0, 0]; s[r, :4] = [4, 3, 1, 1]
+            else:
+                v[r, :4] = [1, fid, [-2.0, 0.0, 7.5][r % 3], 2]; t[r, :4] = [3, 2, 1, 0]; s[r, :4] = [4, 2, 1, 1]
+            assert oracle.validate_tree(t[r], s[r]) == 0
+            r += 1
+    X = rng.uniform(-4, 4, (D, 5)).astype(np.float32)
+    X[:, 3] = rng.uniform(-100, 100, D)                  # exp over- and underflows
+    X[0, :] = [0.0, -0.0, np.inf, -np.inf, np.nan]
+    X[1, :] = [1e-40, -1e-40, 1e38, 88.8, -104.0]          # denormals, exp at its range ends
+    X[2, :] = [1e-30, 4.0, 2.5e-39, -88.8, 89.0]
+    y = rng.uniform(-1, 1, (D, 1)).astype(np.float32)
+    got = g.sr_fitness(v, t, s, X, y, True)
+    outs = g.batch_evaluate(v, t, s, X, 1)[:, :, 0]
+    with np.errstate(all="ignore"):
+        d = outs - y[:, 0][None, :]
+        ref = (d * d).astype(np.float64).mean(1).astype(np.float32)
+    assert_close_classes(got, ref, 1e-4, what=f"sqrt/exp/log/inv vs batch_evaluate, D={D}")
+    _assert_mostly_close(got, oracle.sr_fitness(v, t, s, X, y, True), RTOL_TRANS, ATOL_TRANS, "vs oracle", allowed_bad=0.03)
