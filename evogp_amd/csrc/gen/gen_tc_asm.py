@@ -1,31 +1,37 @@
 #!/usr/bin/env python3
-"""Generate tc_interp_k<K>.inc: the threaded-code SR-fitness interpreter for gfx950 (v3.1).
+"""Generate tc_interp_k<K>.inc: the threaded-code SR-fitness interpreter for gfx950.
 
-Why it looks the way it does — all numbers measured on MI355X (scripts/ubench/issue_model.hip,
-profiles/r01_issue_model_ubench.log; PMC counters in profiles/):
+Why it looks the way it does — measured on MI355X (scripts/ubench/*.hip, profiles/*ubench*.log; PMC counters in profiles/;
+DESIGN.md section 3.1 has the numbers):
 
-  * one SIMD retires a wave64 fp32 VALU instruction every ~2.3 clocks but only ONE scalar instruction every
-    4 clocks, a v_readlane costs 8-12 VALU clocks, a single wave issues at most one instruction per ~4.3 clocks,
-    a computed jump costs the wave ~60 clocks, an LDS read ~200-300 under load, a scalar load of a cold
-    record ~6000.  The interpreter is bound by per-wave LATENCY per tree instruction, so everything below
-    is about fewer dispatches, more vector work per dispatch and no exposed waits.
-  * it interprets a COMPILED program: tc_compile_kernel (sr_tc.hip) fuses every leaf into its parent
-    operator, so there is one dispatch per FUNCTION node (12.9 instead of 26.3 per tree on configs[1]) and
-    the operand stack only holds intermediate results;
-  * the program is fetched with scalar loads into a 64-SGPR window (16 instructions of 4 dwords:
-    {handler address, LDS offset of its first variable operand, operand a, operand b}); the dispatch is
-    s_movrels_b32 + s_setpc_b64 on an ABSOLUTE handler address — no v_readlane, no decode, no compare chain;
-  * K = 8 rows per lane: one tree instruction = 8 VALU (a division ~120);
-  * the dataset lives in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per four
-    rows.  Variable operands are PREFETCHED one instruction ahead: every handler starts by issuing the LDS
-    reads for the NEXT instruction's variable into the other of two operand banks, so the LDS latency runs
-    under the current handler's arithmetic.  Handlers therefore come in two flavours (current bank 0 / 1),
-    chosen by the compiler from the parity of the instruction index;
-  * every wave evaluates WHOLE trees (all datapoint tiles, one after the other): no barrier, no partial sums
-    in LDS, no float atomics.  Work distribution: each workgroup owns a static share that its waves walk
-    round-robin (no atomics, the next batch is known, so its program records are pulled into L2 with one
-    vector load while the current batch runs); the load-balancing tail comes from one global counter
-    (same-address atomics serialise at ~11 ns each).
+  * a tree interpreter on this chip ends up bound by VALU issue (the division's dependent operations above all) once the
+    per-instruction overheads are gone: a computed jump costs a wave ~50 clocks, a v_readlane 8-12 VALU clocks, one
+    scalar instruction issues per ~4 clocks and SIMD, a cold 256-byte scalar load takes >1000 clocks.  So: as few
+    dispatches as possible, as much vector work per dispatch as the registers allow, no exposed waits;
+  * it interprets a COMPILED program: tc_compile_kernel (sr_tc.hip) fuses every leaf into its parent operator, so there
+    is one dispatch per FUNCTION node (12.9 instead of 26.3 per tree on configs[1]) and the operand stack only holds
+    intermediate results;
+  * a program is 8-byte words {(LDS offset of the instruction's variable operand / 16) << 16 | offset of its handler in the
+    64-KiB-aligned handler table, constant or second variable}; a 256-byte record (32 words) is one fill of the 64-SGPR
+    window (four s_load_dwordx16); dispatch = s_movrels_b32 (next word) + s_pack_lh_b32_b16 (handler address) +
+    s_setpc_b64 — no v_readlane, no decode, no compare chain.  Programs of trees with unary functions may need a second
+    block: word 31 is then NEXT (refill from the tree's overflow record);
+  * K = 8 rows per lane: one tree instruction = 8 VALU (a division ~70, sin / cos ~200);
+  * handlers: + - * / in the eight operand forms {S stack, V variable, C constant}^2 minus CC (folded by the compiler);
+    unary neg abs sin cos tan sqrt loose-sqrt exp log loose-log in the forms S (in place) and V (push); the
+    transcendental ones are the device math library's instruction sequences (taken from hipcc's output for sinf, ...),
+    sin / cos / tan only their small-argument path: a block with an operand of 2^17 or more BAILS OUT at run time (the
+    tree gets the register kernels' sentinel and their pending flag is raised);
+  * the division comes in three selectable row sequences (ieee / short / fast, evogp_hip_set_sr_division); the
+    reference's "b == 0 -> NaN" is tested once per K x 64 block (min |b|), not per row;
+  * the dataset lives in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per four rows.
+    Variable operands are PREFETCHED one instruction ahead: every handler starts by issuing the LDS reads for the NEXT
+    instruction's variable into the other of two operand banks.  Handlers therefore come in two flavours (current bank
+    0 / 1), chosen by the compiler from the parity of the instruction index;
+  * every wave evaluates WHOLE trees (all datapoint tiles, one after the other): no barrier, no partial sums in LDS, no
+    float atomics.  Work distribution: each workgroup owns a static share that its waves walk round-robin in batches (the
+    next batch is known: its records are pulled into L2 / the scalar cache while the current one runs); the
+    load-balancing tail is one dynamic region and one counter line per XCD.
 
 The block is ONE `asm volatile` statement that never returns (it ends the wave).  Register map (fixed):
 
@@ -49,7 +55,7 @@ import sys
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the FULL register kernel"
 OPS = ("add", "sub", "mul", "div")
-UNARY = ("neg", "abs", "sin", "cos", "tan", "sqrt", "lsqrt", "exp", "log", "llog")  # unary functions with handlers, in the compiler kernel's numbering (sr_tc.hip: neg abs sin cos tan)
+UNARY = ("neg", "abs", "sin", "cos", "tan", "sqrt", "lsqrt", "exp", "log", "llog")  # unary handlers, in the compiler kernel's numbering (sr_tc.hip)
 SLOT = 256  # bytes per handler slot
 NHF = 37 + 2 * len(UNARY)  # handlers per flavour
 
