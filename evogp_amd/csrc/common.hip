@@ -12,6 +12,32 @@ namespace evogp {
 static std::mutex g_mu;
 static DeviceInfo g_info[64];
 
+// Which XCC ids do workgroups of this device see?  The threaded-code interpreter cuts its dynamic tail into one region per
+// XCD (HW_REG_XCC_ID); a region nobody runs on would never be worked off, so the count is measured, not assumed: a
+// partitioned or differently configured device reports fewer ids.
+__global__ void xcc_probe_kernel(unsigned *seen) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
+    if (threadIdx.x == 0) atomicOr(seen, 1u << (id & 31u));
+}
+
+static int probe_xcc_regions() {
+    unsigned *d = nullptr, h = 0;
+    if (hipMalloc((void **)&d, sizeof(unsigned)) != hipSuccess) return 1;
+    int regions = 1;
+    if (hipMemset(d, 0, sizeof(unsigned)) == hipSuccess) {
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(4096), dim3(64), 0, nullptr, d);
+        if (hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+            int n = 0;
+            while (n < 8 && ((h >> n) & 1u)) ++n;  // ids 0 .. n-1 all present
+            while (regions * 2 <= n) regions *= 2;
+        }
+    }
+    (void)hipGetLastError();
+    (void)hipFree(d);
+    return regions;
+}
+
 const DeviceInfo &device_info() {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -25,6 +51,7 @@ const DeviceInfo &device_info() {
             d.max_waves_per_cu = prop.maxThreadsPerMultiProcessor > 0 ? prop.maxThreadsPerMultiProcessor / 64 : 32;
             d.lds_per_cu = 160 * 1024; // gfx950: 160 KiB per CU (prop.sharedMemPerBlock reports the 64 KiB default cap)
         }
+        d.xcc_regions = probe_xcc_regions();
         d.device = dev;
     }
     return d;

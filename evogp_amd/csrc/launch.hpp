@@ -22,6 +22,7 @@ struct DeviceInfo {
     int num_cus = 256;
     int max_waves_per_cu = 32;
     size_t lds_per_cu = 160 * 1024;
+    int xcc_regions = 1;  // largest power of two <= the number of XCDs that actually run workgroups (<= 8), probed once
 };
 
 // Properties of the CURRENT device (cached per device id).
