@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py — tree-evaluations/s of the SR fitness hot path on N MI355X (one process per GPU).
+"""bench.py — tree-evaluations/s of the SR fitness hot path on N MI355X (one process per GPU over RCCL).
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the hot path over one batch of synthetic input: `tree_SR_fitness` over the
-rank's population shard x 1024 datapoints (BASELINE.json configs[1]: SymbolicRegression synthetic
-10-var, pop = 100k per GPU, 1024 datapoints, max_tree_len = 64).  Inputs (forest, dataset) are
-resident in HBM before the timed region.  The path shards over trees with no data-path collective,
-so scaling is "weak": every rank evaluates its own 100k-tree shard (tree indices offset by rank so
-the union equals the single-device forest), and `value` = trees x datapoints of ALL ranks / time.
+Headline workload (BASELINE.json north_star / configs[2]): SymbolicRegression synthetic 10-var, GLOBAL population
+1 000 000 trees x 1024 datapoints, max_tree_len 64, funcs + - * /.  It fits one GPU (512 MB of trees), so N = 1 runs all
+of it; with N ranks the trees are split into N contiguous shards (rank r generates trees [r P/N, (r+1) P/N) with the
+tree-index offset, so the union is the single-device forest) — "scaling": "strong".  A "step" is ONE pass of the hot
+path: `tree_SR_fitness` over the rank's shard, inputs resident in HBM; the fitness pass has no data-path collective.
+`value` = global_pop x datapoints x steps / max-over-ranks wall time.
 
-Printed by rank 0: one JSON line with the contract fields plus
-  roofline      HBM roofline of the fitness kernel (algorithmic bytes / measured launch time)
-  cpu_baseline  the CPU oracle (plain-C port of the reference algorithm, OpenMP) timed on this
-                host's cores on a bounded sample of the same workload
+With N > 1 and no torch.distributed environment, bench.py launches its N ranks itself (torch.distributed.run, one per
+GPU, backend nccl = RCCL) and fails loudly when fewer than N GPUs are visible.
+
+The same JSON line also carries
+  configs1      BASELINE configs[1] (pop 100k PER GPU x 1024 datapoints, weak), same protocol: ms_per_step, tree-evals/s,
+                generation_ms (fitness + DefaultSelection + DefaultCrossover + DefaultMutation on one shard)
+  generation_ms_sharded  one generation of the GLOBAL population: local fitness + all-gather of the fitness values +
+                all-gather of the survivor rows (RCCL) + selection + breeding of the local rows
+  roofline      the dominant kernel (the threaded-code interpreter sr_tc_kernel): algorithmic bytes / its launch time
+                (HIP events on the launch stream) against the HBM peak, and the fraction of the VALU issue rate it uses,
+                computed from the handler histogram of the compiled population x the generated interpreter's per-handler
+                instruction counts
+  cpu_baseline  the CPU oracle (plain-C port of the reference algorithm, OpenMP) on this host's cores: a bounded sample of
+                the headline workload, and configs[0] (XOR-3d, pop 5000, max_tree_len 32, 8 datapoints) next to the GPU's
+                time for the same call
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,47 +42,103 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
-POP_PER_GPU = 100_000
+GLOBAL_POP = 1_000_000
+POP_PER_GPU = 100_000          # configs[1]
 DATAPOINTS = 1024
 VAR_LEN = 10
 GP_LEN = 64
 
 
-def c2_inputs(rank, pop, device):
-    """SURVEY.md §8d synthetic inputs for configs[1]: forest from tree_generate(keys=[42,0],
-    max_layer_cnt=6, + - * /, consts {-1,0,1}); X ~ U(-5,5) seed 1234; y = x0*x1 + x2*x3 - x4 + 0.5*x5^2."""
+def self_launch(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: become the launcher of N ranks."""
+    have = torch.cuda.device_count()
+    share = os.environ.get("EVOGP_BENCH_SHARE_GPU", "0") == "1"
+    if have < args.gpus and not share:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node (no oversubscription, no CPU fallback)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
+
+
+def sr_inputs(lo, pop, device):
+    """SURVEY.md §8d synthetic inputs: trees [lo, lo + pop) of the forest tree_generate(keys=[42,0], max_layer_cnt=6,
+    + - * /, consts {-1,0,1}) produces; X ~ U(-5,5) seed 1234; y = x0*x1 + x2*x3 - x4 + 0.5*x5^2."""
     from evogp_amd.tree import Forest, GenerateDescriptor
 
     desc = GenerateDescriptor(max_tree_len=GP_LEN, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/"],
                               max_layer_cnt=6, const_samples=[-1, 0, 1])
     keys = torch.tensor([42, 0], dtype=torch.uint32, device=device)
-    forest = Forest.random_generate(pop, desc, keys=keys, tree_index_offset=rank * pop)
+    forest = Forest.random_generate(pop, desc, keys=keys, tree_index_offset=lo)
     rng = np.random.default_rng(1234)
     X = rng.uniform(-5, 5, (DATAPOINTS, VAR_LEN)).astype(np.float32)
     y = (X[:, 0] * X[:, 1] + X[:, 2] * X[:, 3] - X[:, 4] + 0.5 * X[:, 5] ** 2).astype(np.float32)[:, None]
     return forest, torch.from_numpy(X).to(device), torch.from_numpy(y).to(device), X, y
 
 
-def cpu_baseline(forest, X, y, budget_s=12.0):
-    """Time the CPU oracle on a bounded sample (first S trees of this rank's forest x all 1024
-    datapoints); S is sized from a probe so the run takes about `budget_s` seconds."""
-    from oracle.pyoracle import Oracle
+def source_sha():
+    """Hash of the kernel sources: measurements stored in profiles/pmc_latest.json are only quoted for the code they
+    were taken on."""
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "evogp_amd", "csrc")
+    names = sorted(f for f in os.listdir(base) if f.endswith((".hip", ".hpp"))) + ["gen/gen_tc_asm.py"]
+    for n in names:
+        h.update(open(os.path.join(base, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(forest, X, y, device, budget_s=10.0):
+    """The CPU oracle on this host: (a) a bounded sample of the headline workload (first S trees of rank 0's shard x all
+    1024 datapoints, S sized from a probe for ~budget_s seconds); (b) BASELINE configs[0] exactly, beside the GPU."""
+    from oracle.pyoracle import Oracle, depth2leaf, roulette_uniform
 
     o = Oracle("port")
-    v = forest.batch_node_value.cpu().numpy(); t = forest.batch_node_type.cpu().numpy(); s = forest.batch_subtree_size.cpu().numpy()
-    probe = 2048
+    n = min(forest.pop_size, 1_000_000)
+    v = forest.batch_node_value[:n].cpu().numpy(); t = forest.batch_node_type[:n].cpu().numpy(); s = forest.batch_subtree_size[:n].cpu().numpy()
+    probe = 4096
     t0 = time.perf_counter(); o.sr_fitness(v[:probe], t[:probe], s[:probe], X, y, True, 0); dt = time.perf_counter() - t0
-    sample = int(min(v.shape[0], max(probe, probe * budget_s / max(dt, 1e-6))))
+    sample = int(min(n, max(probe, probe * budget_s / max(dt, 1e-6))))
     t0 = time.perf_counter(); o.sr_fitness(v[:sample], t[:sample], s[:sample], X, y, True, 0); dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": sample * X.shape[0] / dt,
         "unit": "tree-evals/s",
         "cores": int(o.threads_used),
         "kind": "port",
-        "sample": f"first {sample} trees of the rank-0 forest x {X.shape[0]} datapoints, {dt:.1f} s, OpenMP over trees "
-                  f"(host has {os.cpu_count()} logical cpus, {len(os.sched_getaffinity(0))} usable)",
+        "sample": f"first {sample} trees of the rank-0 shard x {X.shape[0]} datapoints, {dt:.1f} s, plain-C oracle (-O3 -march=x86-64-v3, "
+                  f"IEEE fp32, no FMA contraction), OpenMP over trees: {int(o.threads_used)} threads on a host with "
+                  f"{os.cpu_count()} logical cpus ({len(os.sched_getaffinity(0))} usable by this process)",
         "node_evals_per_s": float(s[:sample, 0].astype(np.int64).sum()) * X.shape[0] / dt,
     }
+    # configs[0]: XOR-3d SymbolicRegression, pop 5000, max_tree_len 32, 8 datapoints (README.md:130-175), CPU-runnable
+    pop1 = 5000
+    xs = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.float32)
+    ys = (xs[:, 0].astype(int) ^ xs[:, 1].astype(int) ^ xs[:, 2].astype(int)).astype(np.float32)[:, None]
+    f1 = o.generate(pop1, 32, 3, 1, 0.5, 0.5, [42, 0], depth2leaf(4), roulette_uniform([1, 2, 3, 4]), [-1, 0, 1])
+    reps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:
+        o.sr_fitness(*f1, xs, ys, True, 0); reps += 1
+    cpu_s = (time.perf_counter() - t0) / reps
+    from evogp_amd.tree import Forest
+
+    gf = Forest(3, 1, *(torch.from_numpy(a).to(device) for a in f1))
+    gx, gy = torch.from_numpy(xs).to(device), torch.from_numpy(ys).to(device)
+    for _ in range(5):
+        gf.SR_fitness(gx, gy, True, "auto")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50):
+        gf.SR_fitness(gx, gy, True, "auto")
+    torch.cuda.synchronize(); gpu_s = (time.perf_counter() - t0) / 50
+    out["configs0"] = {
+        "workload": "BASELINE configs[0]: XOR-3d SR, pop 5000, max_tree_len 32, 8 datapoints, one fitness pass",
+        "cpu_tree_evals_per_s": pop1 * 8 / cpu_s, "cpu_ms": cpu_s * 1e3, "cpu_threads": int(o.threads_used),
+        "gpu_tree_evals_per_s": pop1 * 8 / gpu_s, "gpu_ms": gpu_s * 1e3,
+        "mean_tree_len": float(f1[2][:, 0].mean()),
+    }
+    return out
 
 
 def main():
@@ -77,44 +146,48 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU)
+    ap.add_argument("--global-pop", type=int, default=GLOBAL_POP, help="trees of the headline workload, split over the ranks")
+    ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU, help="trees per rank of the configs[1] line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline steps (profiling runs: every launch of the fitness kernels then has the headline's shape)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     # EVOGP_BENCH_SHARE_GPU=1 is a functional check of the multi-rank code path on a box with fewer GPUs than ranks: the
     # ranks share the visible devices and talk over gloo (RCCL refuses two ranks on one device).  Never a measurement.
     share_gpu = os.environ.get("EVOGP_BENCH_SHARE_GPU", "0") == "1"
     if share_gpu:
         local_rank %= torch.cuda.device_count()
+    assert local_rank < torch.cuda.device_count(), f"rank {rank}: no GPU {local_rank} on this node"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if share_gpu else "nccl"
         if share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        world = dist.get_world_size()
 
     import evogp_amd  # noqa: F401
     from evogp_amd import _lib
     from evogp_amd.tree import set_default_device
 
     set_default_device(device)
-    pop = args.pop_per_gpu
-    forest, Xd, yd, X, y = c2_inputs(rank, pop, device)
-    sizes = forest.batch_subtree_size[:, 0].to(torch.int64)
-    total_nodes = int(sizes.sum())
-
-    def step():
-        return forest.SR_fitness(Xd, yd, True, "auto")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -122,135 +195,224 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        fit = step()
-    barrier()
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(_lib.lib.evogp_hip_timer_begin(stream), "timer_begin")   # HIP events on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fit = step()
-    kernel_ms = ctypes.c_float(0)
-    _lib.check(_lib.lib.evogp_hip_timer_end(stream, ctypes.byref(kernel_ms)), "timer_end")
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tmax = torch.tensor([x], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        nodes = torch.tensor([total_nodes], dtype=torch.int64, device=device)
-        dist.all_reduce(nodes)
-        all_nodes = int(nodes.item())
-    else:
-        all_nodes = total_nodes
+        return float(tmax.item())
 
-    # the same launch in the other division modes of the fitness path (include/evogp_hip.h), for the record
-    div_ms = {}
-    default_mode = evogp_amd.get_sr_division()
-    for mode in ("ieee", "short", "fast"):
-        evogp_amd.set_sr_division(mode)
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        tsum = torch.tensor([x], dtype=torch.int64, device=device)
+        dist.all_reduce(tsum)
+        return int(tsum.item())
+
+    def timed_steps(forest, Xd, yd, warmup, steps):
+        """W untimed + exactly K timed fitness passes, barrier + synchronize on both sides, max over ranks;
+        also the average duration of one call from a HIP event pair on the launch stream (this rank)."""
+        for _ in range(warmup):
+            forest.SR_fitness(Xd, yd, True, "auto")
+        barrier()
         _lib.check(_lib.lib.evogp_hip_timer_begin(stream), "timer_begin")
-        for _ in range(10):
-            step()
-        ms = ctypes.c_float(0)
-        _lib.check(_lib.lib.evogp_hip_timer_end(stream, ctypes.byref(ms)), "timer_end")
-        div_ms[mode] = ms.value / 10
-    evogp_amd.set_sr_division(default_mode)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            forest.SR_fitness(Xd, yd, True, "auto")
+        ev_ms = ctypes.c_float(0)
+        _lib.check(_lib.lib.evogp_hip_timer_end(stream, ctypes.byref(ev_ms)), "timer_end")
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0), ev_ms.value / steps
 
-    # one generation of the default GP loop on this shard (fitness + selection + crossover + mutation)
-    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
-    from evogp_amd.tree import GenerateDescriptor
+    # ---- headline: the global population, split over the ranks ------------------------------------------------------
+    P = args.global_pop
+    lo, hi = rank * P // world, (rank + 1) * P // world
+    pop = hi - lo
+    forest, Xd, yd, X, y = sr_inputs(lo, pop, device)
+    total_nodes = int(forest.batch_subtree_size[:, 0].to(torch.int64).sum())
+    elapsed, call_ms = timed_steps(forest, Xd, yd, args.warmup, args.steps)
+    all_nodes = sum_over_ranks(total_nodes)
 
-    mdesc = GenerateDescriptor(max_tree_len=GP_LEN, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/"],
-                               max_layer_cnt=3, const_samples=[-1, 0, 1])
-    algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
-    gen_ms = []
-    neg_inf = torch.full((pop,), float("-inf"), dtype=torch.float32, device=device)
-    for _ in range(6):
-        torch.cuda.synchronize(); g0 = time.perf_counter()
-        f = -algo.forest.SR_fitness(Xd, yd, True, "auto")
-        f = torch.where(torch.isnan(f), neg_inf, f)  # no boolean-mask assignment: that one syncs with the host
-        algo.step(f)
-        torch.cuda.synchronize(); gen_ms.append((time.perf_counter() - g0) * 1000)
+    # the same steps once more with per-stage events inside the call (compiler | interpreter | follow-ups): the duration of the
+    # dominant kernel itself.  Kept out of the timed region above.
+    _lib.check(_lib.lib.evogp_hip_debug_profile(1), "profile on")
+    for _ in range(args.steps):
+        forest.SR_fitness(Xd, yd, True, "auto")
+    stage = (ctypes.c_float * 3)()
+    ncalls = ctypes.c_int(0)
+    _lib.check(_lib.lib.evogp_hip_debug_profile_read(stage, ctypes.byref(ncalls)), "profile read")
+    _lib.check(_lib.lib.evogp_hip_debug_profile(0), "profile off")
+    stage_ms = {"program_compiler": stage[0], "interpreter": stage[1], "follow_ups": stage[2], "calls": ncalls.value}
 
-    # the sharded generation step: fitness of the local shard, all-gathers of the fitness values and of the survivor rows,
-    # identical selection / random words on every rank, every rank builds its own rows of the next generation
-    sharded_ms, sharded_err = [], None
+    # VALU issue: handler histogram of the compiled shard x instruction counts of the generated interpreter
+    valu = None
     try:
-        from evogp_amd.algorithm import DefaultSelection as _Sel
-        from evogp_amd.parallel import ShardedGeneticProgramming
+        nh = _lib.lib.evogp_hip_debug_tc_nhandlers()
+        hist = torch.zeros(2 * nh, dtype=torch.int64, device=device)
+        _lib.check(_lib.lib.evogp_hip_debug_tc_histogram(pop, ctypes.c_void_p(hist.data_ptr()), 2 * nh, stream), "tc_histogram")
+        hist = hist.cpu().numpy()
+        table = json.load(open(os.path.join(ROOT, "evogp_amd", "lib", "tc_handlers.json")))
+        mode = evogp_amd.get_sr_division()
+        info = table[f"K8_{mode}"]
+        assert info["nhandlers"] == nh
+        per = np.zeros(nh); names = [None] * nh
+        for name, h in info["handlers"].items():
+            per[h["id"]] = h["valu"]; names[h["id"]] = name
+        words = hist[:nh] + hist[nh:]
+        tiles = (DATAPOINTS + 64 * info["K"] - 1) // (64 * info["K"])
+        wave_insts = float((words * per).sum()) * tiles          # VALU instructions issued per launch (one per 64 lanes)
+        props = torch.cuda.get_device_properties(device)
+        clock_hz = float(getattr(props, "clock_rate", 2_400_000)) * 1e3
+        cus = props.multi_processor_count
+        peak = cus * 4 * clock_hz / 4.0                           # 4 SIMDs per CU, one 64-lane VALU instruction per 4 clocks each
+        kernel_s = stage_ms["interpreter"] / 1e3
+        top = sorted(((int(w), names[i]) for i, w in enumerate(words) if w), reverse=True)[:8]
+        valu = {
+            "frac": wave_insts / kernel_s / peak if kernel_s > 0 else None,
+            "valu_insts_per_launch": wave_insts, "peak_insts_per_s": peak, "cus": cus, "clock_hz": clock_hz,
+            "program_words": int(words.sum()), "words_per_tree": float(words.sum()) / pop, "passes_per_tree": tiles,
+            "top_handlers": [f"{n}:{w}" for w, n in top],
+            "what": "sum over program words of the handler's VALU instruction count (evogp_amd/lib/tc_handlers.json, from the generator) "
+                    "x datapoint tiles, / interpreter launch time, / (CUs x 4 SIMDs x clock / 4): the share of the one-instruction-per-4-clocks "
+                    "VALU issue rate the interpreter's arithmetic uses; transcendental and 3-source instructions take longer than 4 clocks, "
+                    "so the pipe is busier than this fraction says",
+        }
+    except Exception as exc:
+        valu = {"frac": None, "error": repr(exc)[:300]}
 
-        sg = ShardedGeneticProgramming(forest, 0.2, mdesc, _Sel(0.3, elite_rate=0.01), seed=1234)
-        for _ in range(4):
-            barrier(); g0 = time.perf_counter()
-            f = -sg.forest.SR_fitness(Xd, yd, True, "auto")
-            f = torch.where(torch.isnan(f), neg_inf, f)
-            sg.step(f)
-            barrier(); sharded_ms.append((time.perf_counter() - g0) * 1000)
-    except Exception as exc:  # the fitness line must survive a failure of the exchange step
-        sharded_err = repr(exc)[:300]
+    extras = {}
+    if not args.headline_only:
+        # the same launch in the other division modes of the fitness path (include/evogp_hip.h), for the record
+        div_ms = {}
+        default_mode = evogp_amd.get_sr_division()
+        for mode in ("ieee", "short", "fast"):
+            evogp_amd.set_sr_division(mode)
+            for _ in range(2):
+                forest.SR_fitness(Xd, yd, True, "auto")
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib.evogp_hip_timer_begin(stream), "timer_begin")
+            for _ in range(5):
+                forest.SR_fitness(Xd, yd, True, "auto")
+            ms = ctypes.c_float(0)
+            _lib.check(_lib.lib.evogp_hip_timer_end(stream, ctypes.byref(ms)), "timer_end")
+            div_ms[mode] = ms.value / 5
+        evogp_amd.set_sr_division(default_mode)
+        extras["division"] = {"mode": default_mode, "call_ms_by_mode": div_ms,
+                              "what": "short = IEEE range/special handling with one residual correction (default; bit-identical fitness "
+                                      "to ieee on this workload), ieee = correctly rounded always, fast = no range scaling"}
+
+        from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+        from evogp_amd.tree import GenerateDescriptor
+
+        mdesc = GenerateDescriptor(max_tree_len=GP_LEN, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/"],
+                                   max_layer_cnt=3, const_samples=[-1, 0, 1])
+
+        # one generation of the GLOBAL population (SURVEY.md §8e): local fitness, all-gathers of the fitness values and of the
+        # survivor rows, identical selection / random words on every rank, every rank breeds its own rows
+        sharded_ms, sharded_err = [], None
+        try:
+            from evogp_amd.parallel import ShardedGeneticProgramming
+
+            sg = ShardedGeneticProgramming(forest, 0.2, mdesc, DefaultSelection(0.3, elite_rate=0.01), seed=1234)
+            neg_inf = torch.full((pop,), float("-inf"), dtype=torch.float32, device=device)
+            for _ in range(5):
+                barrier(); g0 = time.perf_counter()
+                f = -sg.forest.SR_fitness(Xd, yd, True, "auto")
+                f = torch.where(torch.isnan(f), neg_inf, f)
+                sg.step(f)
+                barrier(); sharded_ms.append(max_over_ranks((time.perf_counter() - g0) * 1000))
+            del sg
+        except Exception as exc:  # the fitness line must survive a failure of the exchange step
+            sharded_err = repr(exc)[:300]
+        extras["generation_ms_sharded"] = {
+            "median": float(np.median(sharded_ms[1:])) if len(sharded_ms) > 1 else None, "global_pop": P, "ranks": world,
+            "exchange": ("none (one rank)" if world == 1 else f"all_gather_into_tensor x2 over {backend}"), "error": sharded_err,
+            "what": "whole population: local fitness + all-gather of the fitness values + all-gather of the survivor rows + selection + "
+                    "breeding pass for the local rows, max over ranks, barriers on both sides"}
+
+        # BASELINE configs[1]: 100k trees per GPU (weak), same protocol
+        pop1 = args.pop_per_gpu
+        forest1, _, _, _, _ = sr_inputs(rank * pop1, pop1, device)
+        nodes1 = int(forest1.batch_subtree_size[:, 0].to(torch.int64).sum())
+        e1, call1_ms = timed_steps(forest1, Xd, yd, args.warmup, args.steps)
+        algo = GeneticProgramming(forest1, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
+        gen_ms = []
+        neg_inf = torch.full((pop1,), float("-inf"), dtype=torch.float32, device=device)
+        for _ in range(6):
+            torch.cuda.synchronize(); g0 = time.perf_counter()
+            f = -algo.forest.SR_fitness(Xd, yd, True, "auto")
+            f = torch.where(torch.isnan(f), neg_inf, f)  # no boolean-mask assignment: that one syncs with the host
+            algo.step(f)
+            torch.cuda.synchronize(); gen_ms.append((time.perf_counter() - g0) * 1000)
+        extras["configs1"] = {
+            "workload": "BASELINE configs[1]: SymbolicRegression synthetic 10-var, pop=100k per GPU, 1024 datapoints, max_tree_len=64, "
+                        "funcs + - * /, one tree_SR_fitness pass per step",
+            "scaling": "weak", "pop_per_gpu": pop1, "ms_per_step": e1 / args.steps * 1000.0, "call_ms_events": call1_ms,
+            "tree_evals_per_s": float(pop1) * DATAPOINTS * world * args.steps / e1,
+            "mean_tree_len": nodes1 / pop1,
+            "generation_ms": {"median": float(np.median(gen_ms[1:])), "first": gen_ms[0],
+                              "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
+        }
 
     if rank == 0:
-        n = world
-        evals = float(pop) * DATAPOINTS * n * args.steps
-        launch_s = kernel_ms.value / 1000.0 / args.steps   # average duration of one fitness launch (rank 0)
-        alg_bytes = 6.0 * total_nodes + 2.0 * pop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * pop
-        achieved = alg_bytes / launch_s / 1e9
-        traffic, valu_busy = None, None
+        evals = float(P) * DATAPOINTS * args.steps
+        kernel_s = stage_ms["interpreter"] / 1e3 if stage_ms["calls"] else call_ms / 1e3
+        alg_bytes = 6.0 * total_nodes + 2.0 * pop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * pop  # SURVEY.md §8d, this rank's launch
+        achieved = alg_bytes / kernel_s / 1e9
+        traffic, traffic_note = None, "no PMC record for this build"
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
-                traffic = pj.get("sr_fitness_hbm_bytes_per_launch")
-                valu_busy = pj.get("valu", {}).get("short_division", {}).get("valu_pipe_busy_frac")
+                if pj.get("source_sha") == source_sha() and pj.get("pop_per_launch") == pop:
+                    traffic = pj.get("sr_tc_kernel_hbm_bytes_per_launch")
+                    traffic_note = f"FETCH_SIZE + WRITE_SIZE of the interpreter kernel, rocprofv3 --pmc, measured on this source ({pj.get('source_sha')}): {pj.get('files')}"
+                else:
+                    traffic_note = (f"profiles/pmc_latest.json was measured on source {pj.get('source_sha')} / {pj.get('pop_per_launch')} trees per launch, "
+                                    f"this is {source_sha()} / {pop}: not quoted")
             except Exception:
-                traffic, valu_busy = None, None
+                pass
         out = {
             "metric": "tree_evals_per_s",
             "value": evals / elapsed,
             "unit": "tree-evals/s",
-            "n_gpus": n,
+            "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1000.0,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not share_gpu else "synthetic; FUNCTIONAL CHECK ONLY: ranks share a GPU over gloo",
             "config": {
-                "workload": "BASELINE configs[1]: SymbolicRegression synthetic 10-var, pop=100k per GPU, 1024 datapoints, "
-                            "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass per step",
-                "pop_per_gpu": pop, "global_pop": pop * n, "datapoints": DATAPOINTS, "var_len": VAR_LEN,
-                "max_tree_len": GP_LEN, "mean_tree_len": total_nodes / pop, "sharding": f"trees x{n}, no data-path collective",
+                "workload": f"BASELINE north_star / configs[2] shape: SymbolicRegression synthetic 10-var, GLOBAL pop={P} x 1024 datapoints, "
+                            "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass over every rank's shard per step",
+                "global_pop": P, "pop_per_gpu": pop, "datapoints": DATAPOINTS, "var_len": VAR_LEN, "max_tree_len": GP_LEN,
+                "mean_tree_len": all_nodes / P, "sharding": f"trees x{world} (contiguous shards, tree-index offset), no data-path collective in the step",
+                "ranks": world, "backend": backend,
             },
             "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
-            "generation_ms": {"median": float(np.median(gen_ms[1:])), "first": gen_ms[0],
-                              "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
-            "generation_ms_sharded": {"median": float(np.median(sharded_ms[1:])) if len(sharded_ms) > 1 else None,
-                                      "global_pop": pop * n, "error": sharded_err,
-                                      "what": "whole population: local fitness + all-gather of the fitness values + all-gather of the "
-                                              "survivor rows (RCCL) + sort + breeding pass for the local rows, max over ranks via barriers"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "valu_pipe_busy": valu_busy,  # what actually bounds the kernel (profiles/pmc_latest.json: SQ counters)
-                "kernel": "tree_SR_fitness = tc_compile_kernel + sr_tc_kernel<8> (+ the two marked-tree follow-ups); launch_ms covers "
-                          "the whole call, HIP events on the launch stream",
-                "launch_ms": launch_s * 1000.0, "algorithmic_bytes": alg_bytes,
-                "division": {"mode": default_mode, "launch_ms_by_mode": div_ms,
-                             "what": "short = IEEE range/special handling with one residual correction (default; bit-identical "
-                                     "fitness to ieee on this workload), ieee = correctly rounded always, fast = no range scaling"},
-                "note": "threaded-code interpreter: ~0.16 algorithmic B per tree-eval at D=1024, bound by the VALU work of the "
-                        "divisions (~37 clocks per 64 rows in the default short sequence, 54 in the IEEE one) and per-instruction latency, not by HBM (DESIGN.md section 5); "
-                        "traffic = FETCH_SIZE + WRITE_SIZE of the call from profiles/pmc_latest.json",
+                "traffic": traffic, "traffic_note": traffic_note,
+                "kernel": "sr_tc_kernel<8,false,2> (threaded-code interpreter, short division), rank 0's launch",
+                "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
+                "call_ms": call_ms, "stage_ms": stage_ms,
+                "frac_whole_call": alg_bytes / (call_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                "valu_issue": valu,
+                "note": "stack-machine interpreter: ~0.16 algorithmic B per tree-eval at D=1024, so the HBM fraction is small by construction "
+                        "(SURVEY.md §7.3-1); the binding resource is VALU issue (valu_issue.frac) plus per-instruction dispatch latency. "
+                        "kernel_ms: HIP events around the interpreter launch inside the call (a second pass of the same steps); "
+                        "call_ms: event pair around the timed steps (compiler + interpreter + follow-up launches)",
             },
         }
-        if not args.no_cpu_baseline and n == 1:
-            out["cpu_baseline"] = cpu_baseline(forest, X, y)
+        out.update(extras)
+        if not args.no_cpu_baseline and world == 1 and not args.headline_only:
+            try:
+                out["cpu_baseline"] = cpu_baseline(forest, X, y, device)
+            except Exception as exc:
+                out["cpu_baseline"] = {"value": None, "error": repr(exc)[:300]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -21,20 +21,28 @@ __global__ void xcc_probe_kernel(unsigned *seen) {
     if (threadIdx.x == 0) atomicOr(seen, 1u << (id & 31u));
 }
 
+// Runs on a private non-blocking stream (never the null stream: no device-wide synchronisation with the caller's streams).
+// Returns 0 when the probe itself failed (the caller then works with one region and tries again later).
 static int probe_xcc_regions() {
     unsigned *d = nullptr, h = 0;
-    if (hipMalloc((void **)&d, sizeof(unsigned)) != hipSuccess) return 1;
-    int regions = 1;
-    if (hipMemset(d, 0, sizeof(unsigned)) == hipSuccess) {
-        hipLaunchKernelGGL(xcc_probe_kernel, dim3(4096), dim3(64), 0, nullptr, d);
-        if (hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
-            int n = 0;
-            while (n < 8 && ((h >> n) & 1u)) ++n;  // ids 0 .. n-1 all present
-            while (regions * 2 <= n) regions *= 2;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int regions = 0;
+    if (hipMalloc((void **)&d, sizeof(unsigned)) == hipSuccess) {
+        if (hipMemsetAsync(d, 0, sizeof(unsigned), s) == hipSuccess) {
+            hipLaunchKernelGGL(xcc_probe_kernel, dim3(4096), dim3(64), 0, s, d);
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess &&
+                hipStreamSynchronize(s) == hipSuccess) {
+                int n = 0;
+                while (n < 8 && ((h >> n) & 1u)) ++n;  // ids 0 .. n-1 all present
+                regions = 1;
+                while (regions * 2 <= n) regions *= 2;
+            }
         }
+        (void)hipFree(d);
     }
     (void)hipGetLastError();
-    (void)hipFree(d);
+    (void)hipStreamDestroy(s);
     return regions;
 }
 
@@ -51,16 +59,38 @@ const DeviceInfo &device_info() {
             d.max_waves_per_cu = prop.maxThreadsPerMultiProcessor > 0 ? prop.maxThreadsPerMultiProcessor / 64 : 32;
             d.lds_per_cu = 160 * 1024; // gfx950: 160 KiB per CU (prop.sharedMemPerBlock reports the 64 KiB default cap)
         }
-        d.xcc_regions = probe_xcc_regions();
         d.device = dev;
     }
     return d;
+}
+
+// Number of dynamic regions (XCDs that run workgroups) of the current device: probed once, on the first call whose stream
+// is not being captured into a graph (the probe allocates, launches and waits: none of that is legal during a capture;
+// such a call works with one region and leaves the probe to a later one).
+static int g_xcc[64];  // 0 = not probed yet
+int xcc_regions(hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (g_xcc[dev] > 0) return g_xcc[dev];
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 1; }
+    const int r = probe_xcc_regions();  // outside the lock: it waits for the device
+    if (r <= 0) return 1;
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_xcc[dev] = r;
+    return r;
 }
 
 constexpr int kCounterRing = 4096;
 struct CounterRing {
     unsigned *base = nullptr;
     std::atomic<unsigned> next{0};
+    hipStream_t last_user[kCounterRing] = {};  // a slot coming round again on ANOTHER stream is not ordered behind its last use
+    bool used[kCounterRing] = {};
 };
 static CounterRing g_ring[64];
 
@@ -78,7 +108,17 @@ unsigned *acquire_counter(hipStream_t stream, hipError_t *err) {
             r.base = ptr;
         }
     }
-    unsigned *slot = r.base + 4 * (r.next.fetch_add(1) % kCounterRing);
+    const unsigned idx = r.next.fetch_add(1) % kCounterRing;
+    unsigned *slot = r.base + 4 * idx;
+    {
+        // 4096 acquisitions later the slot's previous kernel has long finished -- unless thousands of launches are queued.
+        // Same stream: stream order covers it.  Another stream: wait for the device once (cannot happen inside a capture:
+        // captured calls take their counters from the call's scratch block).
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (r.used[idx] && r.last_user[idx] != stream) (void)hipDeviceSynchronize();
+        r.used[idx] = true;
+        r.last_user[idx] = stream;
+    }
     hipError_t e = hipMemsetAsync(slot, 0, 4 * sizeof(unsigned), stream);
     if (e != hipSuccess) { *err = e; return nullptr; }
     *err = hipSuccess;

@@ -64,7 +64,42 @@ NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experimen
 KWARM = True  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=0 at generation time disables it)
 
 
-def gen(K, DEPTH, stats=False, fast=0):
+def count_path(L, start, taken):
+    """Instruction counts along the usual path of one handler: from its label to the jump to the next handler, following
+    unconditional branches; of the conditional ones only those to a label in `taken` (END: a full tile, then the next tile
+    of the same tree).  bench.py multiplies the counts by the handler histogram of a population
+    (evogp_hip_debug_tc_histogram) to state how much of the VALU issue rate the interpreter uses."""
+    idx = {line[:-1]: i for i, line in enumerate(L) if line.endswith(":")}
+    c = {"valu": 0, "trans": 0, "salu": 0, "lds": 0, "vmem": 0, "smem": 0}
+    i, steps = idx[start], 0
+    while steps < 20000:
+        steps += 1
+        line = L[i]
+        i += 1
+        if line.endswith(":") or line.startswith("."):
+            continue
+        w = line.split()
+        op = w[0]
+        if op.startswith("v_"):
+            c["valu"] += 1
+            if op.split("_")[1] in ("rcp", "sqrt", "exp", "log", "rsq", "sin", "cos"):
+                c["trans"] += 1
+        elif op.startswith("ds_"):
+            c["lds"] += 1
+        elif op.startswith("global_") or op.startswith("buffer_"):
+            c["vmem"] += 1
+        elif op.startswith("s_load") or op.startswith("s_memtime"):
+            c["smem"] += 1
+        elif op.startswith("s_"):
+            c["salu"] += 1
+            if op in ("s_setpc_b64", "s_endpgm"):
+                break
+            if op == "s_branch" or (op.startswith("s_cbranch") and w[1] in taken):
+                i = idx[w[1]]
+    return c
+
+
+def gen(K, DEPTH, stats=False, fast=0, info=None):
     assert K % 4 == 0
     G = K // 4
     P = [24, 24 + K]
@@ -940,6 +975,9 @@ def gen(K, DEPTH, stats=False, fast=0):
         a("s_waitcnt vmcnt(0)")
     a("s_endpgm")
 
+    if info is not None:
+        info["K"], info["depth"], info["nhandlers"], info["slot"] = K, DEPTH, NHF, SLOT
+        info["handlers"] = {n: dict(id=i, **count_path(L, lab("h0_" + n), {lab("end_full0"), lab("tile")})) for n, i in hid.items()}
     body = "\n".join(f'    "{line}\\n\\t"' for line in L)
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV)]
     clob_txt = ", ".join(clob)
@@ -965,11 +1003,18 @@ if __name__ == "__main__":
     KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "1") != "0"
     NOPF = os.environ.get("EVOGP_TC_GEN_NOPF", "0") == "1"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
+    import json
+    table = {}
     for K, depth in ((8, 9), (4, 15)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:
-            f.write(gen(K, depth))
+            for fast, tag in ((0, "ieee"), (1, "fast"), (2, "short")):  # division: IEEE / no range scaling / one correction
+                info = {}
+                f.write(gen(K, depth, fast=fast, info=info))
+                table[f"K{K}_{tag}"] = info
             if K == 8:
                 f.write(gen(K, depth, stats=True))  # cycle-accounting build (its top stack slot holds the counters)
-            f.write(gen(K, depth, fast=1))          # fast division (no range scaling)
-            f.write(gen(K, depth, fast=2))          # short division (range-safe, one correction)
         print("wrote", f"{outdir}/tc_interp_k{K}.inc")
+    # per-handler instruction counts of the generated interpreters, read by bench.py (a build artefact like the .inc files)
+    os.makedirs(f"{outdir}/../lib", exist_ok=True)
+    with open(f"{outdir}/../lib/tc_handlers.json", "w") as f:
+        json.dump(table, f, indent=1)

@@ -22,8 +22,11 @@ struct DeviceInfo {
     int num_cus = 256;
     int max_waves_per_cu = 32;
     size_t lds_per_cu = 160 * 1024;
-    int xcc_regions = 1;  // largest power of two <= the number of XCDs that actually run workgroups (<= 8), probed once
 };
+
+// Largest power of two <= the number of XCDs that actually run workgroups (<= 8): probed once per device, outside stream
+// captures (a call on a capturing stream gets 1 until some other call has probed).
+int xcc_regions(hipStream_t stream);
 
 // Properties of the CURRENT device (cached per device id).
 const DeviceInfo &device_info();

@@ -35,11 +35,22 @@
 #include "interp.hpp"
 #include "launch.hpp"
 #include <mutex>
+#include <vector>
 #include "sr_params.hpp"
 
 namespace evogp {
 
 static unsigned long long *g_stats = nullptr; // set by evogp_hip_debug_set_stats
+
+// Per-stage timing of tree_SR_fitness calls (evogp_hip_debug_profile): four events per call on the launch stream --
+// before the call, between the program compiler and the interpreter, behind the interpreter, behind the follow-up kernels.
+struct ProfCall {
+    hipEvent_t ev[4];
+    bool mid;  // ev[1] was recorded (the threaded-code path took the call)
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfCall> g_prof;
 
 __device__ inline float err_term(float diff, int use_mse) { return use_mse ? diff * diff : fabsf(diff); }
 
@@ -367,6 +378,24 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     // EVOGP_SR_ASM: 0 = C++ interpreter only, 3 = threaded code (default)
     static const int asm_depth = env_int("EVOGP_SR_ASM", EVOGP_SR_DEFAULT_ASM);
     bool tc_done = false;
+    ProfCall prof{};
+    bool profiling = false;
+    if (!STORE) {
+        std::lock_guard<std::mutex> pl(g_prof_mu);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (g_prof_on && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            profiling = true;
+            for (auto &ev : prof.ev) if (hipEventCreate(&ev) != hipSuccess) profiling = false;
+            if (profiling) { (void)hipEventRecord(prof.ev[0], stream); p.prof_mid = prof.ev[1]; }
+        }
+    }
+    auto prof_done = [&](bool mid) {
+        if (!profiling) return;
+        (void)hipEventRecord(prof.ev[3], stream);
+        prof.mid = mid;
+        std::lock_guard<std::mutex> pl(g_prof_mu);
+        g_prof.push_back(prof);
+    };
     if (!STORE && !mo && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
         p.stats = g_stats;
@@ -374,6 +403,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         p.stats = nullptr;
         if (e != hipSuccess) return (int)e;
     }
+    if (profiling) (void)hipEventRecord(prof.ev[2], stream);
     if (tc_done) {
         if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
         else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
@@ -393,7 +423,9 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         e = p.var_len <= 16 ? launch_pair<1, 32, 16, true, 16, STORE>(p, stream) : launch_pair<1, 32, 32, true, 16, STORE>(p, stream);
     }
     if (e != hipSuccess) return (int)e;
-    return (int)launch_general<STORE>(p, 1, stream);
+    e = launch_general<STORE>(p, 1, stream);
+    prof_done(tc_done);
+    return (int)e;
 }
 
 } // namespace evogp
@@ -436,5 +468,34 @@ extern "C" int evogp_hip_batch_evaluate(unsigned pop_size, unsigned data_points,
 // nullptr switches the accounting off (the default).
 extern "C" int evogp_hip_debug_set_stats(unsigned long long *device_counters) {
     g_stats = device_counters;
+    return 0;
+}
+
+extern "C" int evogp_hip_debug_profile(int enable) {
+    std::lock_guard<std::mutex> pl(g_prof_mu);
+    for (auto &c : g_prof) for (auto &ev : c.ev) (void)hipEventDestroy(ev);
+    g_prof.clear();
+    g_prof_on = enable != 0;
+    return 0;
+}
+
+extern "C" int evogp_hip_debug_profile_read(float *stage_ms, int *calls) {
+    if (!stage_ms || !calls) return EVOGP_E_NULLPTR;
+    std::lock_guard<std::mutex> pl(g_prof_mu);
+    double sum[3] = {0, 0, 0};
+    int n = 0;
+    for (auto &c : g_prof) {
+        hipError_t e = hipEventSynchronize(c.ev[3]);
+        if (e != hipSuccess) return (int)e;
+        if (!c.mid) continue;  // not a threaded-code call: no compiler / interpreter split
+        for (int i = 0; i < 3; ++i) {
+            float ms = 0;
+            if ((e = hipEventElapsedTime(&ms, c.ev[i], c.ev[i + 1])) != hipSuccess) return (int)e;
+            sum[i] += ms;
+        }
+        ++n;
+    }
+    for (int i = 0; i < 3; ++i) stage_ms[i] = n ? (float)(sum[i] / n) : 0.0f;
+    *calls = n;
     return 0;
 }

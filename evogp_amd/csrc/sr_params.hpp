@@ -27,6 +27,7 @@ struct SrParams {
     int mark_sample; // trees the marking kernel SAMPLED for marks[2] (0: no estimate)
     unsigned long long *stats; // optional cycle counters (profiling builds of the bench only), else nullptr
     unsigned *zero_next; // four words the first kernel of the chain zeroes for the next call on this stream (or nullptr)
+    hipEvent_t prof_mid; // profiling (evogp_hip_debug_profile): recorded between the compiler and the interpreter launch, or nullptr
     unsigned *marks; // [0] != 0: some tree carries kSentinelHeavy, [1] != 0: some tree carries kSentinelDeep,
                      // [2]: how many of the mark_sample sampled trees were marked heavy (may be nullptr)
 };

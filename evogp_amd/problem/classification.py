@@ -50,14 +50,28 @@ class Classification(BaseProblem):
             pred = torch.argmax(torch.clip(torch.softmax(outputs, dim=2), eps, 1 - eps), dim=2)
         return torch.sum(pred == self.labels, dim=1, dtype=torch.float32) / self.labels.shape[0]
 
+    def _int_labels(self):
+        """int32 copy of the labels when every label is integral, else None (checked once: one host sync per problem)"""
+        if not hasattr(self, "_labels_i32"):
+            lab = self.labels
+            ok = bool(torch.all(lab == torch.round(lab))) if lab.is_floating_point() else True
+            self._labels_i32 = lab.to(torch.int32).contiguous() if ok else None
+        return self._labels_i32
+
     def evaluate(self, forest: Forest) -> Tensor:
         D = self.datapoints.shape[0]
         if (self.multi_output and self.datapoints.is_cuda and 2 <= forest.output_len <= 16
-                and forest.input_len * 256 <= 150 * 1024 and os.environ.get("EVOGP_FUSED_ACCURACY", "1") != "0"):
-            # fused epilogue: only the per-tree count of correct rows leaves the kernel (csrc/sr_wide.hip)
+                and forest.input_len * 256 <= 150 * 1024 and os.environ.get("EVOGP_FUSED_ACCURACY", "1") != "0"
+                and self._int_labels() is not None):
+            # fused epilogue: only the per-tree count of correct rows leaves the kernel (csrc/sr_wide.hip).  The kernel compares
+            # the raw arg-max with an int32 label: only taken for integral labels (a label like 1.5 never equals a prediction
+            # in the reference's `pred == labels`, classification.py:62-75; a truncating cast would make it class 1).  One
+            # difference remains and is accepted: the reference takes argmax(clip(softmax(.))), which returns the FIRST of two
+            # outputs whose soft-max values round to the same float (outputs closer than ~6e-8 relative); the kernel
+            # returns the larger raw output.
             counts = torch.ops.evogp_hip.tree_batch_argmax_count(
                 forest.pop_size, D, forest.max_tree_len, forest.input_len, forest.output_len, *forest._tensors(),
-                self.datapoints.contiguous().to(torch.float32), self.labels.to(torch.int32).contiguous())
+                self.datapoints.contiguous().to(torch.float32), self._int_labels())
             return counts.to(torch.float32) / D
         per_tree = 4 * D * max(forest.output_len, 1) * 3        # outputs + soft-max + clip temporaries
         step = max(1, min(forest.pop_size, self.block_bytes // per_tree))

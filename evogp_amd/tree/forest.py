@@ -84,7 +84,7 @@ class Forest:
     # ---- evaluation ---------------------------------------------------------------------------
     def forward(self, x: Tensor) -> Tensor:
         """One input row per tree: x (pop, input_len) -> (pop, output_len)."""
-        x = check_tensor(x)
+        x = check_tensor(x, self.batch_node_value.device)
         assert x.shape == (self.pop_size, self.input_len), (
             f"x shape should be ({self.pop_size}, {self.input_len}), but got {x.shape}")
         return torch.ops.evogp_cuda.tree_evaluate(self.pop_size, self.max_tree_len, self.input_len, self.output_len,
@@ -92,7 +92,7 @@ class Forest:
 
     def batch_forward(self, x: Tensor) -> Tensor:
         """Shared input rows: x (batch, input_len) -> (pop, batch, output_len)."""
-        x = check_tensor(x)
+        x = check_tensor(x, self.batch_node_value.device)
         assert x.dim() == 2 and x.shape[1] == self.input_len, (
             f"x shape[1] should be {self.input_len}, but got {tuple(x.shape)}")
         return torch.ops.evogp_hip.tree_batch_evaluate(self.pop_size, x.shape[0], self.max_tree_len, self.input_len,
@@ -101,7 +101,7 @@ class Forest:
 
     def SR_fitness(self, inputs: Tensor, labels: Tensor, use_MSE: bool = True, execute_mode: str = "auto") -> Tensor:
         """Mean squared / absolute error of every tree over the dataset: (pop,), positive."""
-        inputs, labels = check_tensor(inputs), check_tensor(labels)
+        inputs, labels = check_tensor(inputs, self.batch_node_value.device), check_tensor(labels, self.batch_node_value.device)
         n = inputs.shape[0]
         assert inputs.shape == (n, self.input_len), (
             f"inputs shape should be ({n}, {self.input_len}), but got {inputs.shape}")
@@ -116,7 +116,7 @@ class Forest:
     # ---- genetic operators --------------------------------------------------------------------
     def mutate(self, replace_pos: Tensor, new_sub_forest: "Forest") -> "Forest":
         """Replace the subtree at replace_pos[n] of tree n by the whole tree new_sub_forest[n]."""
-        replace_pos = check_tensor(replace_pos)
+        replace_pos = check_tensor(replace_pos, self.batch_node_value.device)
         assert replace_pos.shape == (self.pop_size,), (
             f"replace_pos shape should be ({self.pop_size}, ), but got {replace_pos.shape}")
         for attr in ("pop_size", "input_len", "output_len", "max_tree_len"):
@@ -130,7 +130,7 @@ class Forest:
     def crossover(self, left_indices: Tensor, right_indices: Tensor, left_pos: Tensor, right_pos: Tensor) -> "Forest":
         """out[n] = self[left_indices[n]] with subtree left_pos[n] replaced by subtree right_pos[n] of
         self[right_indices[n]]."""
-        idx = [check_tensor(t).contiguous().to(torch.int32) for t in (left_indices, right_indices, left_pos, right_pos)]
+        idx = [check_tensor(t, self.batch_node_value.device).contiguous().to(torch.int32) for t in (left_indices, right_indices, left_pos, right_pos)]
         n = idx[0].shape[0]
         for name, t in zip(("left_indices", "right_indices", "left_pos", "right_pos"), idx):
             assert t.shape == (n,), f"{name} shape should be ({n}, ), but got {t.shape}"

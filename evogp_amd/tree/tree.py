@@ -34,7 +34,7 @@ class Tree:
 
     def forward(self, x: Tensor) -> Tensor:
         """x: (input_len,) or (batch, input_len) -> (output_len,) or (batch, output_len)."""
-        x = check_tensor(x)
+        x = check_tensor(x, self.node_value.device)
         assert x.dim() <= 2, f"x dim should be <= 2, but got {x.dim()}"
         squeeze = x.dim() == 1
         if squeeze:
@@ -50,7 +50,7 @@ class Tree:
         return res[0] if squeeze else res
 
     def SR_fitness(self, inputs: Tensor, labels: Tensor, use_MSE: bool = True, execute_mode: str = "auto") -> Tensor:
-        inputs, labels = check_tensor(inputs), check_tensor(labels)
+        inputs, labels = check_tensor(inputs, self.node_value.device), check_tensor(labels, self.node_value.device)
         assert execute_mode in _SR_MODES_TREE, (
             f"execute_mode should be one of {list(_SR_MODES_TREE)}, but got {execute_mode}")
         n = inputs.shape[0]

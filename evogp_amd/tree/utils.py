@@ -89,11 +89,13 @@ def dict2prob(prob_dict) -> torch.Tensor:
     return prob / prob.sum()
 
 
-def check_tensor(x):
-    """Tensor on the default device, detached (non-tensors are converted to float32)."""
+def check_tensor(x, device=None):
+    """Tensor on ``device`` (a Forest passes the device of its own tensors, so operands follow the population in a
+    multi-GPU process; default: the default device), detached (non-tensors are converted to float32)."""
+    device = default_device() if device is None else device
     if not isinstance(x, torch.Tensor):
-        return torch.tensor(x, dtype=torch.float32, device=default_device())
-    return x.to(default_device()).detach().requires_grad_(False)
+        return torch.tensor(x, dtype=torch.float32, device=device)
+    return x.to(device).detach().requires_grad_(False)
 
 
 def randint(size, low, high, dtype=torch.int32, device=None, requires_grad=False):

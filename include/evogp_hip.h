@@ -174,6 +174,20 @@ int evogp_hip_timer_end(evogp_stream_t stream, float *elapsed_ms);
  * barrier wait, trees, nodes, whole kernel, waves, unused}; NULL (the default) disables the accounting. */
 int evogp_hip_debug_set_stats(unsigned long long *device_counters);
 
+/* Per-stage timing of evogp_hip_sr_fitness (profiling, no counterpart in the reference).  While enabled, every call records
+ * HIP events on its launch stream: before the call, between the program compiler and the interpreter kernel, behind the
+ * interpreter, behind the follow-up kernels.  _read waits for the recorded calls and returns the average duration in ms
+ * of {compiler, interpreter, follow-ups} over the calls the threaded-code path took; enable(…) also clears the record. */
+int evogp_hip_debug_profile(int enable);
+int evogp_hip_debug_profile_read(float *stage_ms /* [3] */, int *calls);
+
+/* Handler histogram of the program records the most recent evogp_hip_sr_fitness call on the current device compiled:
+ * device_hist[flavour * N + id] = number of program words with that handler among the first `pop` trees, N =
+ * evogp_hip_debug_tc_nhandlers(), hist_len >= 2 N.  Handler ids and their instruction counts: evogp_amd/lib/tc_handlers.json
+ * (written by csrc/gen/gen_tc_asm.py).  bench.py derives the VALU-issue roofline of the interpreter from it. */
+int evogp_hip_debug_tc_histogram(unsigned pop, unsigned long long *device_hist, int hist_len, evogp_stream_t stream);
+int evogp_hip_debug_tc_nhandlers(void);
+
 /* Human-readable text for a return code of any function above. */
 const char *evogp_hip_error_string(int code);
 

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn the three PMC passes of scripts/gpu_r02.sh (FETCH_SIZE | WRITE_SIZE | SQ counters; bench.py --headline-only, so
+every launch of the fitness kernels has the headline's shape) into profiles/pmc_latest.json.  The record carries the hash
+of the kernel sources and the trees per launch: bench.py quotes `traffic` only when both match what it runs.
+
+    python scripts/pmc_json.py pmc1.md pmc2.md pmc3.md bench_line.log > profiles/pmc_latest.json
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def table(path):
+    out = {}
+    for line in open(path):
+        m = re.match(r"\| `(.+?)` \| (\w+) \| (\d+) \| ([\d.e+-]+) \| ([\d.e+-]+) \|", line)
+        if m:
+            out.setdefault(m.group(1), {})[m.group(2)] = (int(m.group(3)), float(m.group(5)))
+    return out
+
+
+def main():
+    import bench
+
+    t = {}
+    for p in sys.argv[1:4]:
+        for k, v in table(p).items():
+            t.setdefault(k, {}).update(v)
+    line = None
+    for raw in open(sys.argv[4]):
+        raw = raw.strip()
+        if raw.startswith("{") and '"metric"' in raw:
+            line = json.loads(raw)
+    interp = next((k for k in t if "sr_tc_kernel<8, false, 2>" in k), None)
+    comp = next((k for k in t if "tc_compile" in k), None)
+    out = {
+        "what": "rocprofv3 --kernel-trace --pmc, one counter set per pass (FETCH_SIZE | WRITE_SIZE | SQ_*), command: python bench.py "
+                "--steps 4 --warmup 1 --headline-only; per-dispatch averages (scripts/rocpd_summary.py)",
+        "source_sha": bench.source_sha(),
+        "pop_per_launch": line["config"]["pop_per_gpu"] if line else None,
+        "files": [os.path.basename(p) for p in sys.argv[1:4]],
+        "kernels": {},
+    }
+    for name, key in ((interp, "sr_tc_kernel"), (comp, "tc_compile_kernel")):
+        if not name:
+            continue
+        c = {k: v[1] for k, v in t[name].items()}
+        out["kernels"][key] = {"rocprof_name": name, "dispatches": max(v[0] for v in t[name].values()), "per_dispatch": c}
+    if interp and "FETCH_SIZE" in t[interp] and "WRITE_SIZE" in t[interp]:
+        f, w = t[interp]["FETCH_SIZE"][1] * 1024, t[interp]["WRITE_SIZE"][1] * 1024
+        pop = out["pop_per_launch"] or 0
+        out["sr_tc_kernel_fetch_bytes_raw"] = f
+        out["sr_tc_kernel_write_bytes_raw"] = w
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KB) reports half the bytes of wide coalesced reads (16 B per lane).  The interpreter's
+        # HBM reads are of exactly that kind (the global_load_dwordx4 warm-up loads pull the records into L2, the scalar loads then
+        # hit L2), and the known byte count calibrates it: pop x 256-byte records.
+        out["sr_tc_kernel_hbm_bytes_per_launch"] = 2 * f + w
+        out["correction"] = ("counter values are KB (x 1024); FETCH_SIZE doubled (gfx950 tallies 128-byte requests of 16 B/lane coalesced reads at 64 B; "
+                             f"calibration on this kernel: records = pop x 256 B = {pop * 256} B, raw FETCH_SIZE = {f:.0f} B); WRITE_SIZE as reported")
+    if interp and "SQ_WAVE_CYCLES" in t[interp]:
+        c = {k: v[1] for k, v in t[interp].items()}
+        wc = c["SQ_WAVE_CYCLES"]
+        out["sq"] = {k.lower() + "_over_wave_cycles": c[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in c}
+        if "SQ_INSTS_VALU" in c and "SQ_INSTS_SALU" in c:
+            out["sq"]["insts_valu_over_insts_salu"] = c["SQ_INSTS_VALU"] / c["SQ_INSTS_SALU"]
+            out["sq"]["insts_valu_per_launch"] = c["SQ_INSTS_VALU"]
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
