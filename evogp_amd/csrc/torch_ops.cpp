@@ -12,7 +12,7 @@
 // Host code only (no kernels): compiled with g++ against the torch headers and linked to libevogp_hip.so.  There is no CPU
 // implementation and no fallback: a CPU tensor fails in the dispatcher exactly as with the reference.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -52,6 +52,8 @@ void check_rc(int rc, const char *what) {
     TORCH_CHECK(rc == 0, what, " failed: ", evogp_hip_error_string(rc), " (code ", rc, ")");
 }
 
+// torch's current stream of the device.  (ROCm builds of torch present their devices as DeviceType::CUDA; the generic
+// c10::DeviceGuard resolves to the registered implementation, and the stream pool is indexed by the device ordinal.)
 evogp_stream_t current_stream(const c10::Device &dev) { return (evogp_stream_t)c10::hip::getCurrentHIPStream(dev.index()).stream(); }
 
 Tensor3 empty_forest(int64_t rows, int64_t gp_len, const c10::Device &dev) {
@@ -85,7 +87,7 @@ Tensor3 generate_impl(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t
     check_tensor(const_samples, {const_samples_len}, "const_samples", dev, at::kFloat);
     if (active_word) check_tensor(*active_word, {pop_size}, "active_word", dev, at::kInt);
     const Tensor keys = keys_u32(keys_in);
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(pop_size, gp_len, dev);
     const int rc = evogp_hip_generate_masked(
         (unsigned)pop_size, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len, (unsigned)const_samples_len, (float)out_prob,
@@ -112,7 +114,7 @@ Tensor3 tree_mutate(int64_t pop_size, int64_t gp_len, const Tensor &value_ori, c
     check_forest(pop_size, gp_len, value_ori, type_ori, size_ori, dev, "_ori");
     check_tensor(mutate_indices, {pop_size}, "mutateIndices", dev, at::kInt);
     check_forest(pop_size, gp_len, value_new, type_new, size_new, dev, "_new");
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(pop_size, gp_len, dev);
     const int rc = evogp_hip_mutate((int)pop_size, (int)gp_len, value_ori.data_ptr<float>(), type_ori.data_ptr<int16_t>(),
                                     size_ori.data_ptr<int16_t>(), mutate_indices.data_ptr<int>(), value_new.data_ptr<float>(),
@@ -134,7 +136,7 @@ Tensor3 tree_crossover(int64_t pop_size_ori, int64_t pop_size_new, int64_t gp_le
     check_tensor(right_idx, {pop_size_new}, "right_idx", dev, at::kInt);
     check_tensor(left_node_idx, {pop_size_new}, "left_node_idx", dev, at::kInt);
     check_tensor(right_node_idx, {pop_size_new}, "right_node_idx", dev, at::kInt);
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(pop_size_new, gp_len, dev);
     const int rc = evogp_hip_crossover((int)pop_size_ori, (int)pop_size_new, (int)gp_len, value_ori.data_ptr<float>(),
                                        type_ori.data_ptr<int16_t>(), size_ori.data_ptr<int16_t>(), left_idx.data_ptr<int>(),
@@ -153,7 +155,7 @@ Tensor tree_evaluate(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t 
     const c10::Device dev = value.device();
     check_forest(pop_size, gp_len, value, type, size, dev);
     check_tensor(variables, {pop_size, var_len}, "variables", dev, at::kFloat);
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor results = at::empty({pop_size, out_len}, value.options());
     const int rc = evogp_hip_evaluate((unsigned)pop_size, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len, value.data_ptr<float>(),
                                       type.data_ptr<int16_t>(), size.data_ptr<int16_t>(), variables.data_ptr<float>(),
@@ -174,7 +176,7 @@ Tensor tree_SR_fitness(int64_t pop_size, int64_t data_points, int64_t gp_len, in
     check_forest(pop_size, gp_len, value, type, size, dev);
     check_tensor(variables, {data_points, var_len}, "variables", dev, at::kFloat);
     check_tensor(labels, {data_points, out_len}, "labels", dev, at::kFloat);
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor fitness = at::empty({pop_size}, value.options());
     const int rc = evogp_hip_sr_fitness((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len,
                                         use_mse ? 1 : 0, value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(),
@@ -208,7 +210,7 @@ Tensor tree_batch_evaluate(int64_t pop_size, int64_t data_points, int64_t gp_len
     const c10::Device dev = value.device();
     check_forest(pop_size, gp_len, value, type, size, dev);
     check_tensor(variables, {data_points, var_len}, "variables", dev, at::kFloat);
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor results = at::empty({pop_size, data_points, out_len}, value.options());
     const int rc = evogp_hip_batch_evaluate((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len,
                                             (unsigned)out_len, value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(),
@@ -227,7 +229,7 @@ Tensor tree_batch_argmax_count(int64_t pop_size, int64_t data_points, int64_t gp
     check_forest(pop_size, gp_len, value, type, size, dev);
     check_tensor(variables, {data_points, var_len}, "variables", dev, at::kFloat);
     check_tensor(labels, {data_points}, "labels", dev, at::kInt);
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor counts = at::empty({pop_size}, at::TensorOptions().dtype(at::kInt).device(dev));
     const int rc = evogp_hip_batch_argmax_count((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len,
                                                 (unsigned)out_len, value.data_ptr<float>(), type.data_ptr<int16_t>(),
@@ -257,7 +259,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> breed_default(int64_t pop_size, int64
     check_order(order, std::max(n_elite, n_surv), dev);
     check_tensor(rnd, {6, n_new}, "rnd", dev, at::kInt);
     check_forest(n_new, gp_len, donor_value, donor_type, donor_size, dev, " (donor)");
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(pop_size, gp_len, dev);
     Tensor dec = at::empty({want_decisions ? n_new : 0, 6}, at::TensorOptions().dtype(at::kInt).device(dev));
     const int rc = evogp_hip_breed_default((int)pop_size, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(),
@@ -293,7 +295,7 @@ Tensor3 breed_default_rows(int64_t pop_size, int64_t gp_len, int64_t n_elite, in
                 " rows, but got ", drows);
     check_forest(drows, gp_len, donor_value, donor_type, donor_size, dev, " (donor)");
     const int64_t skip = drows == row_count - head ? head : 0;  // the engine indexes donors by (row - row_begin)
-    c10::hip::HIPGuard guard(dev);
+    c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(row_count, gp_len, dev);
     const int rc = evogp_hip_breed_default_table(
         (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),

@@ -248,18 +248,39 @@ void evogp_oracle_crossover(int pop_size_ori, int pop_size_new, int gp_len, cons
     }
 }
 
+/* ---- sensitivity probe (TESTS ONLY, not reference semantics) -------------------------------
+ * Two correct fp32 math libraries differ by an ulp or two per call, and a tree can amplify that without bound
+ * (tan(tan(x)), a / (sin(x) - sin(x))).  With jitter enabled every libm-backed result (sin cos tan sinh cosh tanh log
+ * exp pow) is moved by a pseudo-random number of ulps in [-J, +J]; the spread of a tree's fitness over a few seeds is
+ * the tolerance a parity test may grant THAT tree (tests/test_gpu_parity.py), instead of a blanket "98 % of the trees". */
+static int g_jitter_ulps = 0;
+static uint32_t g_jitter_seed = 0;
+static __thread uint32_t t_jitter_state = 0;
+void evogp_oracle_set_jitter(int ulps, unsigned seed) { g_jitter_ulps = ulps < 0 ? 0 : ulps; g_jitter_seed = seed; }
+static inline void jitter_begin(long tree) { t_jitter_state = g_jitter_seed ^ ((uint32_t)tree * 2654435761u); }
+static inline float jit(float r) {
+    if (g_jitter_ulps == 0 || !isfinite(r) || r == 0.0f) return r;
+    t_jitter_state = t_jitter_state * 1664525u + 1013904223u;
+    const int k = (int)((t_jitter_state >> 8) % (uint32_t)(2 * g_jitter_ulps + 1)) - g_jitter_ulps;
+    uint32_t b = float_to_bits(r);
+    const uint32_t mag = (b & 0x7FFFFFFFu) + (uint32_t)k; /* sign-magnitude: +k ulps away from zero */
+    if (mag == 0u || mag >= 0x7F800000u) return r;
+    b = (b & 0x80000000u) | mag;
+    return bits_to_float(b);
+}
+
 /* ---- interpreter: forward.cu:79-244 (node), :246-302 (tree) ------------------------------ */
 static inline float apply_unary(unsigned f, float a) {
     switch (f) {
-    case F_SIN: return sinf(a);
-    case F_COS: return cosf(a);
-    case F_TAN: return tanf(a);
-    case F_SINH: return sinhf(a);
-    case F_COSH: return coshf(a);
-    case F_TANH: return tanhf(a);
-    case F_LOG: return logf(a);
-    case F_LOOSE_LOG: return a == 0.0f ? -MAXVAL_F : logf(fabsf(a));
-    case F_EXP: return expf(a);
+    case F_SIN: return jit(sinf(a));
+    case F_COS: return jit(cosf(a));
+    case F_TAN: return jit(tanf(a));
+    case F_SINH: return jit(sinhf(a));
+    case F_COSH: return jit(coshf(a));
+    case F_TANH: return jit(tanhf(a));
+    case F_LOG: return jit(logf(a));
+    case F_LOOSE_LOG: return a == 0.0f ? -MAXVAL_F : jit(logf(fabsf(a)));
+    case F_EXP: return jit(expf(a));
     case F_INV: return a == 0.0f ? NAN : 1.0f / a;
     case F_LOOSE_INV: if (fabsf(a) <= DELTA_F) a = copysignf(DELTA_F, a); return 1.0f / a;
     case F_NEG: return -a;
@@ -276,8 +297,8 @@ static inline float apply_binary(unsigned f, float a, float b) {
     case F_MUL: return a * b;
     case F_DIV: return b == 0.0f ? NAN : a / b;
     case F_LOOSE_DIV: if (fabsf(b) <= DELTA_F) b = copysignf(DELTA_F, b); return a / b;
-    case F_POW: return powf(a, b);
-    case F_LOOSE_POW: return (a == 0.0f && b == 0.0f) ? 0.0f : powf(fabsf(a), b);
+    case F_POW: return jit(powf(a, b));
+    case F_LOOSE_POW: return (a == 0.0f && b == 0.0f) ? 0.0f : jit(powf(fabsf(a), b));
     case F_MAX: return a >= b ? a : b;
     case F_MIN: return a <= b ? a : b;
     case F_LT: return a < b ? 1.0f : -1.0f;
@@ -348,6 +369,7 @@ void evogp_oracle_evaluate(unsigned pop_size, unsigned gp_len, unsigned var_len,
 #pragma omp for schedule(static)
         for (long n = 0; n < (long)pop_size; ++n) {
             const size_t off = (size_t)n * gp_len;
+            jitter_begin(n);
             eval_tree(value + off, type + off, live_len(size + off, gp_len), variables + (size_t)n * var_len,
                       out_len, outs, stack);
             for (unsigned o = 0; o < out_len; ++o) results[(size_t)n * out_len + o] = outs[o];
@@ -367,6 +389,7 @@ void evogp_oracle_batch_evaluate(unsigned pop_size, unsigned data_points, unsign
         for (long n = 0; n < (long)pop_size; ++n) {
             const size_t off = (size_t)n * gp_len;
             const int len = live_len(size + off, gp_len);
+            jitter_begin(n);
             for (unsigned d = 0; d < data_points; ++d) {
                 eval_tree(value + off, type + off, len, variables + (size_t)d * var_len, out_len, outs, stack);
                 for (unsigned o = 0; o < out_len; ++o)
@@ -398,6 +421,7 @@ int evogp_oracle_sr_fitness(unsigned pop_size, unsigned data_points, unsigned gp
             const size_t off = (size_t)n * gp_len;
             const int len = live_len(size + off, gp_len);
             float total = 0.0f;
+            jitter_begin(n);
             for (unsigned base = 0; base < data_points; base += BLOCK) {
                 for (unsigned l = 0; l < BLOCK; ++l) {
                     const unsigned d = base + l;

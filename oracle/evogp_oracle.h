@@ -67,6 +67,10 @@ void evogp_oracle_batch_evaluate(unsigned pop_size, unsigned data_points, unsign
  * src/evogp/tree/tree.py:361-413. */
 int evogp_oracle_validate_tree(int gp_len, const int16_t *type, const int16_t *size);
 
+/* Sensitivity probe for parity tests (NOT reference semantics; 0 = off, the default): every libm-backed function result of the
+ * evaluation entry points is moved by a pseudo-random number of ulps in [-ulps, +ulps] (seeded per tree from `seed`). */
+void evogp_oracle_set_jitter(int ulps, unsigned seed);
+
 #ifdef __cplusplus
 }
 #endif

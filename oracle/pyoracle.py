@@ -153,6 +153,11 @@ class Oracle:
                                    pv, pt, ps, pX, res.ctypes.data_as(C.c_void_p))
         return res
 
+    def set_jitter(self, ulps: int, seed: int = 0) -> None:
+        """Sensitivity probe (evogp_oracle.h): libm-backed results are moved by up to +-ulps; 0 switches it off."""
+        assert self.kind == "port"
+        self._fn("set_jitter")(C.c_int(ulps), C.c_uint(seed))
+
     def validate_tree(self, type_row, size_row) -> int:
         assert self.kind == "port"
         t, pt = _p(type_row, _i16); s, ps = _p(size_row, _i16)

@@ -55,7 +55,7 @@ def test_argument_errors_are_runtime_errors(torch_mod):
     keys, d2l, rou, cs = _desc_tensors(torch)
     with pytest.raises(RuntimeError, match="gp_len must be in range"):
         torch.ops.evogp_cuda.tree_generate(2, 2000, 2, 1, 3, 0.3, 0.5, keys, d2l, rou, cs)
-    with pytest.raises(RuntimeError, match="pop_size must larger than 0"):
+    with pytest.raises(RuntimeError, match="pop_size must be larger than 0"):
         torch.ops.evogp_cuda.tree_generate(0, 64, 2, 1, 3, 0.3, 0.5, keys, d2l, rou, cs)
     with pytest.raises(RuntimeError, match="roulette_funcs must have shape"):
         torch.ops.evogp_cuda.tree_generate(2, 64, 2, 1, 3, 0.3, 0.5, keys, d2l, rou[:24].contiguous(), cs)

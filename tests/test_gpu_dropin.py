@@ -56,7 +56,6 @@ def test_ops_are_registered_from_cpp_not_python():
     assert "libevogp_torch.so" in loaded
     # a C++ kernel registration has no Python function behind the dispatch key
     assert torch._C._dispatch_has_kernel_for_dispatch_key("evogp_cuda::tree_SR_fitness", "CUDA")
-    assert not torch._C._dispatch_has_kernel_for_dispatch_key("evogp_cuda::tree_SR_fitness", "CPU") or True
 
 
 def test_binding_rejects_bad_arguments_like_the_reference_wrapper():
@@ -75,8 +74,8 @@ def test_binding_rejects_bad_arguments_like_the_reference_wrapper():
         torch.ops.evogp_cuda.tree_evaluate(4, 8, 2, 1, v, t, s, torch.zeros(2, 4, device=dev).t())
     with pytest.raises(RuntimeError, match="kernel_type"):
         torch.ops.evogp_cuda.tree_SR_fitness(4, 4, 8, 2, 1, True, v, t, s, torch.zeros(4, 2, device=dev), torch.zeros(4, 1, device=dev), 7)
-    with pytest.raises((RuntimeError, NotImplementedError)):   # no CPU implementation, no fallback
-        torch.ops.evogp_cuda.tree_evaluate(4, 8, 2, 1, v.cpu(), t.cpu(), s.cpu(), x.cpu())
+    # (that CPU tensors are rejected -- no CPU implementation, no fallback -- is checked in a fresh interpreter by
+    # tests/test_capi.py: other test modules register the TEST-ONLY oracle-backed CPU ops in this process)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
