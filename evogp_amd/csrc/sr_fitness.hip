@@ -97,29 +97,60 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     };
     if (single) load_tile(w < p.ntiles ? w : 0);
 
-    if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)batch);
+    // Two ways to get a batch.  A full pass pulls batches of consecutive trees from the global counter.  A pass behind
+    // another kernel (only_marked) looks for the few trees that kernel marked: a global batch counter would cost one
+    // same-address atomic per 64 UNMARKED trees (~11 ns each, serialised over the chip: 0.2 ms per million trees) --
+    // instead every workgroup owns a contiguous chunk of the population, reads its mark words coalesced, collects the
+    // hits in an LDS queue and works the queue off in batches.  No global atomics, no counter.
+    const bool marked = p.only_marked != 0;
+    constexpr int SCAN = 4;  // mark words per thread and scan step
+    __shared__ int q_s[kMaxBatch + SCAN * MAXW * 64];
+    __shared__ int tid_s[2][kMaxBatch];
+    __shared__ int qn_s;
+    int scan = 0, scan_end = 0;
+    if (marked) {
+        const int chunk = ((p.pop + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;
+        scan = (int)blockIdx.x * chunk < p.pop ? (int)blockIdx.x * chunk : p.pop;
+        scan_end = scan + chunk < p.pop ? scan + chunk : p.pop;
+        if (threadIdx.x == 0) qn_s = 0;
+    } else if (threadIdx.x == 0) next_s[0] = (int)atomicAdd(p.counter, (unsigned)batch);
     __syncthreads();
     int par = 0;
     for (;;) {
-        const int t0 = uni(next_s[par]);
-        if (t0 >= p.pop) break;
-        const int nb = p.pop - t0 < batch ? p.pop - t0 : batch;
-        if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)batch); // prefetch
-
-        // ---- phase 1: classify the batch, trees split between the waves ----
-        if (p.only_marked) {
-            // behind another kernel: wave 0 reads the mark words of the whole batch at once (one tree per lane); only the
-            // marked trees are classified below -- a wave that walks the marks one dependent load at a time spends
-            // ~1 us per UNMARKED tree
-            if (w == 0 && lane < nb) {
-                const float *mark = STORE ? p.results + (size_t)(t0 + lane) * p.D * p.out_len : p.fitness + (t0 + lane);
-                cls_s[par][lane] = f2bits(*mark) == kSentinelHeavy ? TREE_OK : TREE_SKIP;
+        int t0 = 0, nb = 0;
+        if (!marked) {
+            t0 = uni(next_s[par]);
+            if (t0 >= p.pop) break;
+            nb = p.pop - t0 < batch ? p.pop - t0 : batch;
+            if (threadIdx.x == 0) next_s[par ^ 1] = (int)atomicAdd(p.counter, (unsigned)batch); // prefetch
+        } else {
+            int qn;
+            for (;;) {
+                qn = uni(qn_s);
+                __syncthreads();  // everybody has read the count before anybody adds to it
+                if (qn >= batch || scan >= scan_end) break;
+#pragma unroll
+                for (int j = 0; j < SCAN; ++j) {
+                    const int t = scan + j * (int)blockDim.x + (int)threadIdx.x;
+                    if (t < scan_end) {
+                        const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
+                        if (f2bits(*mark) == kSentinelHeavy) q_s[atomicAdd(&qn_s, 1)] = t;
+                    }
+                }
+                scan += SCAN * (int)blockDim.x;
+                __syncthreads();
             }
+            if (qn == 0) break;  // chunk exhausted, queue empty
+            nb = qn < batch ? qn : batch;
+            if ((int)threadIdx.x < nb) tid_s[par][threadIdx.x] = q_s[qn - nb + (int)threadIdx.x];  // the tail of the queue
+            if (threadIdx.x == 0) qn_s = qn - nb;
             __syncthreads();
         }
+        auto tree_of = [&](int b) -> int { return marked ? tid_s[par][b] : t0 + b; };
+
+        // ---- phase 1: classify the batch, trees split between the waves ----
         for (int b = w; b < nb; b += W) {
-            if (p.only_marked && uni(cls_s[par][b]) == TREE_SKIP) continue;
-            const size_t row = (size_t)(t0 + b) * p.gp_len;
+            const size_t row = (size_t)uni(tree_of(b)) * p.gp_len;
             int len = uni((int)p.size[row]);
             len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
             const int c = classify_tree(p.type + row, p.value + row, len, MO, p.var_len, p.out_len, DEPTH, LEAN ? 1 : 0);
@@ -130,6 +161,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
         // ---- phase 2: every wave interprets every tree of the batch on its own rows ----
         for (int b = 0; b < nb; ++b) {
             const int cls_b = uni(cls_s[par][b]);
+            const int tb = uni(tree_of(b));
             if (cls_b != TREE_OK) {
                 if (STORE && cls_b == TREE_BAD) { // malformed tree: the whole result row is NaN
                     for (int tile = w; tile < p.ntiles; tile += W)
@@ -138,12 +170,12 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
                             const int dd = tile * TILE + k * kWave + lane;
                             if (dd < p.D)
                                 for (int o = 0; o < p.out_len; ++o)
-                                    p.results[((size_t)(t0 + b) * p.D + dd) * p.out_len + o] = __builtin_nanf("");
+                                    p.results[((size_t)tb * p.D + dd) * p.out_len + o] = __builtin_nanf("");
                         }
                 }
                 continue;
             }
-            const size_t row = (size_t)(t0 + b) * p.gp_len;
+            const size_t row = (size_t)tb * p.gp_len;
             const float *tv = p.value + row;
             const int16_t *tt = p.type + row;
             int len = uni((int)p.size[row]);
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         if (d[k] < p.D) {
-                            float *rr = p.results + ((size_t)(t0 + b) * p.D + d[k]) * p.out_len;
+                            float *rr = p.results + ((size_t)tb * p.D + d[k]) * p.out_len;
                             if (!MO) rr[0] = st.tos[k];
                             else {
 #pragma unroll
@@ -221,9 +253,9 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
             if ((int)threadIdx.x < nb) {
                 const int c = cls_s[par][threadIdx.x];
                 if (c == TREE_DEEP || c == TREE_HEAVY)
-                    p.results[(size_t)(t0 + threadIdx.x) * p.D * p.out_len] = bits2f(c == TREE_DEEP ? kSentinelDeep : kSentinelHeavy);
+                    p.results[(size_t)tree_of(threadIdx.x) * p.D * p.out_len] = bits2f(c == TREE_DEEP ? kSentinelDeep : kSentinelHeavy);
             }
-        } else if ((int)threadIdx.x < nb && cls_s[par][threadIdx.x] != TREE_SKIP) {
+        } else if ((int)threadIdx.x < nb) {
             const int b = threadIdx.x;
             const int c = cls_s[par][b];
             float f;
@@ -235,7 +267,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
             } else {
                 f = c == TREE_DEEP ? bits2f(kSentinelDeep) : c == TREE_HEAVY ? bits2f(kSentinelHeavy) : __builtin_nanf("");
             }
-            p.fitness[t0 + b] = f;
+            p.fitness[tree_of(b)] = f;
         }
         par ^= 1;
     }
@@ -250,9 +282,7 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
     if (only_marked && p.marks && uni((int)p.marks[1]) == 0) return;  // no tree needs the general path
     float stk[kMaxStack + 2];
     float outs[MO ? kGeneralOuts : 1];
-    for (int t = blockIdx.x; t < p.pop; t += gridDim.x) {
-        const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
-        if (only_marked && uni(f2bits(*mark)) != kSentinelDeep) continue;
+    auto process = [&](int t) {
         const size_t row = (size_t)t * p.gp_len;
         const float *tv = p.value + row;
         const int16_t *tt = p.type + row;
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
         const int cls = uni(classify_tree(tt, tv, len, MO, p.var_len, p.out_len, kMaxStack));
         if (cls != TREE_OK && !STORE) {
             if (lane == 0) p.fitness[t] = __builtin_nanf("");
-            continue;
+            return;
         }
         float acc = 0.0f;
         for (int base = 0; base < p.D; base += kWave) {
@@ -290,6 +320,29 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
         if (!STORE) {
             const float total = wave_sum(acc);
             if (lane == 0) p.fitness[t] = total / (float)p.D;
+        }
+    };
+    if (!only_marked) {
+        for (int t = blockIdx.x; t < p.pop; t += gridDim.x) process(t);
+        return;
+    }
+    // behind the register kernels: every workgroup (one wave) owns a contiguous chunk of the population and reads its
+    // mark words 64 at a time -- walking the population one dependent load per tree costs ~1 us per UNMARKED tree
+    const int chunk = ((p.pop + (int)gridDim.x - 1) / (int)gridDim.x + 63) & ~63;
+    const int c0 = (int)blockIdx.x * chunk < p.pop ? (int)blockIdx.x * chunk : p.pop;
+    const int c1 = c0 + chunk < p.pop ? c0 + chunk : p.pop;
+    for (int base = c0; base < c1; base += kWave) {
+        const int t = base + lane;
+        bool hit = false;
+        if (t < c1) {
+            const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
+            hit = f2bits(*mark) == kSentinelDeep;
+        }
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            process(base + b);
         }
     }
 }
