@@ -56,8 +56,10 @@ FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the FULL register kernel"
 OPS = ("add", "sub", "mul", "div")
 UNARY = ("neg", "abs", "sin", "cos", "tan", "sqrt", "lsqrt", "exp", "log", "llog")  # unary handlers, in the compiler kernel's numbering (sr_tc.hip)
+GBIN = ("ldiv", "max", "min", "lt", "gt", "le", "ge")  # bodies behind the generic binary stubs, selected by the word's aux field
+GUN = ("zero",)                                        # bodies behind the generic unary stubs
 SLOT = 256  # bytes per handler slot
-NHF = 37 + 2 * len(UNARY)  # handlers per flavour
+NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
@@ -129,7 +131,11 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     for u, uop in enumerate(UNARY):
         hid[f"{uop}_S"], hid[f"{uop}_V"] = 36 + 2 * u, 37 + 2 * u
     hid["next"] = 36 + 2 * len(UNARY)
-    assert NHF == 37 + 2 * len(UNARY)
+    nh = hid["next"] + 1
+    for f, form in enumerate(FORMS):
+        hid[f"gbin_{form}"] = nh + f
+    hid["gun_S"], hid["gun_V"], hid["if_sss"], hid["acc_s"], hid["mo_begin"], hid["end_mo"] = (nh + 8 + i for i in range(6))
+    assert NHF == nh + 14
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -158,10 +164,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
 
     def entry():
         """common head of a handler: address of the next handler and LDS offset of the next instruction's variable"""
-        a(f"s_movrels_b32 s{sX}, s{W + 2}")                  # next word: {LDS offset / 16 of its variable, handler offset}
+        a(f"s_movrels_b32 s{sX}, s{W + 2}")                  # next word: {LDS offset / 1024 of its variable, aux, handler offset}
         a(f"s_pack_lh_b32_b16 s{sPC}, s{sX}, {BASE}")        # handler table is 64 KiB aligned: address = {base.hi16, offset}
-        a(f"s_lshr_b32 {PF}, s{sX}, 12")
-        a(f"s_andn2_b32 {PF}, {PF}, 15")
+        a(f"s_lshr_b32 {PF}, s{sX}, 24")
+        a(f"s_lshl_b32 {PF}, {PF}, 10")
+
+    def read_aux(dst):
+        """aux field (bits 23:16) of the CURRENT instruction's word; M0 must still be J (i.e. before any m0_stack)"""
+        a(f"s_movrels_b32 s{dst}, s{W}")
+        a(f"s_bfe_u32 s{dst}, s{dst}, 0x80010")
 
     def prefetch(nxt):
         if NOPF:  # timing experiment only: wrong results
@@ -338,8 +349,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_mov_b32 s{sH}, 0")
     a(f"s_mov_b32 s{sJ}, 0")
     a(f"{lab('tile_go')}:")
-    a(f"s_lshr_b32 {PF}, s{W}, 12")                # variable operand of the first instruction -> bank 0
-    a(f"s_andn2_b32 {PF}, {PF}, 15")
+    a(f"s_lshr_b32 {PF}, s{W}, 24")                # variable operand of the first instruction -> bank 0
+    a(f"s_lshl_b32 {PF}, {PF}, 10")
     a(f"v_add_u32 v4, {PF}, v2")
     read_bank(P[0], 4)
     a(f"s_set_gpr_idx_on s{sJ}, 0")  # J == 0: enables indexing with no operand selected, M0 = 0
@@ -617,12 +628,117 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         # (sREC now points at the overflow block: the tile loop sees that and reloads the first block for the next pass)
         a("s_waitcnt lgkmcnt(0)")
         a(f"s_pack_lh_b32_b16 s{sPC}, s{W}, {BASE}")
-        a(f"s_lshr_b32 {PF}, s{W}, 12")
-        a(f"s_andn2_b32 {PF}, {PF}, 15")
+        a(f"s_lshr_b32 {PF}, s{W}, 24")
+        a(f"s_lshl_b32 {PF}, {PF}, 10")
         prefetch(nxt)
         a(f"s_mov_b32 s{sJ}, 0")
         a(f"s_mov_b32 m0, s{sJ}")
         a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
+        # ---- generic binary stubs: a -> T bank, b -> Q bank (whatever the form), result slot in sDST, then the body the
+        # word's aux field names (max min < > <= >= loose-div ...: functions too rare or too long for one handler per form)
+        for form in FORMS:
+            begin(f"gbin_{form}", fl)
+            entry()
+            read_aux(T2)
+            la, rb = form[0], form[1]
+            if la == "C" or rb == "C" or form == "VV":
+                a(f"s_movrels_b32 s{sA}, s{W + 1}")           # the word's one 32-bit operand: constant, or second variable
+            if form == "VV":
+                a(f"v_lshl_add_u32 v5, s{sA}, 4, v2")
+                read_bank(Q, 5)
+            prefetch(nxt)
+            wait_cur()  # bodies may use the current operand bank as scratch: its prefetch must have landed
+            if form == "SS":
+                m0_stack(MODE["SRC0"], -2 * K)
+                for k in range(K):
+                    a(f"v_mov_b32 v{T + k}, v{S0 + K + k}")
+                    a(f"v_mov_b32 v{Q + k}, v{S0 + k}")
+                a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - 2 * K)}")
+                a(f"s_sub_u32 s{sH}, s{sH}, {K}")
+            elif la == "S" or rb == "S":
+                m0_stack(MODE["SRC0"], -K)
+                bank = T if la == "S" else Q
+                for k in range(K):
+                    a(f"v_mov_b32 v{bank + k}, v{S0 + k}")
+                a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
+            else:
+                a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
+                a(f"s_add_u32 s{sH}, s{sH}, {K}")
+            a("s_mov_b32 m0, 0")
+            for k in range(K):
+                if la == "V":
+                    a(f"v_mov_b32 v{T + k}, v{cur + k}")
+                elif la == "C":
+                    a(f"v_mov_b32 v{T + k}, s{sA}")
+                if rb == "V" and form != "VV":
+                    a(f"v_mov_b32 v{Q + k}, v{cur + k}")
+                elif rb == "C":
+                    a(f"v_mov_b32 v{Q + k}, s{sA}")
+            a(f"s_branch {lab('gbin_dispatch')}")
+        # ---- generic unary stubs: operand -> T bank, result slot in sDST, body named by aux
+        begin("gun_S", fl)
+        entry()
+        read_aux(T2)
+        prefetch(nxt)
+        m0_stack(MODE["SRC0"], -K)
+        for k in range(K):
+            a(f"v_mov_b32 v{T + k}, v{S0 + k}")
+        a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
+        a("s_mov_b32 m0, 0")
+        a(f"s_branch {lab('gun_dispatch')}")
+        begin("gun_V", fl)
+        entry()
+        read_aux(T2)
+        prefetch(nxt)
+        wait_cur()
+        for k in range(K):
+            a(f"v_mov_b32 v{T + k}, v{cur + k}")
+        a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
+        a(f"s_add_u32 s{sH}, s{sH}, {K}")
+        a(f"s_branch {lab('gun_dispatch')}")
+        # ---- IF (forward.cu:213-224): a > 0 ? b : c with all three operands on the stack (a on top); leaf operands are
+        # pushed by the compiler, this function is too rare for 26 fused forms
+        begin("if_sss", fl)
+        entry()
+        prefetch(nxt)
+        m0_stack(MODE["SRC0"] | MODE["SRC1"] | MODE["DST"], -3 * K)
+        for k in range(K):
+            a(f"v_cmp_lt_f32 vcc, 0, v{S0 + 2 * K + k}")
+            a(f"v_cndmask_b32 v{S0 + k}, v{S0 + k}, v{S0 + K + k}, vcc")
+        a(f"s_sub_u32 s{sH}, s{sH}, {2 * K}")
+        epilogue()
+        # ---- multi-output programs (forward.cu:237-243).  The first out_len entries of the operand stack are the output
+        # accumulators; mo_begin (aux = K * out_len) clears them and starts the stack above them, acc_s (aux = K * output
+        # index) adds the top of the stack to one of them, end_mo folds this tile's errors of all outputs.
+        begin("acc_s", fl)
+        entry()
+        read_aux(T2)
+        prefetch(nxt)
+        m0_stack(MODE["SRC0"], -K)
+        for k in range(K):
+            a(f"v_mov_b32 v{T + k}, v{S0 + k}")
+        a(f"s_add_u32 m0, s{T2}, {hex((MODE['SRC0'] | MODE['DST']) << 12)}")
+        for k in range(K):
+            a(f"v_add_f32 v{S0 + k}, v{S0 + k}, v{T + k}")
+        a(f"s_sub_u32 s{sH}, s{sH}, {K}")
+        epilogue()
+        begin("mo_begin", fl)
+        entry()
+        read_aux(T2)
+        prefetch(nxt)
+        a(f"s_mov_b32 s{T1}, 0")
+        a(f"{lab(f'mobegin_loop{fl}')}:")
+        a(f"s_add_u32 m0, s{T1}, {hex(MODE['DST'] << 12)}")
+        for k in range(K):
+            a(f"v_mov_b32 v{S0 + k}, 0")
+        a(f"s_add_u32 s{T1}, s{T1}, {K}")
+        a(f"s_cmp_lt_u32 s{T1}, s{T2}")
+        a(f"s_cbranch_scc1 {lab(f'mobegin_loop{fl}')}")
+        a(f"s_mov_b32 s{sH}, s{T2}")
+        epilogue()
+        begin("end_mo", fl)
+        read_aux(T2)
+        a(f"s_branch {lab('endmo_body')}")
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # shared division bodies: K rows, then the scatter through v_div_fixup with an indexed destination
@@ -652,6 +768,71 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 for k in range(K):
                     a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
                 epilogue()
+
+    # ---- bodies behind the generic stubs.  Binary: a in T, b in Q, result left in T; unary: operand in T, result in Q.
+    a(f"{lab('gbin_dispatch')}:")
+    a(f"s_lshl_b32 s{T2}, s{T2}, 2")
+    a(f"s_getpc_b64 s[{sA}:{sA + 1}]")
+    a(f"{lab('gbin_pc')}:")
+    a(f"s_add_u32 s{sA}, s{sA}, s{T2}")
+    a(f"s_addc_u32 s{sA + 1}, s{sA + 1}, 0")
+    a(f"s_add_u32 s{sA}, s{sA}, {lab('gbin_table')}-{lab('gbin_pc')}")
+    a(f"s_addc_u32 s{sA + 1}, s{sA + 1}, 0")
+    a(f"s_setpc_b64 s[{sA}:{sA + 1}]")
+    a(f"{lab('gbin_table')}:")
+    for body in GBIN:
+        a(f"s_branch {lab('gbody_' + body)}")
+    a(f"{lab('gun_dispatch')}:")
+    a(f"s_lshl_b32 s{T2}, s{T2}, 2")
+    a(f"s_getpc_b64 s[{sA}:{sA + 1}]")
+    a(f"{lab('gun_pc')}:")
+    a(f"s_add_u32 s{sA}, s{sA}, s{T2}")
+    a(f"s_addc_u32 s{sA + 1}, s{sA + 1}, 0")
+    a(f"s_add_u32 s{sA}, s{sA}, {lab('gun_table')}-{lab('gun_pc')}")
+    a(f"s_addc_u32 s{sA + 1}, s{sA + 1}, 0")
+    a(f"s_setpc_b64 s[{sA}:{sA + 1}]")
+    a(f"{lab('gun_table')}:")
+    for body in GUN:
+        a(f"s_branch {lab('ubody_' + body)}")
+    for body in GBIN:
+        a(f"{lab('gbody_' + body)}:")
+        if body in ("max", "min"):      # forward.cu:201-204: a >= b ? a : b  /  a <= b ? a : b  (a NaN operand selects b)
+            cmp = {"max": "ge", "min": "le"}[body]
+            for k in range(K):
+                a(f"v_cmp_{cmp}_f32 vcc, v{T + k}, v{Q + k}")
+                a(f"v_cndmask_b32 v{T + k}, v{Q + k}, v{T + k}, vcc")
+        elif body in ("lt", "gt", "le", "ge"):   # forward.cu:205-212: 1 or -1
+            for k in range(K):
+                a(f"v_cmp_{body}_f32 vcc, v{T + k}, v{Q + k}")
+                a(f"v_cndmask_b32_e64 v{T + k}, -1.0, 1.0, vcc")
+        elif body == "ldiv":            # forward.cu:188-192: |b| <= DELTA -> b = copysign(DELTA, b); a / b (never a zero divisor)
+            a(f"s_mov_b32 s{T1}, 0x3089705f")        # DELTA = 1e-9f
+            a(f"s_brev_b32 s{T2}, -2")               # 0x7fffffff
+            a(f"v_mov_b32 v9, s{T1}")
+            for k in range(K):
+                a(f"v_cmp_le_f32_e64 vcc, |v{Q + k}|, s{T1}")
+                a(f"v_bfi_b32 v5, s{T2}, v9, v{Q + k}")
+                a(f"v_cndmask_b32 v{Q + k}, v{Q + k}, v5, vcc")
+            for k in range(K):
+                div_rows([T + k], [Q + k], [4], nanfix=False)
+                a(f"v_div_fixup_f32 v{T + k}, v4, v{Q + k}, v{T + k}")
+        a(f"s_branch {lab('gbin_tail')}")
+    a(f"{lab('gbin_tail')}:")
+    a(f"s_mov_b32 m0, s{sDST}")
+    for k in range(K):
+        a(f"v_mov_b32 v{S0 + k}, v{T + k}")
+    epilogue()
+    for body in GUN:
+        a(f"{lab('ubody_' + body)}:")
+        if body == "zero":              # a unary node whose function id is unknown yields 0 (forward.cu:117)
+            for k in range(K):
+                a(f"v_mov_b32 v{Q + k}, 0")
+        a(f"s_branch {lab('gun_tail')}")
+    a(f"{lab('gun_tail')}:")
+    a(f"s_mov_b32 m0, s{sDST}")
+    for k in range(K):
+        a(f"v_mov_b32 v{S0 + k}, v{Q + k}")
+    epilogue()
 
     # ---- sin / cos / tan: the small-argument path of the device math library (|x| < 2^17), transcribed from the ISA that
     # hipcc emits for sinf / cosf / tanf (three-term Cody-Waite reduction by pi/2, the library's polynomials, quadrant
@@ -841,6 +1022,58 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"{lab('bail_done')}:")
     a("s_mov_b64 exec, -1")
     a(f"s_branch {lab('next_tree')}")
+
+    # end of a multi-output program: sum over the outputs of this tile's errors (forward.cu:383-390).  aux = K * out_len is
+    # in T2; the labels of output o sit out_len "variables" behind X in LDS (o * variable stride behind those of output 0).
+    a(f"{lab('endmo_body')}:")
+    a("s_waitcnt lgkmcnt(0)")
+    a(f"s_mul_i32 s{sA}, s15, {G * 1024}")           # LDS bytes between two variables / outputs
+    a(f"s_mov_b32 s{sX}, 0")                          # K * output index
+    a("v_mov_b32 v4, v3")                             # labels of output 0, this tile
+    a(f"s_add_u32 s{T1}, s{sTILE}, 1")
+    a(f"s_cmp_lt_u32 s{T1}, s15")
+    a(f"s_cselect_b32 s{T1}, 0, s17")                 # flag bit 1 (ragged) counts only on the last tile
+    a(f"s_and_b32 s{T1}, s{T1}, 2")
+    a(f"{lab('endmo_loop')}:")
+    read_bank(T, 4)
+    a(f"s_add_u32 m0, s{sX}, {hex(MODE['SRC0'] << 12)}")
+    for k in range(K):
+        a(f"v_mov_b32 v{Q + k}, v{S0 + k}")           # accumulator of this output
+    a("s_mov_b32 m0, 0")
+    a("s_waitcnt lgkmcnt(0)")
+    a(f"s_cmp_eq_u32 s{T1}, 0")
+    a(f"s_cbranch_scc1 {lab('endmo_full')}")
+    a(f"s_mul_i32 s{T4}, s{sTILE}, {256 * G}")        # ragged tile: rows >= D contribute nothing
+    a("v_lshlrev_b32 v5, 2, v0")
+    a(f"v_add_u32 v5, s{T4}, v5")
+    for k in range(K):
+        g, q = divmod(k, 4)
+        a(f"v_add_u32 v9, {g * 256 + q}, v5")
+        a(f"v_sub_f32 v{T + k}, v{T + k}, v{Q + k}")
+        a("v_cmp_gt_u32 vcc, s13, v9")
+        a(f"v_cndmask_b32 v{T + k}, 0, v{T + k}, vcc")  # a zero difference adds nothing, squared or not
+    a(f"s_branch {lab('endmo_sum')}")
+    a(f"{lab('endmo_full')}:")
+    for k in range(K):
+        a(f"v_sub_f32 v{T + k}, v{T + k}, v{Q + k}")
+    a(f"{lab('endmo_sum')}:")
+    a("s_bitcmp0_b32 s17, 0")
+    a(f"s_cbranch_scc1 {lab('endmo_abs')}")
+    for k in range(K):
+        a(f"v_mul_f32 v9, v{T + k}, v{T + k}")
+        a("v_add_f32 v6, v6, v9")
+    a(f"s_branch {lab('endmo_next')}")
+    a(f"{lab('endmo_abs')}:")
+    for k in range(K):
+        a(f"v_add_f32_e64 v6, v6, |v{T + k}|")
+    a(f"{lab('endmo_next')}:")
+    a(f"s_add_u32 s{sX}, s{sX}, {K}")
+    a(f"v_add_u32 v4, s{sA}, v4")
+    a(f"s_cmp_lt_u32 s{sX}, s{T2}")
+    a(f"s_cbranch_scc1 {lab('endmo_loop')}")
+    a("s_set_gpr_idx_off")
+    a(f"s_add_u32 s{T1}, s{sTILE}, 1")
+    a(f"s_branch {lab('end_acc')}")
 
     # end of the program: fold this tile's errors into the accumulator.  The labels of the tile were prefetched by the
     # last instruction of the program (the compiler gives END the LDS offset of y as its "variable"), so they sit in

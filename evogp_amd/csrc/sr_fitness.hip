@@ -449,7 +449,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         std::lock_guard<std::mutex> pl(g_prof_mu);
         g_prof.push_back(prof);
     };
-    if (!STORE && !mo && asm_depth == 3) {
+    if (!STORE && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
         p.stats = g_stats;
         e = launch_threaded_code(p, stream, &tc_done, &p.mark_sample);
@@ -457,7 +457,10 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
     }
     if (profiling) (void)hipEventRecord(prof.ev[2], stream);
-    if (tc_done) {
+    if (tc_done && mo) {  // multi-output trees the threaded code left marked: FULL register build, then the general kernel
+        if (p.D >= 128) e = p.var_len <= 16 ? launch_fast<2, 16, 16, true, 8, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<2, 16, 32, true, 8, STORE, false>(p, 1, stream, p.marks + 3);
+        else e = p.var_len <= 16 ? launch_fast<1, 32, 16, true, 16, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<1, 32, 32, true, 16, STORE, false>(p, 1, stream, p.marks + 3);
+    } else if (tc_done) {
         if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
         else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
         else if (p.var_len <= 16) e = launch_fast<4, 16, 16, false, 4, STORE, false>(p, 1, stream, p.marks + 3);

@@ -1,0 +1,169 @@
+"""GPU: the widened threaded-code fitness path against the CPU oracle.
+
+Round 1's threaded code took single-output trees of at most 64 nodes over + - * / and ten unary functions; everything else
+fell to the 3-6x slower register kernels.  These tests cover what `compile_general` (csrc/sr_tc.hip) and the new handlers add
+— trees of up to gp_len nodes (chained program blocks), loose division / inverse, max min, the four comparisons, IF, unknown
+unary ids, MULTI-OUTPUT trees (forward.cu:237-243) — always `evogp_hip_sr_fitness` through the C ABI against
+`oracle.sr_fitness` on the same inputs, 1e-5 relative on finite values and identical NaN / inf classes.
+
+Each test also reads the handler histogram of the compiled population (`evogp_hip_debug_tc_histogram`): the share of trees
+whose program is SKIP (left to the register kernels) must be small, so that a green result is the threaded code's result and
+not the fallback's."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ARITH, assert_close_classes, c2_dataset, depth2leaf, roulette_uniform
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = [-1.0, 0.0, 1.0, 0.5, 2.0]
+RTOL = 1e-5
+# function ids (defs.h:24-57)
+IF, ADD, SUB, MUL, DIV, LDIV, POW, LPOW, MAX, MIN, LT, GT, LE, GE = range(14)
+SIN, COS, TAN, SINH, COSH, TANH, LOG, LLOG, EXP, INV, LINV, NEG, ABS, SQRT, LSQRT = range(14, 29)
+EXACT_WIDE = [IF, ADD, SUB, MUL, DIV, LDIV, MAX, MIN, LT, GT, LE, GE, INV, LINV, NEG, ABS, SQRT, LSQRT]  # IEEE-exact on both sides
+
+
+@pytest.fixture(scope="module")
+def g():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import gpu_capi
+
+    return gpu_capi
+
+
+def handler_histogram(g, pop):
+    """{handler name: words} of the programs the last sr_fitness call compiled (both flavours added)"""
+    import torch
+
+    nh = g.L.evogp_hip_debug_tc_nhandlers()
+    hist = torch.zeros(2 * nh, dtype=torch.int64, device=g.DEV)
+    rc = g.L.evogp_hip_debug_tc_histogram(pop, ctypes.c_void_p(hist.data_ptr()), 2 * nh, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, g.L.evogp_hip_error_string(rc)
+    h = hist.cpu().numpy()
+    table = json.load(open(os.path.join(ROOT, "evogp_amd", "lib", "tc_handlers.json")))["K8_short"]["handlers"]
+    return {name: int(h[v["id"]] + h[nh + v["id"]]) for name, v in table.items()}
+
+
+def check(g, oracle, forest, X, y, what, max_skipped=0.02, mse=(True, False)):
+    pop = forest[0].shape[0]
+    for m in mse:
+        got = g.sr_fitness(*forest, X, y, m)
+        if m is mse[0]:
+            h = handler_histogram(g, pop)
+            assert h["skip"] <= max_skipped * pop, f"{what}: {h['skip']} of {pop} trees were left to the register kernels"
+        assert_close_classes(got, oracle.sr_fitness(*forest, X, y, m), RTOL, what=f"{what} mse={m}")
+    return h
+
+
+# ---- long trees: chained program blocks ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,mlc,funcs", [(128, 7, ARITH), (256, 8, ARITH), (256, 7, ARITH + [NEG, ABS, SQRT, INV]), (1024, 10, ARITH), (130, 7, ARITH)])
+def test_long_trees(g, oracle, rng, L, mlc, funcs):
+    assert 2 ** mlc - 1 <= L  # GenerateDescriptor's check_tree_length (descriptor.py:19-31): a full tree must fit the row
+    d2l = depth2leaf(mlc, 0.1)
+    forest = oracle.generate(3000, L, 6, 1, 0.5, 0.5, [L, mlc], d2l, roulette_uniform(funcs), CS)
+    sizes = forest[2][:, 0]
+    assert sizes.max() > 64, "the forest must contain trees beyond one 64-node chunk"
+    X = rng.uniform(-3, 3, (700, 6)).astype(np.float32); y = rng.uniform(-3, 3, (700, 1)).astype(np.float32)
+    # trees whose operand stack is deeper than the interpreter's register stack legitimately go to the register kernels
+    h = check(g, oracle, forest, X, y, f"L={L}", max_skipped=0.25)
+    assert h["next"] > 0, "no program needed a second block: the test does not exercise the chaining"
+
+
+def test_evolved_long_trees_after_crossover(g, oracle, rng):
+    """second-generation trees at the length cap (L = 128): crossover products, lengths up to exactly gp_len"""
+    L = 128
+    f0 = oracle.generate(4000, L, 5, 1, 0.5, 0.5, [9, 9], depth2leaf(7, 0.1), roulette_uniform(ARITH + [NEG]), CS)
+    sizes = f0[2][:, 0].astype(np.int64)
+    li = rng.integers(0, 4000, 4000).astype(np.int32); ri = rng.integers(0, 4000, 4000).astype(np.int32)
+    ln = (rng.integers(0, 2**31 - 1, 4000) % sizes[li]).astype(np.int32); rn = (rng.integers(0, 2**31 - 1, 4000) % sizes[ri]).astype(np.int32)
+    f1 = oracle.crossover(*f0, li, ri, ln, rn)
+    X = rng.uniform(-3, 3, (1024, 5)).astype(np.float32); y = rng.uniform(-3, 3, (1024, 1)).astype(np.float32)
+    check(g, oracle, f1, X, y, "crossover products, L=128", max_skipped=0.25)
+
+
+# ---- the functions behind the generic stubs -------------------------------------------------------------------------------
+@pytest.mark.parametrize("funcs", [[LDIV, ADD, MUL], [MAX, MIN, ADD, SUB], [LT, GT, LE, GE, ADD, MUL], [IF, ADD, SUB, LT], [LINV, INV, ADD, MUL],
+                                   EXACT_WIDE], ids=["ldiv", "maxmin", "cmp", "if", "linv", "all-exact"])
+def test_generic_functions(g, oracle, rng, funcs):
+    mlc = 4 if IF in funcs else 5   # a full ternary tree of depth 4 has 40 nodes, of depth 5 121: it must fit the 64-node row
+    forest = oracle.generate(6000, 64, 4, 1, 0.5, 0.4, [sum(funcs), 1], depth2leaf(mlc, 0.15), roulette_uniform(funcs), [-1.0, 0.0, 1.0, 0.5, 2.0, 1e-10, -1e-10])
+    X = rng.uniform(-2, 2, (520, 4)).astype(np.float32)
+    X[::7, 0] = 0.0; X[::11, 1] = np.float32(1e-10); X[::13, 2] = -0.0   # the loose functions' clamp, exact zeros
+    y = rng.uniform(-2, 2, (520, 1)).astype(np.float32)
+    check(g, oracle, forest, X, y, f"funcs {funcs}")
+
+
+def test_generic_functions_every_operand_form(g, oracle, rng):
+    """hand-built two-level trees: op(x, y) with x, y each a stack value, a variable or a constant (the eight forms)"""
+    ops = [LDIV, MAX, MIN, LT, GT, LE, GE]
+    rows = []
+    for f in ops:
+        for la in "SVC":
+            for rb in "SVC":
+                def operand(kind, var, const):
+                    if kind == "S":
+                        return [(3, float(ADD), 3), (0, float(var), 1), (1, const, 1)]   # ADD(var, const)
+                    return [(0, float(var), 1)] if kind == "V" else [(1, const, 1)]
+                a, b = operand(la, 0, 0.5), operand(rb, 1, -0.25)
+                rows.append([(3, float(f), 1 + len(a) + len(b))] + a + b)
+    # IF with every mix of leaf / subtree operands
+    for mix in range(8):
+        kids = []
+        for j in range(3):
+            kids += [(3, float(SUB), 3), (0, float(j), 1), (1, 0.1 * j, 1)] if (mix >> j) & 1 else [(0, float(j), 1)]
+        rows.append([(4, float(IF), 1 + len(kids))] + kids)
+    rows.append([(2, 29.0, 4), (3, float(ADD), 3), (0, 0.0, 1), (0, 1.0, 1)])   # unknown unary id over a subtree: 0
+    rows.append([(2, 29.0, 2), (0, 2.0, 1)])                                    # ... over a leaf
+    L = 16
+    pop = len(rows)
+    v = np.zeros((pop, L), np.float32); t = np.zeros((pop, L), np.int16); s = np.zeros((pop, L), np.int16)
+    for r, nodes in enumerate(rows):
+        for i, (ty, val, sz) in enumerate(nodes):
+            t[r, i], v[r, i], s[r, i] = ty, val, sz
+        assert oracle.validate_tree(t[r], s[r]) == 0
+    X = rng.uniform(-1, 1, (300, 3)).astype(np.float32); X[:40, 1] = 0.0; X[40:60, 1] = np.float32(-1e-10)
+    y = rng.uniform(-1, 1, (300, 1)).astype(np.float32)
+    check(g, oracle, (v, t, s), X, y, "operand forms", max_skipped=0.0)
+
+
+# ---- multi-output trees ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("out_len,D,funcs,L", [(2, 1024, ARITH, 64), (4, 1024, ARITH, 64), (6, 700, ARITH, 64), (4, 1024, EXACT_WIDE, 128),
+                                               (10, 200, ARITH, 128), (12, 1797, ARITH, 64), (3, 8, ARITH, 64), (4, 1024, ARITH + [SIN, EXP, LOG], 64)])
+def test_multi_output(g, oracle, rng, out_len, D, funcs, L):
+    mlc = 5 if IF in funcs else 6   # full trees must fit the row: ternary depth 5 = 121 nodes, binary depth 6 = 63
+    forest = oracle.generate(5000, L, 7, out_len, 0.5, 0.5, [out_len, D], depth2leaf(mlc, 0.15), roulette_uniform(funcs), CS)
+    X = rng.uniform(-2, 2, (D, 7)).astype(np.float32); y = rng.uniform(-2, 2, (D, out_len)).astype(np.float32)
+    trans = any(f in (SIN, EXP, LOG) for f in funcs)
+    if trans:  # library functions: a looser bar on this one case (operands are leaves: no amplification through the tree)
+        got, want = g.sr_fitness(*forest, X, y), oracle.sr_fitness(*forest, X, y)
+        assert handler_histogram(g, 5000)["skip"] <= 100
+        assert_close_classes(got, want, 1e-4, what="multi-output with library functions")
+    else:
+        h = check(g, oracle, forest, X, y, f"out_len={out_len} D={D}")
+        assert h["acc_s"] > 0 and h["mo_begin"] == 5000 - h["skip"]
+
+
+def test_multi_output_out_index_beyond_out_len_and_nested_outs(g, oracle, rng):
+    """OUT nodes whose stored index is >= out_len add nothing (forward.cu:239); OUT nodes nested in OUT nodes pass their LAST
+    operand upward, not their result (forward.cu:241-243)"""
+    out_len = 3
+    forest = oracle.generate(3000, 128, 5, 6, 0.9, 0.5, [6, 6], depth2leaf(5, 0.1), roulette_uniform(ARITH + [IF, MAX]), CS)  # indices 0..5 stored
+    X = rng.uniform(-2, 2, (300, 5)).astype(np.float32); y = rng.uniform(-2, 2, (300, out_len)).astype(np.float32)
+    check(g, oracle, forest, X, y, "stored out indices up to 5, out_len 3")
+
+
+def test_what_still_goes_to_the_register_kernels(g, oracle, rng):
+    """pow and the hyperbolic functions have no handler yet: their trees are marked and the result is still the oracle's"""
+    forest = oracle.generate(2000, 64, 4, 1, 0.5, 0.5, [1, 2], depth2leaf(5), roulette_uniform([ADD, MUL, POW, TANH]), CS)
+    X = rng.uniform(0.1, 2, (260, 4)).astype(np.float32); y = rng.uniform(-2, 2, (260, 1)).astype(np.float32)
+    got, want = g.sr_fitness(*forest, X, y), oracle.sr_fitness(*forest, X, y)
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert (np.abs(got[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-6).mean() > 0.99

@@ -21,6 +21,7 @@ gpurun_out/ exists), never looser than the OpenCL/OCML documented bound in the c
 """
 import json
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -97,19 +98,19 @@ def _truth_binary(name, a64, b64):
 #   documented OCML / OpenCL full-profile bounds: sin cos 4, tan 5, sinh cosh tanh 5, log exp 3, pow 16, sqrt 3 (correctly rounded
 #   here: the library's fix-up sequence), division 2.5 (correctly rounded here; the default "short" sequence of the threaded
 #   code is faithfully rounded: < 1 ulp).
-#   MEASURED on MI355X (profiles/r02_ulp_report.json), largest error over all four routes: cosh 0.56, exp 1.00, log 1.88, pow 1.28,
-#   sinh 0.90, tanh 1.33, sin / cos / tan beyond 2^17: 1.53 / 1.58 / 1.97; sqrt and the divisions are correctly rounded (0.5).  The bounds
+#   MEASURED on MI355X (profiles/r02_ulp_report.json), largest error over all four routes: cosh 0.56, exp 1.00, log 1.88, pow 1.31,
+#   sinh 0.90, tanh 1.35, sin / cos / tan 1.50 / 1.53 / 2.27 (beyond 2^17: 1.53 / 1.58 / 1.97); sqrt and the divisions are correctly rounded (0.5).  The bounds
 #   below are those figures rounded up to one decimal: a handler or a folded constant that strays from the library's result by a
 #   single ulp on a single operand fails here.
 UNARY = {
-    "SIN": (2.0, 2.0, dict(e_hi=17)), "COS": (2.0, 2.0, dict(e_hi=17)), "TAN": (2.5, 2.5, dict(e_hi=17)),
+    "SIN": (1.6, 1.6, dict(e_hi=17)), "COS": (1.6, 1.6, dict(e_hi=17)), "TAN": (2.4, 2.4, dict(e_hi=17)),
     "SINH": (1.0, 1.0, dict(e_hi=7, lo=-89.0, hi=89.0)), "COSH": (0.6, 0.6, dict(e_hi=7, lo=-89.0, hi=89.0)), "TANH": (1.4, 1.4, dict(e_hi=8)),
     "LOG": (1.9, 1.9, dict(e_hi=127)), "LOOSE_LOG": (1.9, 1.9, dict(e_hi=127)), "EXP": (1.0, 1.0, dict(e_hi=7, lo=-104.0, hi=88.7)),
     "SQRT": (0.5, 0.5, dict(e_hi=127)), "LOOSE_SQRT": (0.5, 0.5, dict(e_hi=127)),
     "INV": (0.5, 0.5, dict(e_hi=126)), "LOOSE_INV": (0.5, 0.5, dict(e_hi=126)),
 }
 LARGE = {"SIN": (1.6, 1.6), "COS": (1.6, 1.6), "TAN": (2.0, 2.0)}
-BINARY = {"DIV": (0.5, 0.5), "LOOSE_DIV": (0.5, 0.5), "POW": (1.3, 1.3), "LOOSE_POW": (1.3, 1.3)}
+BINARY = {"DIV": (0.5, 0.5), "LOOSE_DIV": (0.5, 0.5), "POW": (1.4, 1.4), "LOOSE_POW": (1.4, 1.4)}
 
 
 def ulp32(t64):
@@ -212,7 +213,7 @@ def run_all_routes(g, name, arity, ops32, truth_fn, b_reg, b_tc, label=None):
 @pytest.mark.parametrize("name", list(UNARY))
 def test_unary_function_within_ulp_bound(g, name):
     b_reg, b_tc, dom = UNARY[name]
-    rng = np.random.default_rng(abs(hash(name)) % 2**32)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))  # the same operands in every run
     signed = name not in ()
     x = inputs(rng, dom["e_hi"], dom.get("lo"), dom.get("hi"), signed)
     run_all_routes(g, name, 1, [x], lambda a: _truth_unary(name, a), b_reg, b_tc)
@@ -231,7 +232,7 @@ def test_trigonometric_large_arguments(g, name):
 @pytest.mark.parametrize("name", list(BINARY))
 def test_binary_function_within_ulp_bound(g, name):
     b_reg, b_tc = BINARY[name]
-    rng = np.random.default_rng(abs(hash(name)) % 2**32)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))  # the same operands in every run
     if "POW" in name:
         a = inputs(rng, 20, signed=(name == "LOOSE_POW"))
         b = rng.uniform(-12, 12, a.shape).astype(np.float32)
