@@ -50,14 +50,19 @@ The block is ONE `asm volatile` statement that never returns (it ends the wave).
 VGPR indexing stays enabled while a program runs; handlers select the indexed operands by writing
 M0 = (mode << 12) | index directly (s_add_u32 m0, H, imm), which replaces s_set_gpr_idx_on/off pairs.
 """
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ocml_bodies import BODIES  # noqa: E402  (the library's sequences for pow / sinh / cosh, gen/ocml_transcribe.py)
 
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the FULL register kernel"
 OPS = ("add", "sub", "mul", "div")
 UNARY = ("neg", "abs", "sin", "cos", "tan", "sqrt", "lsqrt", "exp", "log", "llog")  # unary handlers, in the compiler kernel's numbering (sr_tc.hip)
-GBIN = ("ldiv", "max", "min", "lt", "gt", "le", "ge")  # bodies behind the generic binary stubs, selected by the word's aux field
-GUN = ("zero",)                                        # bodies behind the generic unary stubs
+GBIN = ("ldiv", "max", "min", "lt", "gt", "le", "ge", "pow", "lpow")  # bodies behind the generic binary stubs, selected by the word's aux field
+GUN = ("zero", "sinh", "cosh", "tanh")                                # bodies behind the generic unary stubs
+HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top of the operand stack (the compiler keeps it free)
 SLOT = 256  # bytes per handler slot
 NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo
 
@@ -769,6 +774,82 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                     a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
                 epilogue()
 
+
+    # ---- library sequences run row by row (pow, sinh, cosh: 120-190 instructions and 14-24 registers each; K unrolled
+    # copies would not fit anywhere).  The row loop reads its operands and writes its result through M0-relative
+    # addressing; the sequence itself is gen/ocml_bodies.py with its placeholders bound to registers that are free inside a
+    # handler: v4 v5 v9 v18-v22 and the top HEAVY_REGS registers of the operand stack, which the program compiler leaves
+    # unused wherever such a function occurs.  The sequences want more SGPRs than the interpreter has to spare: sixteen control
+    # registers that no handler needs (the kernel's pointers and sizes, s8-s19; the batch bookkeeping, s26-s29) wait in the
+    # lanes of one VGPR meanwhile.
+    top = NV - HEAVY_REGS - (K if stats else 0)
+    assert top % 2 == 0 and top >= S0
+    VPAIRS = [4, 18, 20] + list(range(top, top + HEAVY_REGS, 2))
+    VSINGLES = [9, 22]
+    SPILL = list(range(8, 20)) + list(range(26, 30))
+    SPAIRS = [T1, sA] + list(range(8, 20, 2)) + [26, 28]
+
+    def bind(body, extra_v=0):
+        """placeholder -> register; returns (format function, register map, extra VGPRs, spill VGPR, loop counter SGPR)"""
+        vp, vs, sp = list(VPAIRS), list(VSINGLES), list(SPAIRS)
+        vmap, smap = {}, {}
+        for lo in body["vpairs"]:
+            r = vp.pop(0); vmap[lo], vmap[lo + 1] = r, r + 1
+        for lo in body["spairs"]:
+            r = sp.pop(0); smap[lo], smap[lo + 1] = r, r + 1
+
+        def single(pool_s, pool_p):
+            if not pool_s:
+                r = pool_p.pop(0); pool_s += [r, r + 1]
+            return pool_s.pop(0)
+        ss = []
+        for r in body["vregs"]:
+            if r not in vmap:
+                vmap[r] = single(vs, vp)
+        for r in body["sregs"]:
+            if r not in smap:
+                smap[r] = single(ss, sp)
+        extra = [single(vs, vp) for _ in range(extra_v)]
+        spill = single(vs, vp)
+        counter = single(ss, sp)
+
+        def fmt(line):
+            import re
+
+            def rep(m):
+                kind, lo, pair = m.group(1), int(m.group(2)), m.group(3)
+                mp = vmap if kind == "v" else smap
+                return f"{kind}[{mp[lo]}:{mp[lo] + 1}]" if pair else f"{kind}{mp[lo]}"
+            return re.sub(r"\{([vs])(\d+)(_\d+)?\}", rep, line)
+        return fmt, vmap, extra, spill, counter
+
+    def row_loop(label, body, nin, out_bank, pre=(), post=(), extra_v=0):
+        """operands T[k] (and Q[k]) -> the sequence -> out_bank[k], for k = 0 .. K-1"""
+        fmt, vmap, extra, spill, counter = bind(body, extra_v)
+        for i, r in enumerate(SPILL):
+            a(f"v_writelane_b32 v{spill}, s{r}, {i}")
+        a(f"s_mov_b32 s{counter}, 0")
+        a(f"{lab(label + '_row')}:")
+        a(f"s_add_u32 m0, s{counter}, {hex(MODE['SRC0'] << 12)}")
+        a(f"v_mov_b32 v{vmap[body['inputs'][0]]}, v{T}")
+        if nin == 2:
+            a(f"v_mov_b32 v{vmap[body['inputs'][1]]}, v{Q}")
+        a("s_mov_b32 m0, 0")
+        ctx = dict(a=vmap[body["inputs"][0]], b=vmap[body["inputs"][1]] if nin == 2 else None, o=vmap[body["output"]], x=extra)
+        for ln in pre:
+            a(ln(ctx))
+        for ln in body["lines"]:
+            a(fmt(ln))
+        for ln in post:
+            a(ln(ctx))
+        a(f"s_add_u32 m0, s{counter}, {hex(MODE['DST'] << 12)}")
+        a(f"v_mov_b32 v{out_bank}, v{vmap[body['output']]}")
+        a(f"s_add_u32 s{counter}, s{counter}, 1")
+        a(f"s_cmp_lt_u32 s{counter}, {K}")
+        a(f"s_cbranch_scc1 {lab(label + '_row')}")
+        a("s_mov_b32 m0, 0")
+        for i, r in enumerate(SPILL):
+            a(f"v_readlane_b32 s{r}, v{spill}, {i}")
     # ---- bodies behind the generic stubs.  Binary: a in T, b in Q, result left in T; unary: operand in T, result in Q.
     a(f"{lab('gbin_dispatch')}:")
     a(f"s_lshl_b32 s{T2}, s{T2}, 2")
@@ -816,6 +897,16 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             for k in range(K):
                 div_rows([T + k], [Q + k], [4], nanfix=False)
                 a(f"v_div_fixup_f32 v{T + k}, v4, v{Q + k}, v{T + k}")
+        elif body == "pow":             # forward.cu:193-194
+            row_loop("pow", BODIES["pow"], 2, T)
+        elif body == "lpow":            # forward.cu:195-200: (a == 0 && b == 0) ? 0 : pow(|a|, b)
+            row_loop("lpow", BODIES["pow"], 2, T, extra_v=1,
+                     pre=(lambda c: f"v_and_b32 v{c['a']}, 0x7fffffff, v{c['a']}",
+                          lambda c: f"v_and_b32 v{c['x'][0]}, 0x7fffffff, v{c['b']}",
+                          lambda c: f"v_or_b32 v{c['x'][0]}, v{c['x'][0]}, v{c['a']}"),   # zero exactly when both operands are +-0
+                     post=(lambda c: f"v_cmp_eq_u32 vcc, 0, v{c['x'][0]}",
+                           lambda c: "s_nop 1",
+                           lambda c: f"v_cndmask_b32_e64 v{c['o']}, v{c['o']}, 0, vcc"))
         a(f"s_branch {lab('gbin_tail')}")
     a(f"{lab('gbin_tail')}:")
     a(f"s_mov_b32 m0, s{sDST}")
@@ -827,6 +918,49 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         if body == "zero":              # a unary node whose function id is unknown yields 0 (forward.cu:117)
             for k in range(K):
                 a(f"v_mov_b32 v{Q + k}, 0")
+        elif body in ("sinh", "cosh"):  # forward.cu:129-134
+            row_loop(body, BODIES[body], 1, Q)
+        elif body == "tanh":            # the library's tanhf: both of its branches, then the select it makes with the exec mask
+            t2, t3, t4, t5 = 18, 19, 20, 21
+            for k in range(K):
+                x = T + k
+                a(f"v_add_f32_e64 v{t2}, |v{x}|, |v{x}|")
+                a(f"v_mul_f32 v{t3}, 0x3fb8aa3b, v{t2}")
+                a(f"s_mov_b32 s{T1}, 0x3fb8aa3b")
+                a(f"v_rndne_f32 v{t4}, v{t3}")
+                a(f"v_sub_f32 v{t5}, v{t3}, v{t4}")
+                a(f"v_fma_f32 v{t3}, v{t2}, s{T1}, -v{t3}")
+                a(f"v_fmamk_f32 v{t3}, v{t2}, 0x32a5705f, v{t3}")
+                a(f"v_add_f32 v{t3}, v{t5}, v{t3}")
+                a(f"v_exp_f32 v{t3}, v{t3}")
+                a(f"v_cvt_i32_f32 v{t4}, v{t4}")
+                a(f"s_mov_b32 s{T1}, 0xc2ce8ed0")
+                a(f"v_cmp_ngt_f32 vcc, s{T1}, v{t2}")
+                a(f"s_mov_b32 s{T1}, 0x42b17218")
+                a(f"v_ldexp_f32 v{t3}, v{t3}, v{t4}")
+                a(f"v_cndmask_b32 v{t3}, 0, v{t3}, vcc")
+                a(f"v_mov_b32 v{t4}, 0x7f800000")
+                a(f"v_cmp_nlt_f32 vcc, s{T1}, v{t2}")
+                a("s_nop 1")
+                a(f"v_cndmask_b32 v{t2}, v{t4}, v{t3}, vcc")
+                a(f"v_add_f32 v{t2}, 1.0, v{t2}")
+                a(f"v_rcp_f32 v{t2}, v{t2}")
+                a("s_nop 0")
+                a(f"v_fma_f32 v{t2}, v{t2}, -2.0, 1.0")          # |x| >= 0.625: 1 - 2 / (exp(2|x|) + 1)
+                a(f"v_mul_f32 v{t3}, v{x}, v{x}")
+                a(f"v_mov_b32 v{t4}, 0x3ca908c9")
+                a(f"v_fmac_f32 v{t4}, 0xbbbac73d, v{t3}")
+                a(f"v_fmaak_f32 v{t4}, v{t3}, v{t4}, 0xbd5c1c4e")
+                a(f"v_fmaak_f32 v{t4}, v{t3}, v{t4}, 0x3e088382")
+                a(f"v_fmaak_f32 v{t4}, v{t3}, v{t4}, 0xbeaaaa99")
+                a(f"v_mul_f32_e64 v{t4}, |v{x}|, v{t4}")
+                a(f"v_fma_f32 v{t3}, v{t3}, v{t4}, |v{x}|")     # |x| < 0.625: polynomial
+                a(f"s_mov_b32 s{T1}, 0x3f200000")
+                a(f"v_cmp_nlt_f32_e64 vcc, |v{x}|, s{T1}")
+                a("s_nop 1")
+                a(f"v_cndmask_b32 v{t2}, v{t3}, v{t2}, vcc")
+                a(f"s_brev_b32 s{T1}, -2")
+                a(f"v_bfi_b32 v{Q + k}, s{T1}, v{t2}, v{x}")     # sign of x
         a(f"s_branch {lab('gun_tail')}")
     a(f"{lab('gun_tail')}:")
     a(f"s_mov_b32 m0, s{sDST}")
@@ -1218,7 +1352,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
     if K == 8 and not stats and not fast:
-        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n#define EVOGP_TC_UNARY_MASK {(1 << len(UNARY)) - 1}\n"
+        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n#define EVOGP_TC_UNARY_MASK {(1 << len(UNARY)) - 1}\n#define EVOGP_TC_HEAVY_REGS {HEAVY_REGS}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
     out += f"#define EVOGP_TC_ASM_{name}(karg_, wgid_, ldsx_, wave_, dyn_, pf_, base_) \\\n  asm volatile( \\\n"

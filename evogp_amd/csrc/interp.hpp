@@ -274,7 +274,7 @@ __device__ inline void run_chunk(uint32_t opv, uint32_t payv, int n, RegStack<K,
 }
 
 // Result of the structural pre-pass over one tree.
-enum TreeClass : int { TREE_OK = 0, TREE_DEEP = 1, TREE_BAD = 2, TREE_HEAVY = 3, TREE_SKIP = 4 };
+enum TreeClass : int { TREE_OK = 0, TREE_DEEP = 1, TREE_BAD = 2, TREE_HEAVY = 3, TREE_SKIP = 4, TREE_GENERAL = 5 };
 
 // Classify a tree: walk it in chunks of 64 nodes in execution (reverse prefix) order, prefix-sum
 // the stack-height deltas, and check 1 <= height everywhere, final height == 1, and the maximum

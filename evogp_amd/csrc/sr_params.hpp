@@ -7,6 +7,7 @@ namespace evogp {
 
 constexpr uint32_t kSentinelDeep = 0x7FC0DEEDu;  // quiet-NaN payload: "evaluate me in the general kernel"
 constexpr uint32_t kSentinelHeavy = 0x7FC0FEEDu; // quiet-NaN payload: "evaluate me in the FULL register kernel"
+constexpr uint32_t kSentinelGeneral = 0x7FC0BEEFu; // quiet-NaN payload: "compile me with the general program compiler" (sr_tc.hip)
 constexpr int kMaxBatch = 64;                    // trees per batch (LDS partial-sum slots)
 constexpr int kMaxWaves = 16;
 

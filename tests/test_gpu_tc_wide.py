@@ -159,11 +159,25 @@ def test_multi_output_out_index_beyond_out_len_and_nested_outs(g, oracle, rng):
     check(g, oracle, forest, X, y, "stored out indices up to 5, out_len 3")
 
 
-def test_what_still_goes_to_the_register_kernels(g, oracle, rng):
-    """pow and the hyperbolic functions have no handler yet: their trees are marked and the result is still the oracle's"""
-    forest = oracle.generate(2000, 64, 4, 1, 0.5, 0.5, [1, 2], depth2leaf(5), roulette_uniform([ADD, MUL, POW, TANH]), CS)
-    X = rng.uniform(0.1, 2, (260, 4)).astype(np.float32); y = rng.uniform(-2, 2, (260, 1)).astype(np.float32)
-    got, want = g.sr_fitness(*forest, X, y), oracle.sr_fitness(*forest, X, y)
+@pytest.mark.parametrize("funcs,out_len", [([ADD, MUL, POW, TANH], 1), ([ADD, SUB, LPOW, SINH, COSH], 1), ([ADD, SUB, LOG, SQRT, POW, DIV, INV], 1),
+                                           ([ADD, MUL, POW, TANH, SINH], 3)], ids=["pow-tanh", "lpow-sinh-cosh", "vis.ipynb", "3 outputs"])
+def test_library_functions_in_the_threaded_code(g, oracle, rng, funcs, out_len):
+    """pow, loose pow and the hyperbolic functions run the device library's transcribed sequences row by row
+    (gen/ocml_bodies.py).  Function-level accuracy is pinned in test_gpu_ulp.py; here whole trees against the oracle (host libm):
+    identical NaN sets, and 1e-4 on all but the ill-conditioned few (pow amplifies an ulp of its base by its exponent)."""
+    forest = oracle.generate(4000, 64, 4, out_len, 0.5, 0.5, [len(funcs), out_len], depth2leaf(5, 0.15), roulette_uniform(funcs), [-1.0, 0.0, 1.0, 0.5, 2.0])
+    X = rng.uniform(0.1, 2, (300, 4)).astype(np.float32); y = rng.uniform(-2, 2, (300, out_len)).astype(np.float32)
+    got = g.sr_fitness(*forest, X, y)
+    h = handler_histogram(g, 4000)
+    assert h["skip"] <= 0.05 * 4000, f"{h['skip']} trees left to the register kernels"
+    want = oracle.sr_fitness(*forest, X, y)
     ok = np.isfinite(want)
-    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
     assert (np.abs(got[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-6).mean() > 0.99
+    # the same trees on the register kernels (which call the library): the threaded code must agree to the last bit on every
+    # datapoint-independent tree and to rounding of the final sum elsewhere
+    be = g.batch_evaluate(*forest, X, out_len).astype(np.float64)
+    with np.errstate(all="ignore"):
+        ref = ((be - y[None, :, :].astype(np.float64)) ** 2).sum(2).mean(1)
+    both = np.isfinite(ref) & ok & (np.abs(ref) < 1e30)
+    assert np.allclose(got[both], ref[both], rtol=2e-5, atol=1e-30), "threaded code vs the register kernels on the same trees"

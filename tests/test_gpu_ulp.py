@@ -170,7 +170,8 @@ def run_all_routes(g, name, arity, ops32, truth_fn, b_reg, b_tc, label=None):
     name = label or name
     X = np.stack(ops32, 1)
     truth64 = truth_fn(*[o.astype(np.float64) for o in ops32])
-    check(name, "batch", g.batch_evaluate(*one_node_forest(fid, arity, 1), X, 1), truth64, b_reg)
+    lib = np.asarray(g.batch_evaluate(*one_node_forest(fid, arity, 1), X, 1), np.float32).ravel()   # the register kernels call the device library
+    check(name, "batch", lib, truth64, b_reg)
     check(name, "evaluate", g.evaluate(*one_node_forest(fid, arity, X.shape[0]), X, 1), truth64, b_reg)
     # the fitness routes feed the operand through ADD(c, x0 = 0), which turns -0 into +0: same operands for the truth
     ops32 = [np.where(o == 0, np.float32(0.0), o) for o in ops32]
@@ -185,6 +186,13 @@ def run_all_routes(g, name, arity, ops32, truth_fn, b_reg, b_tc, label=None):
     err = res.astype(np.float64) / ulp32(truth64[ok])
     REPORT.setdefault(name, {})["fit_S"] = round(float(err.max()), 3)
     assert err.max() <= b_tc + 0.5, f"{name} via fit_S: {err.max():.2f} ulp (bound {b_tc} + 0.5 for the rounded truth)"
+    # the threaded-code handlers are the library's own instruction sequences: with the register kernels' result as the constant r,
+    # every residual must be exactly zero (the divisions excepted: their default sequence is faithfully, not correctly, rounded)
+    if "DIV" not in name and "INV" not in name:
+        lib_s = np.asarray(g.batch_evaluate(*one_node_forest(fid, arity, 1), np.stack(sel, 1), 1), np.float32).ravel()
+        fin = np.isfinite(lib_s)
+        res = g.sr_fitness(*residual_forest(fid, [o[fin] for o in sel], lib_s[fin]), np.zeros((1, 1), np.float32), np.zeros((1, 1), np.float32), False)
+        assert (res == 0).all(), f"{name}: {int((res != 0).sum())} of {res.size} handler results differ from the library's (largest residual {res.max()})"
     # operands from the dataset: 144 / arity trees per call (the dataset of one call lives in LDS), 24 calls
     per_call = 144 // arity
     worst = 0.0
