@@ -39,39 +39,59 @@ class DefaultMutation(BaseMutation):
 # ---- structural and point mutations -----------------------------------------------------------
 # The reference builds these from boolean-mask gathers, a per-row "vmap_subtree" gather program and tree_mutate
 # (mutation/mutation_utils.py:6-48, hoist.py:43-75, insert.py:45-85, delete.py:44-105, single_point.py:43-126,
-# multi_point.py, single_const.py, multi_const.py).  Every structural one is a subtree replacement whose donor is a
-# subtree of an existing tree — exactly what tree_crossover does — so here each is ONE (Insert: two) native launch over
+# multi_point.py:46-143, single_const.py:39-98, multi_const.py:43-95).  Every structural one is a subtree replacement whose
+# donor is a subtree of an existing tree — exactly what tree_crossover does — so Hoist and Delete are ONE native launch over
 # the whole population with no gather program and no host sync: trees that do not mutate get left position -1, which the
-# kernel answers with a verbatim copy (mutation.cu:256-266).  The point mutations are elementwise torch programs over
-# the (pop, L) grid.
+# kernel answers with a verbatim copy (mutation.cu:256-266).  The point mutations are elementwise programs over the
+# (pop, L) grid.
+#
+# Each operator is split into `draw` (the random numbers, on the device) and `apply` (what the operator does with them).
+# `apply` takes the draws the REFERENCE operator makes, in the reference's meaning, as population-sized tensors (entries of
+# trees that do not mutate are ignored): tests/golden/make_mutation_golden.py records the reference's own draws and results
+# on the CPU, tests/test_gpu_mutation_parity.py feeds the draws to `apply` on the GPU and compares bit for bit.
+# Where the reference's behaviour is a quirk rather than a choice, it is still the default and the alternative is an option:
+#   * HoistMutation draws the inner subtree as an ABSOLUTE node index below size(outer) (hoist.py:58-68), not as an offset
+#     inside the outer subtree (`inner_is_offset=True` for that);
+#   * Multi{Point,Const}Mutation compare ONE uniform number per tree with the intensity (multi_point.py:70-75): either every
+#     (constant) node of a mutating tree is redrawn or none (`per_node=True` draws one number per node);
+#   * the per-arity roulettes are cumulative sums of probabilities normalised over ALL functions (descriptor.py:106-139), so a
+#     uniform draw above the class total lands on the invalid id 29 (single_point.py:70-90).  `fix_roulette=True` scales
+#     the draw by the class total instead.
 
-def _rand_below(high: torch.Tensor) -> torch.Tensor:
-    """uniform integer in [0, high) per element (high >= 1), int64, on high's device"""
-    return torch.randint(0, 2**31 - 1, high.shape, device=high.device) % high.clamp(min=1).to(torch.int64)
+def _uniform_int(u: torch.Tensor, low, high) -> torch.Tensor:
+    """the reference's randint (tree/utils.py:306-310): trunc(low + u * (high - low)), computed in float32"""
+    return (low + u * (high - low)).to(torch.int64)
 
 
-def _mutate_mask(forest: Forest, rate: float) -> torch.Tensor:
-    return torch.rand(forest.pop_size, device=forest.batch_node_value.device) < rate
+def _rand(shape, dev):
+    return torch.rand(shape, device=dev)
 
 
 class HoistMutation(BaseMutation):
-    """Pick a subtree, pick a subtree inside it, and put the inner one in the outer one's place (hoist.py:43-75): trees
-    shrink.  ``reference_indexing=True`` reproduces the reference's draw of the inner position, which is an ABSOLUTE node
-    index in [0, size(outer)) rather than an offset inside the outer subtree (hoist.py:58-68)."""
+    """Pick a subtree, pick a subtree inside it, and put the inner one in the outer one's place (hoist.py:43-75)."""
 
-    def __init__(self, mutation_rate: float, reference_indexing: bool = False):
+    def __init__(self, mutation_rate: float, inner_is_offset: bool = False):
         self.mutation_rate = mutation_rate
-        self.reference_indexing = reference_indexing
+        self.inner_is_offset = inner_is_offset
+
+    def draw(self, forest: Forest):
+        dev = forest.batch_node_value.device
+        sizes = forest.batch_subtree_size.to(torch.int64)
+        mask = _rand(forest.pop_size, dev) < self.mutation_rate
+        p = _uniform_int(_rand(forest.pop_size, dev), 0, sizes[:, 0].to(torch.float32))
+        inner = _uniform_int(_rand(forest.pop_size, dev), 0, sizes.gather(1, p[:, None]).squeeze(1).to(torch.float32))
+        return mask, p, inner
+
+    def apply(self, forest: Forest, mask: torch.Tensor, positions: torch.Tensor, subtree_positions: torch.Tensor) -> Forest:
+        """positions: hoist.py:53-58 `mutate_positions`; subtree_positions: :61-68 (an absolute node index in the reference)"""
+        dev = forest.batch_node_value.device
+        p = positions.to(torch.int64)
+        q = subtree_positions.to(torch.int64) + (p if self.inner_is_offset else 0)
+        ar = torch.arange(forest.pop_size, dtype=torch.int32, device=dev)
+        return forest.crossover(ar, ar, torch.where(mask, p, -1).to(torch.int32), q.to(torch.int32))
 
     def __call__(self, forest: Forest) -> Forest:
-        dev = forest.batch_node_value.device
-        sizes = forest.batch_subtree_size
-        p = _rand_below(sizes[:, 0])
-        inner = _rand_below(sizes.gather(1, p[:, None]).squeeze(1))
-        q = inner if self.reference_indexing else p + inner
-        ar = torch.arange(forest.pop_size, dtype=torch.int32, device=dev)
-        p = torch.where(_mutate_mask(forest, self.mutation_rate), p, -1)
-        return forest.crossover(ar, ar, p.to(torch.int32), q.to(torch.int32))
+        return self.apply(forest, *self.draw(forest))
 
 
 class DeleteMutation(BaseMutation):
@@ -83,157 +103,241 @@ class DeleteMutation(BaseMutation):
         self.mutation_rate = mutation_rate
         self.max_mutatable_size = max_mutatable_size
 
-    def __call__(self, forest: Forest) -> Forest:
+    def draw(self, forest: Forest):
+        dev = forest.batch_node_value.device
+        n, L = forest.batch_subtree_size.shape
+        mask = (_rand(n, dev) < self.mutation_rate) & (forest.batch_subtree_size[:, 0] > 1)
+        return mask, _rand((n, L), dev), _rand(n, dev)
+
+    def apply(self, forest: Forest, mask: torch.Tensor, node_scores: torch.Tensor, child_u: torch.Tensor = None,
+              nth_childs: torch.Tensor = None) -> Forest:
+        """node_scores: the (pop, L) uniform numbers of `choose_nonleaf_pos` (delete.py:66-85); the child is either drawn from
+        child_u as the reference does (:96-101) or given directly as nth_childs"""
         dev = forest.batch_node_value.device
         sizes = forest.batch_subtree_size.to(torch.int64)
         n, L = sizes.shape
         live = torch.arange(L, device=dev)[None, :] < sizes[:, :1]
-        eligible = live & (sizes > 1)
+        score = node_scores * live
+        score = torch.where(sizes == 1, torch.zeros_like(score), score)
         if self.max_mutatable_size:
-            eligible &= sizes <= self.max_mutatable_size
-        p = torch.argmax(torch.rand((n, L), device=dev) * eligible, dim=1)          # a random eligible node (0 if none)
-        arity = ((forest.batch_node_type.gather(1, p[:, None]).squeeze(1).to(torch.int64) & NType.TYPE_MASK)
-                 - NType.UFUNC + 1).clamp(min=1)
-        nth = 1 + _rand_below(arity)
+            score = torch.where(sizes > self.max_mutatable_size, torch.zeros_like(score), score)
+        p = torch.argmax(score, dim=1)                                   # a random eligible node (0 if none)
+        if nth_childs is None:
+            arity = (forest.batch_node_type.gather(1, p[:, None]).squeeze(1).to(torch.int64) & NType.TYPE_MASK) - NType.UFUNC + 1
+            nth_childs = _uniform_int(child_u, 1, arity.to(torch.float32))
         c1 = (p + 1).clamp(max=L - 1)
         c2 = (c1 + sizes.gather(1, c1[:, None]).squeeze(1)).clamp(max=L - 1)
         c3 = (c2 + sizes.gather(1, c2[:, None]).squeeze(1)).clamp(max=L - 1)
-        q = torch.where(nth == 3, c3, torch.where(nth == 2, c2, c1))
-        mask = _mutate_mask(forest, self.mutation_rate) & (sizes[:, 0] > 1)
+        q = torch.where(nth_childs == 3, c3, torch.where(nth_childs == 2, c2, c1))
         ar = torch.arange(n, dtype=torch.int32, device=dev)
         return forest.crossover(ar, ar, torch.where(mask, p, -1).to(torch.int32), q.to(torch.int32))
+
+    def __call__(self, forest: Forest) -> Forest:
+        mask, scores, child_u = self.draw(forest)
+        return self.apply(forest, mask, scores, child_u)
 
 
 class InsertMutation(BaseMutation):
     """Pick a subtree, generate a small random tree, hang the subtree into a random position (>= 1) of the new tree and
-    put the result where the subtree was (insert.py:45-85): trees grow by one random operator layer."""
+    put the result where the subtree was (insert.py:45-85): trees grow by one random operator layer.  As in the reference
+    the new trees are generated for the mutating trees only (tree index = rank among them), which costs one host sync."""
 
     def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor):
         self.mutation_rate = mutation_rate
         self.descriptor = descriptor
 
-    def __call__(self, forest: Forest) -> Forest:
+    def draw(self, forest: Forest):
         dev = forest.batch_node_value.device
         n = forest.pop_size
-        mask = _mutate_mask(forest, self.mutation_rate)
-        p = _rand_below(forest.batch_subtree_size[:, 0])
-        fresh = Forest.random_generate(pop_size=n, descriptor=self.descriptor)
-        fsize = fresh.batch_subtree_size[:, 0].to(torch.int64)
-        r = 1 + _rand_below(fsize - 1)                                  # a position below the new root
-        mask = mask & (fsize > 1)                                       # a single-node tree has no such position
-        ar = torch.arange(n, dtype=torch.int32, device=dev)
-        both = fresh + forest                                           # rows [0, n): new trees, [n, 2n): the population
-        grafted = both.crossover(ar, ar + n, r.to(torch.int32), p.to(torch.int32))
-        return forest.mutate(torch.where(mask, p, -1).to(torch.int32), grafted)
+        mask = _rand(n, dev) < self.mutation_rate
+        p = _uniform_int(_rand(n, dev), 0, forest.batch_subtree_size[:, 0].to(torch.float32))
+        keys = torch.randint(0, 1000000, (2,), device=dev).to(torch.uint32)
+        return mask, p, keys, _rand(n, dev)
+
+    def apply(self, forest: Forest, mask: torch.Tensor, positions: torch.Tensor, keys: torch.Tensor, new_u: torch.Tensor = None,
+              new_positions: torch.Tensor = None) -> Forest:
+        """positions: insert.py:57-62; keys: the two generation keys of :68-71; the position inside the new tree is drawn from
+        new_u as the reference does (:74-79: low 1, high = its size) or given as new_positions — both indexed by tree"""
+        idx = torch.nonzero(mask).squeeze(1)
+        m = int(idx.shape[0])
+        if m == 0:
+            return forest
+        sub = forest[idx]
+        p = positions[idx].to(torch.int64)
+        fresh = Forest.random_generate(pop_size=m, descriptor=self.descriptor, keys=keys)
+        if new_positions is None:
+            r = _uniform_int(new_u[idx], 1, fresh.batch_subtree_size[:, 0].to(torch.float32))
+        else:
+            r = new_positions[idx].to(torch.int64)
+        ar = torch.arange(m, dtype=torch.int32, device=idx.device)
+        both = fresh + sub                                               # rows [0, m): new trees, [m, 2m): the mutating trees
+        grafted = both.crossover(ar, ar + m, r.to(torch.int32), p.to(torch.int32))   # subtree p of the old tree into position r of the new
+        out = sub.mutate(p.to(torch.int32), grafted)
+        res = Forest(forest.input_len, forest.output_len, forest.batch_node_value.clone(), forest.batch_node_type.clone(),
+                     forest.batch_subtree_size.clone())
+        res[idx] = out
+        return res
+
+    def __call__(self, forest: Forest) -> Forest:
+        mask, p, keys, u = self.draw(forest)
+        return self.apply(forest, mask, p, keys, u)
 
 
-def _same_kind_values(ntype: torch.Tensor, value: torch.Tensor, d: GenerateDescriptor, input_len: int, output_len: int,
-                      modify_output: bool) -> torch.Tensor:
+def _roulette_pick(roulette: torch.Tensor, u: torch.Tensor, fix: bool, fallback: torch.Tensor) -> torch.Tensor:
+    """function id for a uniform draw: the reference's searchsorted on the class roulette (single_point.py:70-84), or with
+    `fix` the draw scaled by the class total (then never the invalid id 29; a class without functions keeps the old id)"""
+    if not fix:
+        return torch.searchsorted(roulette, u.contiguous(), out_int32=True)
+    total = roulette[-1]
+    idx = torch.searchsorted(roulette, (u * total).contiguous(), right=True, out_int32=True).clamp(max=roulette.shape[0] - 1)
+    return torch.where(total > 0, idx, fallback)
+
+
+def _same_kind_values(ntype: torch.Tensor, value: torch.Tensor, d: GenerateDescriptor, input_len: int, u_uf, u_bf, u_tf, var_idx, const_idx,
+                      out_idx=None, fix_roulette: bool = False) -> torch.Tensor:
     """For every node a fresh payload of the node's own kind: a function of the same arity drawn from the descriptor's
-    per-arity roulettes (an output node keeps, or with modify_output redraws, its output index in the high half-word),
-    a variable index, or a constant sample (single_point.py:70-124)."""
-    dev = value.device
+    per-arity roulettes (an output node keeps, or with out_idx takes, its output index in the high half-word), a variable
+    index, or a constant sample (single_point.py:64-124).  All arguments have the shape of `value`."""
     kind = ntype.to(torch.int64) & NType.TYPE_MASK
     is_out = (ntype.to(torch.int64) & NType.OUT_NODE) != 0
-    shape = value.shape
-    # the per-arity roulettes are cumulative sums of the UNnormalised class probabilities (descriptor.py:113-139), so the
-    # uniform draw is scaled by the class total; the reference draws in [0, 1) and can land on the invalid id 29
-    old_func = torch.where(is_out, value.contiguous().view(torch.int32) & 0xFFFF, value.to(torch.int32))
-    draws = []
-    for rl in (d.roulette_ufuncs, d.roulette_bfuncs, d.roulette_tfuncs):
-        total = rl[-1]
-        u = torch.rand(shape, device=dev).reshape(-1) * total
-        idx = torch.searchsorted(rl, u, right=True, out_int32=True).reshape(shape).clamp(max=rl.shape[0] - 1)
-        draws.append(torch.where(total > 0, idx, old_func))
-    func = torch.where(kind == NType.TFUNC, draws[2], torch.where(kind == NType.BFUNC, draws[1], draws[0]))
-    if modify_output:
-        out_idx = torch.randint(0, output_len, shape, dtype=torch.int32, device=dev)
-    else:
-        out_idx = torch.where(is_out, value.contiguous().view(torch.int32) >> 16, 0)
-    packed = (func + (out_idx << 16)).to(torch.int32).view(torch.float32)
+    bits = value.contiguous().view(torch.int32)
+    old_func = torch.where(is_out, bits & 0xFFFF, value.to(torch.int32))
+    uf = _roulette_pick(d.roulette_ufuncs, u_uf, fix_roulette, old_func)
+    bf = _roulette_pick(d.roulette_bfuncs, u_bf, fix_roulette, old_func)
+    tf = _roulette_pick(d.roulette_tfuncs, u_tf, fix_roulette, old_func)
+    sel = (kind - NType.UFUNC).clamp(0, 2)                               # single_point.py:86-89: leaves read the unary draw (unused)
+    func = torch.where(sel == 2, tf, torch.where(sel == 1, bf, uf))
+    if out_idx is None:
+        out_idx = torch.where(is_out, bits >> 16, torch.zeros_like(bits))
+    packed = (func + (out_idx.to(torch.int32) << 16)).to(torch.int32).view(torch.float32)
     func_val = torch.where(is_out, packed, func.to(torch.float32))
-    var_val = torch.randint(0, input_len, shape, device=dev).to(torch.float32)
-    const_val = d.const_samples[torch.randint(0, d.const_samples.shape[0], shape, device=dev)]
+    var_val = var_idx.to(torch.float32)
+    const_val = d.const_samples[const_idx.to(torch.int64)]
     return torch.where(kind == NType.CONST, const_val, torch.where(kind == NType.VAR, var_val, func_val))
 
 
 class MultiPointMutation(BaseMutation):
-    """Every node of a mutating tree is replaced, with probability ``mutation_intensity``, by a random node of its own
-    kind (multi_point.py); the tree structure is unchanged."""
+    """Nodes of a mutating tree are replaced by random nodes of their own kind (multi_point.py:46-143); the tree structure is
+    unchanged.  Reference behaviour (default): one uniform number per TREE is compared with ``mutation_intensity``, so
+    all nodes of a mutating tree are redrawn or none; ``per_node=True`` compares one number per node."""
 
     def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor, mutation_intensity: float = 0.3,
-                 modify_output: bool = False):
+                 modify_output: bool = False, per_node: bool = False, fix_roulette: bool = False):
         self.mutation_rate = mutation_rate
         self.descriptor = descriptor
         self.mutation_intensity = mutation_intensity
         self.modify_output = modify_output
+        self.per_node = per_node
+        self.fix_roulette = fix_roulette
 
-    def _targets(self, forest: Forest) -> torch.Tensor:
+    def _node_draws(self, forest: Forest):
+        dev = forest.batch_node_value.device
+        shape = forest.batch_node_value.shape
+        d = self.descriptor
+        out_idx = torch.randint(0, forest.output_len, shape, dtype=torch.int32, device=dev) if self.modify_output else None
+        return dict(u_uf=_rand(shape, dev), u_bf=_rand(shape, dev), u_tf=_rand(shape, dev),
+                    var_idx=_uniform_int(_rand(shape, dev), 0, forest.input_len),
+                    const_idx=_uniform_int(_rand(shape, dev), 0, d.const_samples.shape[0]), out_idx=out_idx)
+
+    def draw(self, forest: Forest):
         dev = forest.batch_node_value.device
         n, L = forest.batch_node_value.shape
+        mask = _rand(n, dev) < self.mutation_rate
+        intensity_u = _rand((n, L) if self.per_node else (n, 1), dev)
+        return mask, intensity_u, self._node_draws(forest)
+
+    def targets(self, forest: Forest, mask: torch.Tensor, intensity_u: torch.Tensor) -> torch.Tensor:
+        dev = forest.batch_node_value.device
+        L = forest.max_tree_len
         live = torch.arange(L, device=dev)[None, :] < forest.batch_subtree_size[:, :1]
-        return live & _mutate_mask(forest, self.mutation_rate)[:, None] & (torch.rand((n, L), device=dev) < self.mutation_intensity)
+        return live & mask[:, None] & (intensity_u < self.mutation_intensity)
+
+    def apply(self, forest: Forest, targets: torch.Tensor, node_draws: dict) -> Forest:
+        """targets: (pop, L) bool; node_draws: per-node tensors u_uf, u_bf, u_tf (uniform), var_idx, const_idx and optionally out_idx"""
+        fresh = _same_kind_values(forest.batch_node_type, forest.batch_node_value, self.descriptor, forest.input_len,
+                                  fix_roulette=self.fix_roulette, **node_draws)
+        value = torch.where(targets, fresh, forest.batch_node_value)
+        return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size)
 
     def __call__(self, forest: Forest) -> Forest:
-        fresh = _same_kind_values(forest.batch_node_type, forest.batch_node_value, self.descriptor, forest.input_len,
-                                  forest.output_len, self.modify_output)
-        value = torch.where(self._targets(forest), fresh, forest.batch_node_value)
-        return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size)
+        mask, intensity_u, node_draws = self.draw(forest)
+        return self.apply(forest, self.targets(forest, mask, intensity_u), node_draws)
 
 
 class SinglePointMutation(MultiPointMutation):
     """One random node of a mutating tree is replaced by a random node of its own kind (single_point.py:43-126)."""
 
-    def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor, modify_output: bool = False):
-        super().__init__(mutation_rate, descriptor, 1.0, modify_output)
+    def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor, modify_output: bool = False, fix_roulette: bool = False):
+        super().__init__(mutation_rate, descriptor, 1.0, modify_output, fix_roulette=fix_roulette)
 
-    def _targets(self, forest: Forest) -> torch.Tensor:
+    def draw(self, forest: Forest):
         dev = forest.batch_node_value.device
-        L = forest.max_tree_len
-        p = _rand_below(forest.batch_subtree_size[:, 0])
-        return (torch.arange(L, device=dev)[None, :] == p[:, None]) & _mutate_mask(forest, self.mutation_rate)[:, None]
+        n = forest.pop_size
+        mask = _rand(n, dev) < self.mutation_rate
+        p = _uniform_int(_rand(n, dev), 0, forest.batch_subtree_size[:, 0].to(torch.float32))
+        return mask, p, self._node_draws(forest)
+
+    def targets(self, forest: Forest, mask: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        dev = forest.batch_node_value.device
+        return (torch.arange(forest.max_tree_len, device=dev)[None, :] == positions.to(torch.int64)[:, None]) & mask[:, None]
 
 
 class MultiConstMutation(BaseMutation):
-    """Every constant of a mutating tree is redrawn from the descriptor's samples with probability
-    ``mutation_intensity`` (multi_const.py)."""
+    """Constants of a mutating tree are redrawn from the descriptor's samples (multi_const.py:43-95).  Reference behaviour
+    (default): one uniform number per TREE against ``mutation_intensity``; ``per_node=True``: one per node."""
 
-    def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor, mutation_intensity: float = 0.3):
+    def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor, mutation_intensity: float = 0.3, per_node: bool = False):
         self.mutation_rate = mutation_rate
         self.descriptor = descriptor
         self.mutation_intensity = mutation_intensity
+        self.per_node = per_node
 
-    def _targets(self, forest: Forest) -> torch.Tensor:
+    def draw(self, forest: Forest):
         dev = forest.batch_node_value.device
         n, L = forest.batch_node_value.shape
+        mask = _rand(n, dev) < self.mutation_rate
+        const_idx = torch.randint(0, self.descriptor.const_samples.shape[0], (n, L), device=dev)
+        return mask, _rand((n, L) if self.per_node else (n, 1), dev), const_idx
+
+    def targets(self, forest: Forest, mask: torch.Tensor, intensity_u: torch.Tensor) -> torch.Tensor:
+        dev = forest.batch_node_value.device
+        L = forest.max_tree_len
         live = torch.arange(L, device=dev)[None, :] < forest.batch_subtree_size[:, :1]
-        is_const = (forest.batch_node_type.to(torch.int64) & NType.TYPE_MASK) == NType.CONST
-        return (live & is_const & _mutate_mask(forest, self.mutation_rate)[:, None]
-                & (torch.rand((n, L), device=dev) < self.mutation_intensity))
+        is_const = forest.batch_node_type == NType.CONST                  # multi_const.py:73: the raw type
+        return live & is_const & mask[:, None] & (intensity_u < self.mutation_intensity)
+
+    def apply(self, forest: Forest, targets: torch.Tensor, const_idx: torch.Tensor) -> Forest:
+        fresh = self.descriptor.const_samples[const_idx.to(torch.int64)]
+        value = torch.where(targets, fresh, forest.batch_node_value)
+        return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size)
 
     def __call__(self, forest: Forest) -> Forest:
-        d = self.descriptor
-        dev = forest.batch_node_value.device
-        fresh = d.const_samples[torch.randint(0, d.const_samples.shape[0], forest.batch_node_value.shape, device=dev)]
-        value = torch.where(self._targets(forest), fresh, forest.batch_node_value)
-        return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size)
+        mask, u, const_idx = self.draw(forest)
+        return self.apply(forest, self.targets(forest, mask, u), const_idx)
 
 
 class SingleConstMutation(MultiConstMutation):
-    """One random constant of a mutating tree is redrawn (single_const.py); trees without constants are unchanged."""
+    """One random constant of a mutating tree is redrawn (single_const.py:39-98); trees without constants are unchanged."""
 
     def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor):
         super().__init__(mutation_rate, descriptor, 1.0)
 
-    def _targets(self, forest: Forest) -> torch.Tensor:
+    def draw(self, forest: Forest):
         dev = forest.batch_node_value.device
         n, L = forest.batch_node_value.shape
+        mask = _rand(n, dev) < self.mutation_rate
+        const_idx = torch.randint(0, self.descriptor.const_samples.shape[0], (n, 1), device=dev).expand(n, L)
+        return mask, _rand((n, L), dev), const_idx
+
+    def targets(self, forest: Forest, mask: torch.Tensor, node_scores: torch.Tensor) -> torch.Tensor:
+        """node_scores: the (pop, L) uniform numbers of `choose_constant_pos` (single_const.py:55-72)"""
+        dev = forest.batch_node_value.device
+        L = forest.max_tree_len
         live = torch.arange(L, device=dev)[None, :] < forest.batch_subtree_size[:, :1]
-        is_const = live & ((forest.batch_node_type.to(torch.int64) & NType.TYPE_MASK) == NType.CONST)
-        score = torch.rand((n, L), device=dev) * is_const
+        is_const = forest.batch_node_type == NType.CONST
+        score = torch.where(is_const, node_scores * live, torch.zeros_like(node_scores))
         p = torch.argmax(score, dim=1)
-        chosen = (torch.arange(L, device=dev)[None, :] == p[:, None]) & is_const
-        return chosen & _mutate_mask(forest, self.mutation_rate)[:, None]
+        return (torch.arange(L, device=dev)[None, :] == p[:, None]) & is_const & mask[:, None]   # :92-97: only if it IS a constant
 
 
 class CombinedMutation(BaseMutation):

@@ -51,12 +51,12 @@ def test_hoist_delete_shrink_and_stay_well_formed():
 
     f, _ = _forest()
     before = f.batch_subtree_size[:, 0].clone()
-    for op in (HoistMutation(1.0), HoistMutation(1.0, reference_indexing=True), DeleteMutation(1.0), DeleteMutation(1.0, max_mutatable_size=5)):
+    for op in (HoistMutation(1.0), HoistMutation(1.0, inner_is_offset=True), DeleteMutation(1.0), DeleteMutation(1.0, max_mutatable_size=5)):
         g = op(f)
         _check_well_formed(g)
         after = g.batch_subtree_size[:, 0]
-        if getattr(op, "reference_indexing", False):
-            continue  # an ABSOLUTE inner index can name the root: the reference's hoist may also grow a tree
+        if isinstance(op, HoistMutation) and not op.inner_is_offset:
+            continue  # the reference's ABSOLUTE inner index can name the root: its hoist may also grow a tree
         assert bool((after <= before).all())
         if isinstance(op, DeleteMutation):
             assert bool((after[before > 1] < before[before > 1]).all())   # a function node always loses at least itself
@@ -74,7 +74,9 @@ def test_insert_grows_and_stays_well_formed():
     _check_well_formed(g)
     before, after = f.batch_subtree_size[:, 0], g.batch_subtree_size[:, 0]
     grew = after > before
-    assert bool((after >= before).all()) and float(grew.float().mean()) > 0.5
+    # a generated tree that is a single leaf has no position below its root: as in the reference it then simply replaces the
+    # chosen subtree (insert.py:74-85) -- those trees shrink
+    assert float(grew.float().mean()) > 0.5
     same = InsertMutation(0.0, small)(f)
     assert torch.equal(same.batch_node_type, f.batch_node_type)
 
@@ -88,10 +90,13 @@ def test_point_mutations_keep_structure_and_kind(out_len):
     L = f.max_tree_len
     live = torch.arange(L)[None, :] < f.batch_subtree_size[:, :1]
     kind = f.batch_node_type.to(torch.int64) & 0x7F
-    for op, max_changes in ((SinglePointMutation(1.0, desc), 1), (MultiPointMutation(1.0, desc, 0.5), L),
+    # fix_roulette: the draw is scaled by the arity class's total probability.  (The reference -- and the default here -- draw
+    # in [0, 1) on a roulette whose class total is below 1 and so land on the invalid id 29 now and then: parity with that is
+    # tests/test_gpu_mutation_parity.py's business, here the SENSIBLE behaviour is checked.)
+    for op, max_changes in ((SinglePointMutation(1.0, desc, fix_roulette=True), 1), (MultiPointMutation(1.0, desc, 0.5, fix_roulette=True, per_node=True), L),
                             (SingleConstMutation(1.0, desc), 1), (MultiConstMutation(1.0, desc, 0.5), L),
-                            (SinglePointMutation(1.0, desc, modify_output=True), 1),
-                            (CombinedMutation([SinglePointMutation(0.5, desc), MultiConstMutation(0.5, desc)]), L)):
+                            (SinglePointMutation(1.0, desc, modify_output=True, fix_roulette=True), 1),
+                            (CombinedMutation([SinglePointMutation(0.5, desc, fix_roulette=True), MultiConstMutation(0.5, desc)]), L)):
         g = op(f)
         assert torch.equal(g.batch_node_type, f.batch_node_type) and torch.equal(g.batch_subtree_size, f.batch_subtree_size)
         changed = (g.batch_node_value.view(torch.int32) != f.batch_node_value.view(torch.int32))
