@@ -141,10 +141,11 @@ def test_structural_and_point_mutations_on_the_device(g):
         return Forest(forest.input_len, forest.output_len, forest.batch_node_value.cpu(), forest.batch_node_type.cpu(),
                       forest.batch_subtree_size.cpu())
 
-    for op in (HoistMutation(0.7), DeleteMutation(0.7), InsertMutation(0.7, desc.update(max_layer_cnt=2)),
+    # (inner_is_offset: the hoist that can only shrink; the reference's absolute inner index is covered by test_gpu_mutation_parity.py)
+    for op in (HoistMutation(0.7, inner_is_offset=True), DeleteMutation(0.7), InsertMutation(0.7, desc.update(max_layer_cnt=2)),
                SinglePointMutation(0.7, desc), MultiPointMutation(0.7, desc), SingleConstMutation(0.7, desc),
                MultiConstMutation(0.7, desc),
-               CombinedMutation([HoistMutation(0.3), InsertMutation(0.3, desc.update(max_layer_cnt=2)), DeleteMutation(0.3)])):
+               CombinedMutation([HoistMutation(0.3, inner_is_offset=True), InsertMutation(0.3, desc.update(max_layer_cnt=2)), DeleteMutation(0.3)])):
         out = op(f)
         _check_well_formed(cpu(out))
         after = out.batch_subtree_size[:, 0]
