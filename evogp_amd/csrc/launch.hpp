@@ -50,7 +50,9 @@ int sr_division_mode();
 // Layout of a block: words 0..3 = pending-marks flags and work counters (sr_params.hpp), then one work counter per XCD of
 // the threaded-code kernel's dynamic tail, each on its own 128-byte line (word 32 * (1 + xcd)).
 constexpr int kCallScratchXcds = 8;
-constexpr int kCallScratchWords = 32 * (1 + kCallScratchXcds);
+constexpr int kCallScratchChunkWords = 32 * (1 + kCallScratchXcds);   // one flag line + one counter line per XCD
+constexpr int kCallScratchChunks = 8;                                  // population chunks of one call (sr_tc.hip), each with its own lines
+constexpr int kCallScratchWords = kCallScratchChunkWords * kCallScratchChunks;
 unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hipError_t *err);
 void call_scratch_next_is_clean(hipStream_t stream);
 

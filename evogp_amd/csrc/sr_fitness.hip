@@ -52,6 +52,14 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfCall> g_prof;
 
+// flag word `i` of the call's scratch block, over the chunks the threaded code cut the population into
+__device__ inline bool marks_pending(const SrParams &p, int i) {
+    unsigned any = 0u;
+    const int n = p.mark_chunks > 1 ? p.mark_chunks : 1;
+    for (int c = 0; c < n; ++c) any |= p.marks[(size_t)c * kCallScratchChunkWords + i];
+    return uni((int)any) != 0;
+}
+
 __device__ inline float err_term(float diff, int use_mse) { return use_mse ? diff * diff : fabsf(diff); }
 
 // K rows per lane, DEPTH-entry register stack, VL variable registers, MO = multi-output,
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     __shared__ int cls_s[2][kMaxBatch];
     __shared__ int next_s[2];
 
-    if (p.only_marked && p.marks && uni((int)p.marks[0]) == 0) return;  // nothing was marked for this build
+    if (p.only_marked && p.marks && !marks_pending(p, 0)) return;  // nothing was marked for this build
     // Behind another kernel the batch size follows the share of marked trees the marking kernel sampled: few marked
     // trees -> full 64-tree batches (the work is one mark word per lane), many -> the launcher's load-balancing size.
     int batch = p.batch;
@@ -452,7 +460,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     if (!STORE && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
         p.stats = g_stats;
-        e = launch_threaded_code(p, stream, &tc_done, &p.mark_sample);
+        e = launch_threaded_code(p, stream, &tc_done, &p.mark_sample, &p.mark_chunks);
         p.stats = nullptr;
         if (e != hipSuccess) return (int)e;
     }

@@ -28,6 +28,7 @@ struct SrParams {
     int mark_sample; // trees the marking kernel SAMPLED for marks[2] (0: no estimate)
     unsigned long long *stats; // optional cycle counters (profiling builds of the bench only), else nullptr
     unsigned *zero_next; // four words the first kernel of the chain zeroes for the next call on this stream (or nullptr)
+    int mark_chunks;     // the threaded code ran the population in this many chunks: chunk c's flags are marks[c * kCallScratchChunkWords + i]
     hipEvent_t prof_mid; // profiling (evogp_hip_debug_profile): recorded between the compiler and the interpreter launch, or nullptr
     unsigned *marks; // [0] != 0: some tree carries kSentinelHeavy, [1] != 0: some tree carries kSentinelDeep,
                      // [2]: how many of the mark_sample sampled trees were marked heavy (may be nullptr)
@@ -36,7 +37,7 @@ struct SrParams {
 // Threaded-code path (sr_tc.hip): compile the population into fused programs and interpret them with the
 // assembly core.  Returns hipSuccess and sets *handled when it took the launch (trees it could not take are
 // marked kSentinelHeavy / NaN in p.fitness for the follow-up kernels); *handled == false means "not eligible".
-hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled, int *mark_sample);
+hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled, int *mark_sample, int *mark_chunks);
 
 // Tile-group kernel for shapes the register kernels cannot keep resident (sr_wide.hip): STORE mode of batch_evaluate.
 hipError_t launch_wide_store(const SrParams &p, hipStream_t stream);

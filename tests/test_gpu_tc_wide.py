@@ -181,3 +181,22 @@ def test_library_functions_in_the_threaded_code(g, oracle, rng, funcs, out_len):
         ref = ((be - y[None, :, :].astype(np.float64)) ** 2).sum(2).mean(1)
     both = np.isfinite(ref) & ok & (np.abs(ref) < 1e30)
     assert np.allclose(got[both], ref[both], rtol=2e-5, atol=1e-30), "threaded code vs the register kernels on the same trees"
+
+
+def test_chunked_pipeline_on_a_large_population(g, oracle):
+    """a population beyond the sizes of the other tests (and, with EVOGP_TC_CHUNKS set, the chunked two-stream pipeline of
+    sr_tc.hip): the result must equal that of the halves run on their own, and the oracle's on a sample"""
+    pop = 450_000
+    forest = g.generate(pop, 64, 10, 1, 0.5, 0.5, [7, 7], depth2leaf(6), roulette_uniform(ARITH + [SIN, MAX]), CS)
+    X, y = c2_dataset()
+    full = g.sr_fitness(*forest, X, y)
+    h = pop // 2
+    halves = np.concatenate([g.sr_fitness(*(a[:h] for a in forest), X, y), g.sr_fitness(*(a[h:] for a in forest), X, y)])
+    assert np.array_equal(full.view(np.uint32), halves.view(np.uint32))
+    again = g.sr_fitness(*forest, X, y)
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32)), "run-to-run reproducible"
+    pick = np.arange(0, pop, 1013)
+    want = oracle.sr_fitness(*(a[pick] for a in forest), X, y)
+    ok = np.isfinite(want)
+    assert np.array_equal(np.isnan(full[pick]), np.isnan(want))
+    assert (np.abs(full[pick][ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-6).mean() > 0.98   # sin in the set: library vs libm
