@@ -253,6 +253,14 @@ static hipError_t launch_eval_lane(const EvalParams &p, hipStream_t stream) {
     return launch_eval_general<MO>(p, 1, stream);
 }
 
+// the trees a previous kernel marked (kSentinelDeepEval in the first result word) through the stack interpreter
+// (evaluate_prepared.hip leaves what its operation lists cannot express to it)
+hipError_t launch_eval_marked_general(unsigned pop, unsigned gp_len, unsigned var_len, unsigned out_len, const float *value,
+                                      const int16_t *type, const int16_t *size, const float *vars, float *results, hipStream_t stream) {
+    EvalParams p{value, type, size, vars, results, (int)pop, (int)gp_len, (int)var_len, (int)out_len};
+    return out_len > 1 ? launch_eval_general<true>(p, 1, stream) : launch_eval_general<false>(p, 1, stream);
+}
+
 } // namespace evogp
 
 using namespace evogp;

@@ -1,0 +1,201 @@
+// evaluate_prepared.hip — the forward pass of a MULTI-OUTPUT policy population, decoded once and run many times (gfx950).
+//
+// The reference's rollout problems call Forest.forward once per environment step, 1000 times per generation, on the same
+// forest (src/evogp/problem/brax_problem.py:54-93 -> forest.py:112-140 -> treeGPEvalKernel, forward.cu:304-351); every
+// call re-reads and re-interprets all three tree arrays.  For multi-output trees the interpretation is almost all waste:
+// every function node hands its LAST operand on to its parent and only nodes flagged OUT add their result to an output
+// (forward.cu:237-243), so the value a subtree passes upward is the value of its rightmost leaf, an OUT node's operands
+// are leaves, and nothing else in the tree is ever observable.  A policy tree is a short list of
+//
+//        outs[o] += f(leaf, leaf [, leaf])                     in execution (reverse prefix) order
+//
+// evogp_hip_evaluate_prepare builds that list once per forest: 16-byte records {function, output, operand kinds | three
+// operands (variable index or constant)}, record i of tree t at [i][t] so that a wave of 64 trees reads a record with one
+// coalesced 1-KiB access.  evogp_hip_evaluate_prepared runs it: one lane per tree, the 64 input rows of the wave staged
+// through LDS, accumulators in LDS as [output][lane], results written back coalesced.  Per step and tree that is ~16 B per
+// OUT node + the input row + the output row instead of 8 B per NODE three arrays wide — and no decoding, no operand stack.
+// Trees the list cannot express (inconsistent subtree sizes, node types outside the five classes, more OUT nodes than the
+// workspace has rows) are counted by `prepare`; the run then leaves them to the stack interpreter of evaluate.hip.
+#include "interp.hpp"
+#include "launch.hpp"
+
+namespace evogp {
+
+constexpr uint32_t kSentinelDeepEvalP = 0x7FC0DEEDu;  // evaluate.hip: "this tree's row is produced by eval_general_kernel"
+
+struct PrepareParams {
+    const float *value;
+    const int16_t *type;
+    const int16_t *size;
+    uint4 *rec;      // [maxrec][pop]
+    int *count;      // [pop]: records of the tree, -1 malformed (NaN row), -2 left to the stack interpreter
+    int *info;       // [0] number of trees with count -2 (zeroed before the launch)
+    int pop, gp_len, var_len, out_len, maxrec;
+};
+
+__global__ __launch_bounds__(256) void eval_prepare_kernel(PrepareParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int t = wave; t < p.pop; t += nwaves) {
+        const size_t row = (size_t)t * p.gp_len;
+        int len = uni((int)p.size[row]);
+        len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
+        int carry_h = 0, nrec = 0;
+        bool bad = len <= 0, fallback = false;
+        for (int c = (len + 63) / 64 - 1; c >= 0; --c) {  // last chunk first: execution order
+            const int i = c * 64 + lane;
+            const bool in = i < len;
+            const int ty = in ? (int)p.type[row + i] : T_CONST;
+            const float val = in ? p.value[row + i] : 0.0f;
+            const int sz = in ? (int)p.size[row + i] : 1;
+            const int cls = ty & T_MASK;
+            const int arity = cls <= T_CONST ? 0 : (cls <= T_TFUNC ? cls - 1 : 3);  // any other type takes the ternary path (forward.cu:213-224)
+            if (__any(in && cls > T_TFUNC)) fallback = true;
+            const int delta = in ? 1 - arity : 0;
+            const int incl = wave_scan_incl(delta);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            if (__any(in && carry_h + tot - (incl - delta) < 1)) bad = true;
+            carry_h += tot;
+            // operands through the subtree sizes (verified: sizes that do not describe the tree send it to the stack interpreter)
+            const Decoded d = decode_node(ty, val, true, p.var_len, p.out_len);
+            int ci = i + 1, sum = 1;
+            bool ok = true;
+            uint32_t kinds = 0, pay[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (in && a < arity && ok) {
+                    const int sc = ci < len ? (int)p.size[row + ci] : 0;
+                    if (sc < 1 || ci + sc > len) ok = false;
+                    else {
+                        const int leaf = ci + sc - 1;                       // the rightmost leaf of the child subtree: what it passes upward
+                        const int lt = (int)p.type[row + leaf] & T_MASK;
+                        const float lv = p.value[row + leaf];
+                        if (lt > T_CONST) ok = false;
+                        else if (lt == T_CONST) { kinds |= 1u << a; pay[a] = f2bits(lv); }
+                        else { int v = (int)lv; v = v < 0 ? 0 : (v >= p.var_len ? p.var_len - 1 : v); pay[a] = (uint32_t)v; }
+                        sum += sc; ci += sc;
+                    }
+                }
+            }
+            if (__any(in && (!ok || sz != sum))) fallback = true;
+            const bool adds = in && arity > 0 && d.pay != kNoOut && d.op != H_UN_ZERO && d.op != H_BIN_ZERO;  // unknown ids add 0
+            const unsigned long long m = __ballot(adds);
+            const int slot = nrec + (lane >= 63 ? 0 : __popcll(m >> (lane + 1)));  // higher node index first
+            if (adds && slot < p.maxrec)
+                p.rec[(size_t)slot * p.pop + t] = make_uint4(d.op | (d.pay << 8) | (kinds << 16) | ((uint32_t)arity << 20), pay[0], pay[1], pay[2]);
+            nrec += __popcll(m);
+        }
+        if (carry_h != 1) bad = true;
+        if (nrec > p.maxrec) fallback = true;
+        if (lane == 0) {
+            p.count[t] = bad ? -1 : (fallback ? -2 : nrec);
+            if (!bad && fallback) atomicAdd(p.info, 1);
+        }
+    }
+}
+
+struct PreparedParams {
+    const uint4 *rec;
+    const int *count;
+    const float *vars;   // [pop][var_len]
+    float *results;      // [pop][out_len]
+    int pop, var_len, out_len;
+};
+
+__device__ inline float prepared_apply(uint32_t op, float a, float b, float c) {
+    if (op >= H_ADD && op <= H_DIV)
+        return op == H_ADD ? a + b : op == H_SUB ? a - b : op == H_MUL ? a * b : (b == 0.0f ? __builtin_nanf("") : a / b);  // forward.cu:177-187
+    if (op == H_IF) return a > 0.0f ? b : c;
+    if (op >= H_UN) return op_unary<false>(op, a);
+    return op_binary_other<false>(op, a, b);
+}
+
+__global__ __launch_bounds__(64) void eval_prepared_kernel(PreparedParams p) {
+    extern __shared__ float prep_lds[];
+    float *var_s = prep_lds;                    // [var_len][64]
+    float *out_s = var_s + p.var_len * 64;      // [out_len][64]
+    const int lane = threadIdx.x;
+    const int t0 = blockIdx.x * 64;
+    const int t = t0 + lane;
+    const int trees = p.pop - t0 < 64 ? p.pop - t0 : 64;
+    for (int e = lane; e < trees * p.var_len; e += 64) {   // the wave's input rows are one contiguous block
+        const int tr = e / p.var_len, v = e - tr * p.var_len;
+        var_s[v * 64 + tr] = p.vars[(size_t)t0 * p.var_len + e];
+    }
+    for (int o = 0; o < p.out_len; ++o) out_s[o * 64 + lane] = 0.0f;
+    __syncthreads();
+    const int n = t < p.pop ? p.count[t] : 0;
+    for (int i = 0; i < n; ++i) {
+        const uint4 r = p.rec[(size_t)i * p.pop + t];
+        const uint32_t op = r.x & 0xFFu, oi = (r.x >> 8) & 0xFFu, kinds = (r.x >> 16) & 7u, arity = (r.x >> 20) & 3u;
+        const float a = (kinds & 1u) ? bits2f(r.y) : var_s[r.y * 64 + lane];
+        const float b = arity < 2 ? 0.0f : ((kinds & 2u) ? bits2f(r.z) : var_s[r.z * 64 + lane]);
+        const float c = arity < 3 ? 0.0f : ((kinds & 4u) ? bits2f(r.w) : var_s[r.w * 64 + lane]);
+        out_s[oi * 64 + lane] += prepared_apply(op, a, b, c);   // forward.cu:239-240, in execution order
+    }
+    if (n < 0)  // malformed: a NaN row (the reference asserts); left to the stack interpreter: its mark in the first word
+        for (int o = 0; o < p.out_len; ++o) out_s[o * 64 + lane] = (n == -2 && o == 0) ? bits2f(kSentinelDeepEvalP) : __builtin_nanf("");
+    __syncthreads();
+    for (int e = lane; e < trees * p.out_len; e += 64) {
+        const int tr = e / p.out_len, o = e - tr * p.out_len;
+        p.results[(size_t)t0 * p.out_len + e] = out_s[o * 64 + tr];
+    }
+}
+
+hipError_t launch_eval_marked_general(unsigned pop, unsigned gp_len, unsigned var_len, unsigned out_len, const float *value,
+                                      const int16_t *type, const int16_t *size, const float *vars, float *results, hipStream_t stream);
+
+} // namespace evogp
+
+using namespace evogp;
+
+static unsigned prepared_rows(unsigned gp_len) { return gp_len < 64u ? gp_len : 64u; }
+
+extern "C" size_t evogp_hip_evaluate_workspace_bytes(unsigned pop_size, unsigned gp_len) {
+    return (size_t)prepared_rows(gp_len) * pop_size * sizeof(uint4) + (size_t)pop_size * sizeof(int) + 64;
+}
+
+extern "C" int evogp_hip_evaluate_prepare(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                          const float *value, const int16_t *type, const int16_t *size, void *workspace,
+                                          size_t workspace_bytes, evogp_stream_t stream_) {
+    if (pop_size == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len < 2 || out_len > 32 || var_len > 255)
+        return EVOGP_E_BADARG;
+    if (!value || !type || !size || !workspace) return EVOGP_E_NULLPTR;
+    if (workspace_bytes < evogp_hip_evaluate_workspace_bytes(pop_size, gp_len) || ((uintptr_t)workspace & 15u)) return EVOGP_E_BADARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const unsigned maxrec = prepared_rows(gp_len);
+    PrepareParams p{};
+    p.value = value; p.type = type; p.size = size;
+    p.rec = (uint4 *)workspace;
+    p.count = (int *)((char *)workspace + (size_t)maxrec * pop_size * sizeof(uint4));
+    p.info = p.count + pop_size;
+    p.pop = (int)pop_size; p.gp_len = (int)gp_len; p.var_len = (int)var_len; p.out_len = (int)out_len; p.maxrec = (int)maxrec;
+    hipError_t e = hipMemsetAsync(p.info, 0, 64, stream);
+    if (e != hipSuccess) return (int)e;
+    long blocks = ((long)pop_size + 3) / 4;
+    const long cap = (long)device_info().num_cus * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(eval_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                           const float *value, const int16_t *type, const int16_t *size, const void *workspace,
+                                           int with_fallback, const float *variables, float *results, evogp_stream_t stream_) {
+    if (pop_size == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len < 2 || out_len > 32 || var_len > 255)
+        return EVOGP_E_BADARG;
+    if (!value || !type || !size || !workspace || !variables || !results) return EVOGP_E_NULLPTR;
+    hipStream_t stream = (hipStream_t)stream_;
+    const unsigned maxrec = prepared_rows(gp_len);
+    PreparedParams p{};
+    p.rec = (const uint4 *)workspace;
+    p.count = (const int *)((const char *)workspace + (size_t)maxrec * pop_size * sizeof(uint4));
+    p.vars = variables; p.results = results;
+    p.pop = (int)pop_size; p.var_len = (int)var_len; p.out_len = (int)out_len;
+    const size_t lds = (size_t)(var_len + out_len) * 64 * sizeof(float);
+    hipLaunchKernelGGL(eval_prepared_kernel, dim3((pop_size + 63) / 64), dim3(64), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !with_fallback) return (int)e;
+    return (int)launch_eval_marked_general(pop_size, gp_len, var_len, out_len, value, type, size, variables, results, stream);
+}

@@ -239,6 +239,41 @@ Tensor tree_batch_argmax_count(int64_t pop_size, int64_t data_points, int64_t gp
     return counts;
 }
 
+// the operation lists of a multi-output forest (evaluate_prepared.hip): -> (workspace uint8[bytes], info int32[16]; info[0] = trees
+// the lists cannot express, which tree_evaluate_prepared then has to send through the stack interpreter)
+std::tuple<Tensor, Tensor> tree_evaluate_prepare(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t out_len, const Tensor &value,
+                                                 const Tensor &type, const Tensor &size) {
+    check_sizes(pop_size, gp_len);
+    TORCH_CHECK(var_len > 0 && var_len <= 255, "var_len must be in [1, 255], but got ", var_len);
+    TORCH_CHECK(out_len >= 2 && out_len <= 32, "out_len must be in [2, 32], but got ", out_len);
+    const c10::Device dev = value.device();
+    check_forest(pop_size, gp_len, value, type, size, dev);
+    c10::DeviceGuard guard(dev);
+    const int64_t bytes = (int64_t)evogp_hip_evaluate_workspace_bytes((unsigned)pop_size, (unsigned)gp_len);
+    Tensor ws = at::empty({bytes}, at::TensorOptions().dtype(at::kByte).device(dev));
+    const int rc = evogp_hip_evaluate_prepare((unsigned)pop_size, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len, value.data_ptr<float>(),
+                                              type.data_ptr<int16_t>(), size.data_ptr<int16_t>(), ws.data_ptr(), (size_t)bytes, current_stream(dev));
+    check_rc(rc, "tree_evaluate_prepare");
+    Tensor info = ws.narrow(0, bytes - 64, 64).view(at::kInt);
+    return {ws, info};
+}
+
+Tensor tree_evaluate_prepared(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t out_len, const Tensor &value, const Tensor &type,
+                              const Tensor &size, const Tensor &workspace, bool with_fallback, const Tensor &variables) {
+    check_sizes(pop_size, gp_len);
+    const c10::Device dev = value.device();
+    check_forest(pop_size, gp_len, value, type, size, dev);
+    check_tensor(variables, {pop_size, var_len}, "variables", dev, at::kFloat);
+    check_tensor(workspace, {(int64_t)evogp_hip_evaluate_workspace_bytes((unsigned)pop_size, (unsigned)gp_len)}, "workspace", dev, at::kByte);
+    c10::DeviceGuard guard(dev);
+    Tensor results = at::empty({pop_size, out_len}, value.options());
+    const int rc = evogp_hip_evaluate_prepared((unsigned)pop_size, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len, value.data_ptr<float>(),
+                                               type.data_ptr<int16_t>(), size.data_ptr<int16_t>(), workspace.data_ptr(), with_fallback ? 1 : 0,
+                                               variables.data_ptr<float>(), results.data_ptr<float>(), current_stream(dev));
+    check_rc(rc, "tree_evaluate_prepared");
+    return results;
+}
+
 void check_order(const Tensor &order, int64_t need, const c10::Device &dev) {
     TORCH_CHECK(order.is_cuda() && order.is_contiguous() && order.scalar_type() == at::kInt && order.dim() == 1 && order.size(0) >= need &&
                     order.device() == dev,
@@ -337,6 +372,10 @@ TORCH_LIBRARY(evogp_hip, m) {
           " Tensor subtree_size, Tensor variables) -> Tensor results");
     m.def("tree_batch_argmax_count(int pop_size, int data_points, int gp_len, int var_len, int out_len, Tensor value, Tensor node_type,"
           " Tensor subtree_size, Tensor variables, Tensor labels) -> Tensor counts");
+    m.def("tree_evaluate_prepare(int pop_size, int gp_len, int var_len, int out_len, Tensor value, Tensor node_type, Tensor subtree_size)"
+          " -> (Tensor workspace, Tensor info)");
+    m.def("tree_evaluate_prepared(int pop_size, int gp_len, int var_len, int out_len, Tensor value, Tensor node_type, Tensor subtree_size,"
+          " Tensor workspace, bool with_fallback, Tensor variables) -> Tensor results");
     m.def("breed_default(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
           " bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)");
@@ -350,6 +389,8 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("tree_generate_masked", &tree_generate_masked);
     m.impl("tree_batch_evaluate", &tree_batch_evaluate);
     m.impl("tree_batch_argmax_count", &tree_batch_argmax_count);
+    m.impl("tree_evaluate_prepare", &tree_evaluate_prepare);
+    m.impl("tree_evaluate_prepared", &tree_evaluate_prepared);
     m.impl("breed_default", &breed_default);
     m.impl("breed_default_rows", &breed_default_rows);
 }

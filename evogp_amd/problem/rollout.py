@@ -101,10 +101,14 @@ class RolloutProblem(BaseProblem):
         done = torch.zeros(n, dtype=torch.bool, device=dev)
         graph = self.use_graph if self.use_graph is not None else dev.type == "cuda"
         if not graph:
+            forest.prepare_forward()
             for _ in range(self.max_episode_length):
                 state, total, done = self._step(forest, state, total, done)
             return total
-        # capture ONE step on static buffers, replay it max_episode_length times
+        # capture ONE step on static buffers, replay it max_episode_length times.  A multi-output forest is decoded once into its
+        # operation lists first (Forest.prepare_forward: one host sync, not allowed inside the capture): every replayed step
+        # then runs evaluate_prepared.hip instead of re-interpreting the three tree arrays
+        forest.prepare_forward()
         s_state, s_total, s_done = state.clone(), total.clone(), done.clone()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))

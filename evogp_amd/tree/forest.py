@@ -29,6 +29,7 @@ from .descriptor import GenerateDescriptor
 from .tree import Tree
 from .utils import NType, check_tensor
 
+_PREPARED_FORWARD = __import__("os").environ.get("EVOGP_PREPARED_FORWARD", "1") != "0"
 _SR_MODES = {"hybrid parallel": 0, "data parallel": 1, "tree parallel": 2, "auto": 4}  # forest.py:340-347
 
 
@@ -82,11 +83,49 @@ class Forest:
                 self.batch_subtree_size.contiguous())
 
     # ---- evaluation ---------------------------------------------------------------------------
+    def _forest_key(self):
+        v, t, s = self.batch_node_value, self.batch_node_type, self.batch_subtree_size
+        return (v.data_ptr(), t.data_ptr(), s.data_ptr(), v._version, t._version, s._version, self.pop_size, self.max_tree_len)
+
+    def prepare_forward(self):
+        """Decode a multi-output forest once for many ``forward`` calls (a rollout evaluates the same forest once per
+        environment step, src/evogp/problem/brax_problem.py:54-93): the operation lists of csrc/evaluate_prepared.hip.  Returns
+        the cached (workspace, with_fallback) or None when the forest is not eligible.  The cache is keyed on the tensors'
+        identity and version counters, so an in-place edit of the forest invalidates it; ``forward`` calls this itself from
+        its SECOND call on an unchanged forest on (one host sync per preparation: the count of trees left to the stack
+        interpreter)."""
+        v, t, s = self.batch_node_value, self.batch_node_type, self.batch_subtree_size
+        if not (v.is_cuda and 2 <= self.output_len <= 32 and self.input_len <= 255 and v.is_contiguous() and t.is_contiguous() and s.is_contiguous()):
+            return None
+        key = self._forest_key()
+        cached = getattr(self, "_prepared", None)
+        if cached is not None and cached[0] == key:
+            return cached[1], cached[2]
+        ws, info = torch.ops.evogp_hip.tree_evaluate_prepare(self.pop_size, self.max_tree_len, self.input_len, self.output_len, v, t, s)
+        with_fallback = bool(int(info[0]) != 0)
+        self._prepared = (key, ws, with_fallback)
+        return ws, with_fallback
+
     def forward(self, x: Tensor) -> Tensor:
         """One input row per tree: x (pop, input_len) -> (pop, output_len)."""
         x = check_tensor(x, self.batch_node_value.device)
         assert x.shape == (self.pop_size, self.input_len), (
             f"x shape should be ({self.pop_size}, {self.input_len}), but got {x.shape}")
+        # a forest that is evaluated AGAIN unchanged is a policy population inside a rollout: from the second call on it runs
+        # from its operation lists (multi-output forests only; EVOGP_PREPARED_FORWARD=0 switches this off).  Preparing costs a
+        # host sync, so it never happens while the stream is being captured: RolloutProblem prepares before it captures.
+        if self.output_len > 1 and x.is_cuda and _PREPARED_FORWARD:
+            key = self._forest_key()
+            prepared = None
+            cached = getattr(self, "_prepared", None)
+            if cached is not None and cached[0] == key:
+                prepared = cached[1:]
+            elif getattr(self, "_forward_seen", None) == key and not torch.cuda.is_current_stream_capturing():
+                prepared = self.prepare_forward()
+            self._forward_seen = key
+            if prepared is not None:
+                return torch.ops.evogp_hip.tree_evaluate_prepared(self.pop_size, self.max_tree_len, self.input_len, self.output_len,
+                                                                  *self._tensors(), prepared[0], prepared[1], x.contiguous().to(torch.float32))
         return torch.ops.evogp_cuda.tree_evaluate(self.pop_size, self.max_tree_len, self.input_len, self.output_len,
                                                   *self._tensors(), x.contiguous().to(torch.float32))
 

@@ -163,6 +163,24 @@ int evogp_hip_batch_argmax_count(unsigned pop_size, unsigned data_points, unsign
                                  const float *variables, const int *labels, unsigned *counts,
                                  evogp_stream_t stream);
 
+/* Prepared forward pass of a MULTI-OUTPUT population (no counterpart in the reference's ABI).  The
+ * reference's rollout problems call `evaluate` once per environment step on the same forest, 1000 times per generation
+ * (src/evogp/problem/brax_problem.py:54-93).  In multi-output mode only nodes flagged OUT are observable and their operands
+ * are leaves (forward.cu:237-243: every function hands its last operand on), so a tree reduces to a short list of
+ * "outs[o] += f(leaf, leaf)".  _prepare builds the lists once per forest into `workspace` (device memory,
+ * >= evogp_hip_evaluate_workspace_bytes, 16-byte aligned; the last 64 bytes hold an int: the number of trees the lists cannot
+ * express); _prepared evaluates results[n][:] = tree_n(variables[n][:]) from them — same values as evogp_hip_evaluate, bit for
+ * bit (same operations in the same order) — and, when with_fallback != 0, runs the stack interpreter on the trees counted
+ * above (pass 0 only if that count, read back after _prepare, is 0).  out_len in [2, 32], var_len <= 255. */
+size_t evogp_hip_evaluate_workspace_bytes(unsigned pop_size, unsigned gp_len);
+int evogp_hip_evaluate_prepare(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                               const float *value, const int16_t *type, const int16_t *size,
+                               void *workspace, size_t workspace_bytes, evogp_stream_t stream);
+int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                const float *value, const int16_t *type, const int16_t *size,
+                                const void *workspace, int with_fallback,
+                                const float *variables, float *results, evogp_stream_t stream);
+
 /* Average duration in milliseconds of the most recent `evogp_hip_*` launch sequence that was
  * bracketed by evogp_hip_timer_begin/_end on `stream` (hipEvent pair recorded on that stream).
  * Used by bench.py to time the kernel on the stream it is launched on. */

@@ -130,3 +130,26 @@ def batch_argmax_count(value, type_, size, X, labels, out_len):
     assert rc == 0, L.evogp_hip_error_string(rc)
     torch.cuda.synchronize()
     return cnt.cpu().numpy()
+
+
+def evaluate_prepared(value, type_, size, X, out_len, steps=1):
+    """-> (results of the prepared forward pass, number of trees it left to the stack interpreter)"""
+    import ctypes
+
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32)]
+    var_len = a[3].shape[1]
+    nbytes = L.evogp_hip_evaluate_workspace_bytes(pop, gp_len)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    rc = L.evogp_hip_evaluate_prepare(pop, gp_len, var_len, out_len, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), ws.data_ptr(),
+                                      ctypes.c_size_t(nbytes), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    torch.cuda.synchronize()
+    left = int(ws[nbytes - 64:nbytes - 60].view(torch.int32).item())
+    res = torch.full((pop, out_len), 12345.0, dtype=torch.float32, device=DEV)
+    for _ in range(steps):
+        rc = L.evogp_hip_evaluate_prepared(pop, gp_len, var_len, out_len, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), ws.data_ptr(),
+                                           1 if left else 0, a[3].data_ptr(), res.data_ptr(), _stream())
+        assert rc == 0, L.evogp_hip_error_string(rc)
+    torch.cuda.synchronize()
+    return res.cpu().numpy(), left
