@@ -56,26 +56,70 @@ def _unpack(buf: torch.Tensor, L: int, input_len: int, output_len: int) -> Fores
     return Forest(input_len, output_len, value, ntype, size)
 
 
-def plan_exchange(fit_all: torch.Tensor, n_keep: int, world: int):
-    """From the gathered fitness of the whole population (rank-major): which trees are kept (the best ``n_keep`` in stable
-    descending order), where each lands in the gathered table, and the ranking expressed in table positions.
-    -> (per_rank bool[world][n_local], cap, order int32[n_keep] of table rows).  ``cap`` is the one host sync."""
+def _sort_key(fit: torch.Tensor) -> torch.Tensor:
+    """float32 -> int64 key with the same order (NaN-free input); every real key is > 0, so 0 can mark padding rows"""
+    u = fit.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return torch.where(u >= 0x80000000, 0xFFFFFFFF - u, u + 0x80000000) + 1
+
+
+def select_kept(fit_all: torch.Tensor, n_keep: int) -> torch.Tensor:
+    """bool[pop]: the best n_keep trees in stable descending order of fitness (ties: lower global index first) WITHOUT
+    sorting the population: the k-th largest value comes from a radix select (torch.kthvalue), the rest is elementwise.
+    Every rank runs this on the identical gathered vector; the work is O(pop) streaming, not an O(pop log pop) sort of
+    keys and indices."""
     pop = fit_all.shape[0]
-    n_local = pop // world
-    dev = fit_all.device
-    order_g = torch.sort(fit_all, descending=True, stable=True).indices[:n_keep]
-    keep = torch.zeros(pop, dtype=torch.bool, device=dev)
-    keep[order_g] = True
-    per_rank = keep.view(world, n_local)
+    if n_keep >= pop:
+        return torch.ones(pop, dtype=torch.bool, device=fit_all.device)
+    thr = -torch.kthvalue(-fit_all, n_keep).values               # the n_keep-th largest fitness
+    above = fit_all > thr
+    ties = fit_all == thr
+    room = n_keep - above.sum()                                   # how many of the tied trees still fit (device scalar)
+    return above | (ties & (torch.cumsum(ties.to(torch.int64), 0) <= room))
+
+
+def plan_exchange(fit_all: torch.Tensor, n_keep: int, world: int):
+    """From the gathered fitness of the whole population (rank-major): which trees are kept and how many rows every rank
+    contributes.  -> (per_rank bool[world][n_local], cap).  ``cap`` — the largest number of kept trees on any rank, the row
+    count every rank pads its block to — is the step's one host sync (eight integers); a bound that needs none would have to
+    be min(n_local, n_keep), i.e. gather the whole population at world sizes where n_keep > n_local."""
+    pop = fit_all.shape[0]
+    per_rank = select_kept(fit_all, n_keep).view(world, pop // world)
     cap = int(per_rank.sum(1).max())
-    within = torch.cumsum(per_rank.to(torch.int64), dim=1) - 1
-    pos = (torch.arange(world, device=dev)[:, None] * cap + within).view(pop)
-    return per_rank, cap, pos[order_g].to(torch.int32).contiguous()
+    return per_rank, cap
 
 
 def kept_rows(mine: torch.Tensor, cap: int) -> torch.Tensor:
     """local indices of this rank's kept trees in ascending order, padded with other local trees up to ``cap`` rows"""
     return torch.argsort((~mine).to(torch.int8), stable=True)[:cap]
+
+
+def table_order(table_key: torch.Tensor, n_keep: int) -> torch.Tensor:
+    """ranking of the gathered table (rank-major, within a rank ascending tree index, padding rows key 0): stable descending
+    sort of the kept trees' keys = the order a stable descending sort of the whole population gives them"""
+    return torch.sort(table_key, descending=True, stable=True).indices[:n_keep].to(torch.int32).contiguous()
+
+
+# ---- counter-based random words ------------------------------------------------------------------------------------------
+# Every rank needs the six random words of ITS offspring only, and all ranks must agree on the words of offspring i whatever the
+# world size.  A generator with a running state forces every rank to draw the words of the whole generation (24 MB per rank and
+# generation at 1 M trees); here word k of offspring i of generation g is a hash of (seed, g, k, i) — the splitmix64 finaliser
+# in wrap-around int64 arithmetic — so a rank computes exactly its slice.
+_M1, _M2 = -4658895280553007687, -7723592293110705685    # 0xBF58476D1CE4E5B9, 0x94D049BB133111EB as signed 64-bit
+
+
+def _mix64(x: torch.Tensor) -> torch.Tensor:
+    x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * _M1
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * _M2
+    return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+
+def random_words(seed: int, generation: int, rows: int, lo: int, hi: int, device) -> torch.Tensor:
+    """int32[rows][hi - lo]: word k of offspring i in [lo, hi), uniform in [0, 2^31 - 1) like torch.randint(0, 2^31 - 1)"""
+    i = torch.arange(lo, hi, dtype=torch.int64, device=device)[None, :]
+    k = torch.arange(rows, dtype=torch.int64, device=device)[:, None]
+    base = _mix64(torch.tensor([seed * 1000003 + generation], dtype=torch.int64, device=device))
+    x = _mix64(base + (k << 40) + i)
+    return (((x >> 33) & 0x7FFFFFFF) % (2**31 - 1)).to(torch.int32)
 
 
 class ShardedGeneticProgramming:
@@ -98,8 +142,10 @@ class ShardedGeneticProgramming:
         self.n_local = local_forest.pop_size
         self.pop_size = self.n_local * self.world
         dev = local_forest.batch_node_value.device
+        self.seed = seed
+        self.generation = 0
         self.gen = torch.Generator(device=dev)
-        self.gen.manual_seed(seed)  # identical on every rank: all index draws agree
+        self.gen.manual_seed(seed)  # identical on every rank: the draws of the torch composition (slice_torch) agree
 
     # -- the exchange step -------------------------------------------------------------------------
     def exchange(self, local_fitness: torch.Tensor):
@@ -113,11 +159,16 @@ class ShardedGeneticProgramming:
             return f, order, self.pop_size
         fit_all = torch.empty(self.pop_size, dtype=torch.float32, device=fit.device)
         dist.all_gather_into_tensor(fit_all, fit, group=self.group)
-        per_rank, cap, order = plan_exchange(fit_all, n_keep, self.world)
-        send = _pack(f, kept_rows(per_rank[self.rank], cap))
+        per_rank, cap = plan_exchange(fit_all, n_keep, self.world)
+        mine = per_rank[self.rank]
+        rows = kept_rows(mine, cap)
+        # a kept row travels with its sort key (8 bytes in front of the 8 L bytes of the tree); padding rows carry key 0
+        key = torch.where(mine[rows], _sort_key(fit[rows]), torch.zeros(cap, dtype=torch.int64, device=fit.device))
+        send = torch.cat([key.view(torch.uint8).view(cap, 8), _pack(f, rows)], dim=1).contiguous()
         table = torch.empty((self.world * cap, send.shape[1]), dtype=torch.uint8, device=send.device)
         dist.all_gather_into_tensor(table, send, group=self.group)
-        return _unpack(table, f.max_tree_len, f.input_len, f.output_len), order, self.pop_size
+        order = table_order(table[:, :8].contiguous().view(torch.int64).view(-1), n_keep)
+        return _unpack(table[:, 8:], f.max_tree_len, f.input_len, f.output_len), order, self.pop_size
 
     def step(self, local_fitness: torch.Tensor) -> Forest:
         assert local_fitness.shape == (self.n_local,)
@@ -128,6 +179,7 @@ class ShardedGeneticProgramming:
             self.forest = self.slice_native(table, order, pop, lo, hi)
         else:
             self.forest = self.slice_torch(table, order, pop, lo, hi)
+        self.generation += 1
         return self.forest
 
     def _order_of(self, full: Forest, fitness: torch.Tensor) -> torch.Tensor:
@@ -152,13 +204,16 @@ class ShardedGeneticProgramming:
         L = full.max_tree_len
         n_elite, n_surv = self.selection.counts(pop)
         n_new = pop - n_elite
-        g = self.gen
-        rnd = torch.randint(0, 2**31 - 1, (6, n_new), generator=g, device=dev, dtype=torch.int32)
-        keys = torch.randint(0, 1000000, (2,), generator=g, device=dev).to(torch.uint32)
         below = int(min(max(self.mutation_rate, 0.0), 1.0) * (2**31 - 1))
         d = self.descriptor
         rows = hi - lo
         o_lo, o_hi = max(lo, n_elite) - n_elite, max(hi, n_elite) - n_elite   # my offspring indices
+        # the words of MY offspring only (the breeding pass indexes the array by offspring number: the other columns are
+        # never read and stay uninitialised), and this generation's two generation keys
+        rnd = torch.empty((6, n_new), dtype=torch.int32, device=dev)
+        if o_hi > o_lo:
+            rnd[:, o_lo:o_hi] = random_words(self.seed, self.generation, 6, o_lo, o_hi, dev)
+        keys = (random_words(self.seed, self.generation, 8, 0, 2, dev)[7].to(torch.int64) % 1000000).to(torch.uint32)   # row 7: not an offspring word
         if o_hi > o_lo:
             donors = torch.ops.evogp_hip.tree_generate_masked(
                 o_hi - o_lo, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,

@@ -220,15 +220,20 @@ def test_sharded_native_step_union_equals_single_device(g):
                                b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), f"G = {G}"
     # the exchange of a sharded run gathers only the trees that can be parents or elites: the slices built from that
     # compact table (ranking expressed in table rows) are the same rows again
-    from evogp_amd.parallel import _pack, _unpack, kept_rows, plan_exchange
+    from evogp_amd.parallel import _pack, _sort_key, _unpack, kept_rows, plan_exchange, table_order
 
     for G in (2, 8):
         n_local = pop // G
         sel = DefaultSelection(0.3, elite_rate=0.01)
         n_elite, n_surv = sel.counts(pop)
-        per_rank, cap, order = plan_exchange(fitness, max(n_elite, n_surv), G)
+        n_keep = max(n_elite, n_surv)
+        per_rank, cap = plan_exchange(fitness, n_keep, G)
         assert cap < n_local
-        table = _unpack(torch.cat([_pack(full[r * n_local:(r + 1) * n_local], kept_rows(per_rank[r], cap)) for r in range(G)]), 64, 5, 1)
+        rows = [kept_rows(per_rank[r], cap) for r in range(G)]
+        table = _unpack(torch.cat([_pack(full[r * n_local:(r + 1) * n_local], rows[r]) for r in range(G)]), 64, 5, 1)
+        keys = torch.cat([torch.where(per_rank[r][rows[r]], _sort_key(fitness[r * n_local:(r + 1) * n_local][rows[r]]),
+                                      torch.zeros(cap, dtype=torch.int64, device=dev)) for r in range(G)])
+        order = table_order(keys, n_keep)
         parts = []
         for r in range(G):
             sg = ShardedGeneticProgramming(full[:n_local], 0.2, desc.update(max_layer_cnt=3), sel, seed=5)
