@@ -34,6 +34,7 @@ PROTOTYPES = {
     "evogp_hip_batch_argmax_count": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_evaluate_prepare": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_size_t, _vp],
     "evogp_hip_evaluate_prepared": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "evogp_hip_random_words": [C.c_longlong, C.c_longlong, _i, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp],
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
     "evogp_hip_debug_set_stats": [_vp],

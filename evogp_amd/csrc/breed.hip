@@ -314,3 +314,37 @@ extern "C" int evogp_hip_breed_default_table(int pop_size, int table_rows, int g
     hipLaunchKernelGGL(breed_kernel, dim3((unsigned)blocks), dim3(kRepBlock), lds, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
+
+// ---- counter-based random words -----------------------------------------------------------------------------------------------
+// Word k of offspring i of generation g is a hash of (seed, g, k, i): the splitmix64 finaliser, the same arithmetic as
+// evogp_amd/parallel.py random_words (which serves the CPU paths and the tests).  A rank of a sharded run fills exactly the
+// columns of its own offspring; every rank computes the same word for the same offspring whatever the world size.
+namespace evogp {
+__host__ __device__ inline unsigned long long mix64(unsigned long long x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void random_words_kernel(unsigned long long base, int rows, long long n_cols, long long lo, long long hi, int *out) {
+    const long long n = hi - lo;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n * rows; e += (long long)gridDim.x * blockDim.x) {
+        const long long k = e / n, i = lo + (e - k * n);
+        const unsigned long long x = mix64(base + ((unsigned long long)k << 40) + (unsigned long long)i);
+        out[k * n_cols + i] = (int)(((x >> 33) & 0x7FFFFFFFull) % 0x7FFFFFFFull);
+    }
+}
+}  // namespace evogp
+
+extern "C" int evogp_hip_random_words(long long seed, long long generation, int rows, long long n_cols, long long lo, long long hi,
+                                      int *out, evogp_stream_t stream) {
+    if (rows <= 0 || n_cols <= 0 || lo < 0 || hi > n_cols || lo > hi) return EVOGP_E_BADARG;
+    if (!out) return EVOGP_E_NULLPTR;
+    if (hi == lo) return EVOGP_OK;
+    const unsigned long long base = evogp::mix64((unsigned long long)(seed * 1000003ll + generation));
+    const long long n = (hi - lo) * rows;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(evogp::random_words_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, base, rows, n_cols, lo, hi, out);
+    return (int)hipGetLastError();
+}

@@ -1166,7 +1166,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a("v_mov_b32 v4, v3")                             # labels of output 0, this tile
     a(f"s_add_u32 s{T1}, s{sTILE}, 1")
     a(f"s_cmp_lt_u32 s{T1}, s15")
-    a(f"s_cselect_b32 s{T1}, 0, s17")                 # flag bit 1 (ragged) counts only on the last tile
+    a(f"s_cselect_b32 s{T1}, 0, s17")                 # flag bit 1 (ragged) counts only on the last tile ...
+    a("s_bitcmp1_b32 s17, 4")
+    a(f"s_cselect_b32 s{T1}, s17, s{T1}")             # ... or on every tile (bit 4: a piece of a dataset that is run in pieces)
     a(f"s_and_b32 s{T1}, s{T1}, 2")
     a(f"{lab('endmo_loop')}:")
     read_bank(T, 4)
@@ -1220,7 +1222,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             pass
         a(f"s_add_u32 s{T1}, s{sTILE}, 1")
         a(f"s_cmp_lt_u32 s{T1}, s15")
-        a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile
+        a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile ...
+        a("s_bitcmp1_b32 s17, 4")
+        a(f"s_cselect_b32 s{T2}, s17, s{T2}")  # ... unless bit 4 says that any tile of this launch can reach past its rows
         a(f"s_and_b32 s{T2}, s{T2}, 2")
         a("s_waitcnt lgkmcnt(0)")
         a(f"s_cmp_eq_u32 s{T2}, 0")
@@ -1303,6 +1307,27 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_cmp_eq_u64 s[{sOK}:{sOK + 1}], 0")
     a(f"s_cbranch_scc1 {lab('batch')}")
     a(f"s_mov_b64 exec, s[{sOK}:{sOK + 1}]")
+    # A dataset larger than LDS is run in pieces, one launch per piece: flags bit 2 = add this piece's sums to what the fitness
+    # words hold (a word that holds the register kernels' sentinel -- a run-time bail-out in an earlier piece -- keeps it),
+    # bit 3 = store the sum itself (the mean is taken behind the last piece, by tc_scale_kernel).
+    a(f"v_add_u32 v4, s{sT0}, v0")
+    a("v_lshlrev_b32 v4, 2, v4")
+    a("s_bitcmp0_b32 s17, 2")
+    a(f"s_cbranch_scc1 {lab('fin_first')}")
+    a("global_load_dword v5, v4, s[10:11]")
+    a(f"s_mov_b32 s{T1}, {hex(SENTINEL_HEAVY)}")
+    a("s_waitcnt vmcnt(0)")
+    a("v_add_f32 v7, v5, v7")
+    a(f"v_cmp_eq_u32 vcc, s{T1}, v5")
+    a("s_nop 1")
+    a("v_cndmask_b32 v7, v7, v5, vcc")
+    a(f"{lab('fin_first')}:")
+    a("s_bitcmp0_b32 s17, 3")
+    a(f"s_cbranch_scc1 {lab('fin_mean')}")
+    a("global_store_dword v4, v7, s[10:11]")
+    a("s_mov_b64 exec, -1")
+    a(f"s_branch {lab('batch')}")
+    a(f"{lab('fin_mean')}:")
     a("v_cvt_f32_u32 v9, s13")
     d3, d4, d6, d7, d8 = DT
     a(f"v_div_scale_f32 v{d3}, s[{T1}:{T2}], v9, v9, v7")
@@ -1316,8 +1341,6 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"v_fma_f32 v{d3}, -v{d3}, v{d7}, v{d6}")
     a(f"v_div_fmas_f32 v{d3}, v{d3}, v{d4}, v{d7}")
     a(f"v_div_fixup_f32 v{d3}, v{d3}, v9, v7")
-    a(f"v_add_u32 v4, s{sT0}, v0")
-    a("v_lshlrev_b32 v4, 2, v4")
     a(f"global_store_dword v4, v{d3}, s[10:11]")
     a("s_mov_b64 exec, -1")
     a(f"s_branch {lab('batch')}")

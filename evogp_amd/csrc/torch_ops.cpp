@@ -274,6 +274,17 @@ Tensor tree_evaluate_prepared(int64_t pop_size, int64_t gp_len, int64_t var_len,
     return results;
 }
 
+// int32[rows][n_cols] whose columns [lo, hi) hold the counter-based random words of (seed, generation) (breed.hip); the other
+// columns are uninitialised
+Tensor random_words(int64_t seed, int64_t generation, int64_t rows, int64_t n_cols, int64_t lo, int64_t hi, c10::Device device) {
+    TORCH_CHECK(device.is_cuda(), "random_words: the native generator runs on the GPU");
+    TORCH_CHECK(rows > 0 && n_cols > 0 && lo >= 0 && lo <= hi && hi <= n_cols, "random_words: column range out of the array");
+    c10::DeviceGuard guard(device);
+    Tensor out = at::empty({rows, n_cols}, at::TensorOptions().dtype(at::kInt).device(device));
+    check_rc(evogp_hip_random_words(seed, generation, (int)rows, n_cols, lo, hi, out.data_ptr<int>(), current_stream(out.device())), "random_words");
+    return out;
+}
+
 void check_order(const Tensor &order, int64_t need, const c10::Device &dev) {
     TORCH_CHECK(order.is_cuda() && order.is_contiguous() && order.scalar_type() == at::kInt && order.dim() == 1 && order.size(0) >= need &&
                     order.device() == dev,
@@ -376,6 +387,7 @@ TORCH_LIBRARY(evogp_hip, m) {
           " -> (Tensor workspace, Tensor info)");
     m.def("tree_evaluate_prepared(int pop_size, int gp_len, int var_len, int out_len, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor workspace, bool with_fallback, Tensor variables) -> Tensor results");
+    m.def("random_words(int seed, int generation, int rows, int n_cols, int lo, int hi, Device device) -> Tensor");
     m.def("breed_default(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
           " bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)");
@@ -383,6 +395,8 @@ TORCH_LIBRARY(evogp_hip, m) {
           " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
           " int row_begin, int row_count) -> (Tensor value, Tensor node_type, Tensor subtree_size)");
 }
+
+TORCH_LIBRARY_IMPL(evogp_hip, CompositeExplicitAutograd, m) { m.impl("random_words", &random_words); }  // no tensor argument to dispatch on
 
 TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("tree_generate_offset", &tree_generate_offset);

@@ -210,10 +210,8 @@ class ShardedGeneticProgramming:
         o_lo, o_hi = max(lo, n_elite) - n_elite, max(hi, n_elite) - n_elite   # my offspring indices
         # the words of MY offspring only (the breeding pass indexes the array by offspring number: the other columns are
         # never read and stay uninitialised), and this generation's two generation keys
-        rnd = torch.empty((6, n_new), dtype=torch.int32, device=dev)
-        if o_hi > o_lo:
-            rnd[:, o_lo:o_hi] = random_words(self.seed, self.generation, 6, o_lo, o_hi, dev)
-        keys = (random_words(self.seed, self.generation, 8, 0, 2, dev)[7].to(torch.int64) % 1000000).to(torch.uint32)   # row 7: not an offspring word
+        rnd = torch.ops.evogp_hip.random_words(self.seed, self.generation, 6, n_new, o_lo, o_hi, dev)   # one launch, this rank's columns
+        keys = (torch.ops.evogp_hip.random_words(self.seed, self.generation, 8, 2, 0, 2, dev)[7] % 1000000).to(torch.uint32)   # row 7: not an offspring word
         if o_hi > o_lo:
             donors = torch.ops.evogp_hip.tree_generate_masked(
                 o_hi - o_lo, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,

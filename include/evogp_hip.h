@@ -144,6 +144,13 @@ int evogp_hip_breed_default_table(int pop_size, int table_rows, int gp_len, int 
                                   const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
                                   int *decisions, int row_begin, int row_count, evogp_stream_t stream);
 
+/* Counter-based random words for the breeding pass of a sharded run (no counterpart in the reference, which draws with
+ * torch's generator): out[k][i] for k < rows, i in [lo, hi) = hash(seed, generation, k, i) mapped to [0, 2^31 - 1), the value
+ * evogp_amd/parallel.py random_words computes on any device; out: i32[rows][n_cols], only columns [lo, hi) are written.  Every
+ * rank fills the columns of its own offspring; equal arguments give equal words on every rank and for every world size. */
+int evogp_hip_random_words(long long seed, long long generation, int rows, long long n_cols, long long lo, long long hi,
+                           int *out, evogp_stream_t stream);
+
 /* Non-replicating batch evaluation (replaces the repeat_interleave + tree_evaluate
  * composition of src/evogp/tree/forest.py:143-176): results[t][d][:] = tree_t(variables[d][:]),
  * variables: f32[D][var_len], results: f32[pop][D][out_len]. */

@@ -246,3 +246,20 @@ def test_sharded_native_step_union_equals_single_device(g):
     sg = ShardedGeneticProgramming(full, 0.2, desc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=5)
     nxt = sg.next_slice_torch(full, fitness, 0, pop)
     assert nxt.pop_size == pop
+
+
+def test_native_random_words_equal_the_python_definition(g):
+    """csrc/breed.hip random_words_kernel vs evogp_amd/parallel.py random_words (the CPU paths and the gloo test use the latter):
+    the same hash of (seed, generation, word, offspring), a slice equals the same columns of the whole"""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.parallel import random_words
+
+    dev = torch.device("cuda", 0)
+    for seed, gen, n, lo, hi in ((0, 0, 1000, 0, 1000), (1234, 7, 99_000, 12_345, 40_000), (2**40 + 3, 123456, 5000, 4999, 5000)):
+        nat = torch.ops.evogp_hip.random_words(seed, gen, 6, n, lo, hi, dev)
+        ref = random_words(seed, gen, 6, lo, hi, "cpu")
+        assert torch.equal(nat[:, lo:hi].cpu(), ref)
+        assert int(ref.min()) >= 0 and int(ref.max()) < 2**31 - 1
+    assert abs(float(random_words(5, 5, 6, 0, 200_000, "cpu").float().mean()) / 2**31 - 0.5) < 0.005

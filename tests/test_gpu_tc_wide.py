@@ -200,3 +200,30 @@ def test_chunked_pipeline_on_a_large_population(g, oracle):
     ok = np.isfinite(want)
     assert np.array_equal(np.isnan(full[pick]), np.isnan(want))
     assert (np.abs(full[pick][ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-6).mean() > 0.98   # sin in the set: library vs libm
+
+
+@pytest.mark.parametrize("D,var_len,out_len,funcs", [(5000, 10, 1, ARITH), (12000, 10, 1, ARITH), (20001, 6, 1, ARITH + [MAX, NEG]), (6000, 8, 4, ARITH),
+                                                      (3000, 40, 1, ARITH), (9000, 10, 1, ARITH + [SIN, TAN])])
+def test_datasets_larger_than_lds_run_in_pieces(g, oracle, rng, D, var_len, out_len, funcs):
+    """the dataset of a call lives in LDS (150 KiB); a larger one is run in pieces over the same programs, the interpreter adding
+    each piece's error sums to the fitness words (sr_tc.hip run_tc, gen_tc_asm.py batch finalisation).  The last piece is
+    ragged on every tile.  With tan in the set a tree can bail out to the register kernels in ANY piece."""
+    pop = 1500
+    forest = oracle.generate(pop, 64, var_len, out_len, 0.5, 0.5, [D % 1000, var_len], depth2leaf(5, 0.15), roulette_uniform(funcs), CS)
+    X = rng.uniform(-3, 3, (D, var_len)).astype(np.float32); y = rng.uniform(-3, 3, (D, out_len)).astype(np.float32)
+    if SIN in funcs:
+        X[D - 50:, 0] = 3e5   # beyond 2^17 in the LAST piece only: run-time bail-out after earlier pieces stored partial sums
+    for mse in (True, False):
+        got = g.sr_fitness(*forest, X, y, mse)
+        if mse:
+            h = handler_histogram(g, pop)
+            assert h["skip"] <= 0.02 * pop, f"{h['skip']} trees left to the register kernels: the pieces path was not taken"
+        want = oracle.sr_fitness(*forest, X, y, mse)
+        if SIN in funcs:
+            ok = np.isfinite(want)
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            # (operands of 3e5: one ulp of the operand is 0.03 rad, so the device library and the host libm differ visibly on the
+            # trees that see them; function-level accuracy is pinned in test_gpu_ulp.py, here the pieces / bail-out mechanics)
+            assert (np.abs(got[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-6).mean() > 0.9
+        else:
+            assert_close_classes(got, want, RTOL, what=f"D={D} mse={mse}")
