@@ -243,10 +243,79 @@ def test_sr_fitness_c2_config_subset_and_kernel_types(g, oracle):
     assert np.array_equal(bits(g.sr_fitness(*forest, X, y, True, 0)), bits(got)), "run-to-run reproducible"
 
 
-def test_sr_fitness_paper_function_set(g, oracle):
-    forest = oracle.generate(4000, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform(PAPER7), CS3)
+def _per_tree_tolerance(oracle, forest, X, y, base_rtol=1e-5, ulps=3, seeds=4):
+    """How far may a tree's fitness move when every libm-backed function result moves by up to `ulps` ulp?  The device library and
+    the host libm both stay within ~2 ulp of the true value (tests/test_gpu_ulp.py pins the device side), so two correct
+    evaluations of a tree differ by at most what such a perturbation does to THAT tree: well-conditioned trees must agree to
+    1e-5, tan(tan(x)) may not.  The oracle's sensitivity probe (evogp_oracle_set_jitter) measures it per tree."""
+    want = oracle.sr_fitness(*forest, X, y)
+    spread = np.zeros_like(want, dtype=np.float64)
+    unstable = np.zeros(want.shape, bool)
+    try:
+        for seed in range(seeds):
+            oracle.set_jitter(ulps, 1000 + seed)
+            j = oracle.sr_fitness(*forest, X, y)
+            with np.errstate(all="ignore"):
+                spread = np.maximum(spread, np.nan_to_num(np.abs(j.astype(np.float64) - want), nan=0.0, posinf=0.0))
+            unstable |= (np.isnan(j) != np.isnan(want)) | (np.isinf(j) != np.isinf(want))   # the class itself hangs on an ulp
+    finally:
+        oracle.set_jitter(0)
+    return want, base_rtol * np.abs(want.astype(np.float64)) + 2.0 * spread, unstable
+
+
+@pytest.mark.parametrize("funcs,name", [(PAPER7, "paper7"), ([1, 2, 3, 4, 20, 22, 6], "exp-log-pow"), ([1, 2, 20, 27, 6, 4, 23], "vis.ipynb")])
+def test_sr_fitness_library_function_sets_per_tree_tolerance(g, oracle, funcs, name):
+    """trees of sin cos tan / exp log pow against the oracle (host libm): EVERY tree within 1e-5 relative plus twice the
+    spread a 3-ulp perturbation of its library calls produces in the oracle itself — no allowed-bad fraction.  Trees whose NaN /
+    inf class flips under that perturbation are compared by class membership only."""
+    forest = oracle.generate(4000, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform(funcs), CS3)
     X, y = c2_dataset()
-    _assert_mostly_close(g.sr_fitness(*forest, X, y), oracle.sr_fitness(*forest, X, y), RTOL_TRANS, ATOL_TRANS, "paper7")
+    got = g.sr_fitness(*forest, X, y).astype(np.float64)
+    want, tol, unstable = _per_tree_tolerance(oracle, forest, X, y)
+    stable = ~unstable
+    assert unstable.mean() < 0.1, f"{name}: {unstable.sum()} trees have an ulp-dependent NaN/inf class"
+    assert np.array_equal(np.isnan(got[stable]), np.isnan(want[stable])), f"{name}: NaN sets differ on ulp-stable trees"
+    fin = stable & np.isfinite(want)
+    assert np.isfinite(got[fin]).all(), f"{name}: non-finite result for an ulp-stable finite tree"
+    err = np.abs(got[fin] - want[fin])
+    worst = np.argmax(err - tol[fin])
+    assert (err <= tol[fin]).all(), (f"{name}: tree {np.flatnonzero(fin)[worst]} off by {err[worst]:.6g} (fitness {want[fin][worst]:.6g}, "
+                                     f"granted {tol[fin][worst]:.6g}); {(err > tol[fin]).sum()} trees beyond their own sensitivity")
+    # the grant must not be a blank cheque: for a good share of the finite trees it is the 1e-5 bar itself, give or take the
+    # rounding of the perturbed runs
+    tight = (tol[fin] <= 1e-4 * np.abs(want[fin]) + 1e-12).mean()
+    assert tight > 0.3, f"{name}: the granted tolerance is below 1e-4 relative for only {tight:.0%} of the finite trees"
+
+
+def test_sr_fitness_full_c2_forest_against_the_oracle(g, oracle):
+    """BASELINE configs[1] in full: all 100 000 trees x 1024 datapoints against the oracle at the north-star tolerance"""
+    forest = oracle.generate(100_000, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform(ARITH), CS3)
+    X, y = c2_dataset()
+    assert_close_classes(g.sr_fitness(*forest, X, y), oracle.sr_fitness(*forest, X, y), RTOL_ARITH, what="C2 full")
+
+
+def test_sr_fitness_evolved_forest_against_the_oracle(g, oracle, rng):
+    """a population after 30 generations of the default GP loop (trees grow towards the length cap, deeper operand stacks,
+    constants folded through several levels): fitness against the oracle at 1e-5"""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6, const_samples=[-1, 0, 1])
+    forest = Forest.random_generate(20_000, desc, keys=torch.tensor([42, 0], dtype=torch.uint32, device=dev))
+    X, y = c2_dataset()
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, desc.update(max_layer_cnt=3)), DefaultSelection(0.3, elite_rate=0.01))
+    for _ in range(30):
+        f = -algo.forest.SR_fitness(Xd, yd)
+        algo.step(torch.where(torch.isnan(f), torch.full_like(f, float("-inf")), f))
+    f = algo.forest
+    trees = (f.batch_node_value.cpu().numpy(), f.batch_node_type.cpu().numpy(), f.batch_subtree_size.cpu().numpy())
+    assert trees[2][:, 0].mean() > 35, "the population did not grow: not the evolved-forest case"
+    assert_close_classes(g.sr_fitness(*trees, X, y), oracle.sr_fitness(*trees, X, y), RTOL_ARITH, what="generation 30")
 
 
 def test_full_size_properties(g, oracle):
