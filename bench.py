@@ -302,7 +302,7 @@ def main():
                                       "to ieee on this workload), ieee = correctly rounded always, fast = no range scaling"}
 
         from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
-        from evogp_amd.tree import GenerateDescriptor
+        from evogp_amd.tree import Forest, GenerateDescriptor
 
         mdesc = GenerateDescriptor(max_tree_len=GP_LEN, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/"],
                                    max_layer_cnt=3, const_samples=[-1, 0, 1])
@@ -354,6 +354,32 @@ def main():
                               "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
         }
 
+    if not args.headline_only and rank == 0:
+        # the reference's only published timing: test/vis.ipynb:12-45,171,181 -- XOR-3d, pop 100 000, max_tree_len 128, 8 datapoints,
+        # functions + - log sqrt pow / inv, max_layer_cnt 2, default operators: 14-21 ms per generation on an unnamed NVIDIA GPU
+        try:
+            vdesc = GenerateDescriptor(max_tree_len=128, input_len=3, output_len=1, using_funcs=["+", "-", "log", "sqrt", "pow", "/", "inv"],
+                                       max_layer_cnt=2, const_samples=[-1, 0, 1])
+            vX = torch.tensor([[a, b, c] for a in (0., 1.) for b in (0., 1.) for c in (0., 1.)], device=device)
+            vy = (vX.sum(1) % 2)[:, None].contiguous()
+            vf = Forest.random_generate(100_000, vdesc, keys=torch.tensor([42, 0], dtype=torch.uint32, device=device))
+            valgo = GeneticProgramming(vf, DefaultCrossover(), DefaultMutation(0.2, vdesc), DefaultSelection(0.3, elite_rate=0.01))
+            vms, vlen = [], []
+            vneg = torch.full((100_000,), float("-inf"), dtype=torch.float32, device=device)
+            for g_ in range(40):
+                torch.cuda.synchronize(); g0 = time.perf_counter()
+                f = -valgo.forest.SR_fitness(vX, vy, True, "auto")
+                valgo.step(torch.where(torch.isnan(f), vneg, f))
+                torch.cuda.synchronize(); vms.append((time.perf_counter() - g0) * 1000)
+                if g_ in (0, 39):
+                    vlen.append(float(valgo.forest.batch_subtree_size[:, 0].float().mean()))
+            extras["vis_ipynb_config"] = {
+                "workload": "test/vis.ipynb:171,181: XOR-3d SR, pop 100k, max_tree_len 128, 8 datapoints, funcs + - log sqrt pow / inv, default operators",
+                "generation_ms": {"median_gen_10_39": float(np.median(vms[10:])), "first": vms[0], "max_after_warmup": float(max(vms[2:]))},
+                "mean_tree_len_first_last": vlen, "reference_published_ms": "14-21 (hardware not stated)"}
+        except Exception as exc:
+            extras["vis_ipynb_config"] = {"error": repr(exc)[:300]}
+
     if rank == 0:
         evals = float(P) * DATAPOINTS * args.steps
         kernel_s = stage_ms["interpreter"] / 1e3 if stage_ms["calls"] else call_ms / 1e3
@@ -396,7 +422,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_note": traffic_note,
-                "kernel": "sr_tc_kernel<8,false,2> (threaded-code interpreter, short division), rank 0's launch",
+                "kernel": "sr_tc_kernel<8,false,2> (threaded-code interpreter, short division), rank 0's launch; algorithmic bytes = SURVEY.md §8d "
+                          "(6 B per live node + size + dataset + fitness) x the trees of the launch",
                 "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
                 "call_ms": call_ms, "stage_ms": stage_ms,
                 "frac_whole_call": alg_bytes / (call_ms / 1e3) / 1e9 / HBM_PEAK_GBS,

@@ -11,17 +11,23 @@ DESIGN.md section 3.1 has the numbers):
   * it interprets a COMPILED program: tc_compile_kernel (sr_tc.hip) fuses every leaf into its parent operator, so there
     is one dispatch per FUNCTION node (12.9 instead of 26.3 per tree on configs[1]) and the operand stack only holds
     intermediate results;
-  * a program is 8-byte words {(LDS offset of the instruction's variable operand / 16) << 16 | offset of its handler in the
-    64-KiB-aligned handler table, constant or second variable}; a 256-byte record (32 words) is one fill of the 64-SGPR
-    window (four s_load_dwordx16); dispatch = s_movrels_b32 (next word) + s_pack_lh_b32_b16 (handler address) +
-    s_setpc_b64 — no v_readlane, no decode, no compare chain.  Programs of trees with unary functions may need a second
-    block: word 31 is then NEXT (refill from the tree's overflow record);
+  * a program is 8-byte words {(LDS offset of the instruction's variable operand / 1024) << 24 | aux << 16 | offset of its
+    handler in the 64-KiB-aligned handler table, constant or second variable}; a 256-byte record (32 words) is one fill of
+    the 64-SGPR window (four s_load_dwordx16); dispatch = s_movrels_b32 (next word) + s_pack_lh_b32_b16 (handler address) +
+    s_setpc_b64 — no v_readlane, no decode, no compare chain.  Longer programs chain blocks: word 31 is then NEXT (refill
+    from the tree's record in the next array of records);
   * K = 8 rows per lane: one tree instruction = 8 VALU (a division ~70, sin / cos ~200);
   * handlers: + - * / in the eight operand forms {S stack, V variable, C constant}^2 minus CC (folded by the compiler);
     unary neg abs sin cos tan sqrt loose-sqrt exp log loose-log in the forms S (in place) and V (push); the
     transcendental ones are the device math library's instruction sequences (taken from hipcc's output for sinf, ...),
     sin / cos / tan only their small-argument path: a block with an operand of 2^17 or more BAILS OUT at run time (the
     tree gets the register kernels' sentinel and their pending flag is raised);
+  * the rarer functions share GENERIC STUBS (eight binary forms, two unary ones) that gather the operands into fixed banks
+    and jump to the body the word's aux field names: loose division, max min, < > <= >=, and — run row by row through the
+    library's transcribed sequences (gen/ocml_transcribe.py -> ocml_bodies.py, 120-190 instructions each) — pow, loose pow,
+    sinh, cosh; tanh inline; IF with its three operands on the stack;
+  * multi-output programs (forward.cu:237-243): the first out_len stack entries are the output accumulators; mo_begin clears
+    them, acc_s adds the top of the stack to one of them, end_mo folds the errors of all outputs;
   * the division comes in three selectable row sequences (ieee / short / fast, evogp_hip_set_sr_division); the
     reference's "b == 0 -> NaN" is tested once per K x 64 block (min |b|), not per row;
   * the dataset lives in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per four rows.
