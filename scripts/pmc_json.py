@@ -45,11 +45,16 @@ def main():
         "files": [os.path.basename(p) for p in sys.argv[1:4]],
         "kernels": {},
     }
+    # rocprofv3 stores one row per launch AND counter instance for the SQ counters (32 rows per launch on this device: the
+    # one-launch xcc_probe_kernel shows it), each holding that instance's share; the derived TCC sizes are per launch already
+    probe = next((k for k in t if "xcc_probe" in k), None)
+    inst = max(v[0] for v in t[probe].values()) if probe else 32
+    out["sq_rows_per_launch"] = inst
     for name, key in ((interp, "sr_tc_kernel"), (comp, "tc_compile_kernel")):
         if not name:
             continue
-        c = {k: v[1] for k, v in t[name].items()}
-        out["kernels"][key] = {"rocprof_name": name, "dispatches": max(v[0] for v in t[name].values()), "per_dispatch": c}
+        c = {k: (v[1] * inst if k.startswith("SQ_") else v[1]) for k, v in t[name].items()}
+        out["kernels"][key] = {"rocprof_name": name, "launches": max(v[0] for v in t[name].values()) // inst, "per_launch": c}
     if interp and "FETCH_SIZE" in t[interp] and "WRITE_SIZE" in t[interp]:
         f, w = t[interp]["FETCH_SIZE"][1] * 1024, t[interp]["WRITE_SIZE"][1] * 1024
         pop = out["pop_per_launch"] or 0
@@ -62,7 +67,7 @@ def main():
         out["correction"] = ("counter values are KB (x 1024); FETCH_SIZE doubled (gfx950 tallies 128-byte requests of 16 B/lane coalesced reads at 64 B; "
                              f"calibration on this kernel: records = pop x 256 B = {pop * 256} B, raw FETCH_SIZE = {f:.0f} B); WRITE_SIZE as reported")
     if interp and "SQ_WAVE_CYCLES" in t[interp]:
-        c = {k: v[1] for k, v in t[interp].items()}
+        c = {k: v[1] * inst for k, v in t[interp].items()}
         wc = c["SQ_WAVE_CYCLES"]
         out["sq"] = {k.lower() + "_over_wave_cycles": c[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in c}
         if "SQ_INSTS_VALU" in c and "SQ_INSTS_SALU" in c:
