@@ -113,8 +113,9 @@ def count_path(L, start, taken):
 
 
 def gen(K, DEPTH, stats=False, fast=0, info=None):
-    assert K % 4 == 0
-    G = K // 4
+    assert K % 4 == 0 or K == 1
+    G = max(K // 4, 1)   # 1-KiB groups of a variable's tile: 64 lanes x 16 bytes (K = 1 uses the first row of every lane's four)
+    RPL = min(K, 4)      # rows per lane and group
     P = [24, 24 + K]
     T, Q = 24 + 2 * K, 24 + 3 * K
     S0 = 24 + 4 * K
@@ -170,6 +171,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_setpc_b64 s[{sPC}:{sPC + 1}]")
 
     def read_bank(bank, vaddr):
+        if K == 1:
+            a(f"ds_read_b32 v{bank}, v{vaddr}")
+            return
         for g in range(G):
             a(f"ds_read_b128 v[{bank + 4 * g}:{bank + 4 * g + 3}], v{vaddr}" + (f" offset:{1024 * g}" if g else ""))
 
@@ -762,8 +766,12 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             # turn the numerator into NaN.  (A NaN divisor drops out of the minimum and makes its quotient NaN anyway.)
             ys_ = [y + k for k in range(K)]
             acc = DT[0]
-            a(f"v_min3_f32 v{acc}, |v{ys_[0]}|, |v{ys_[1]}|, |v{ys_[2]}|")
-            rest = ys_[3:]
+            if K >= 3:
+                a(f"v_min3_f32 v{acc}, |v{ys_[0]}|, |v{ys_[1]}|, |v{ys_[2]}|")
+                rest = ys_[3:]
+            else:
+                a(f"v_and_b32 v{acc}, 0x7fffffff, v{ys_[0]}")
+                rest = ys_[1:]
             while len(rest) >= 2:
                 a(f"v_min3_f32 v{acc}, v{acc}, |v{rest[0]}|, |v{rest[1]}|")
                 rest = rest[2:]
@@ -984,8 +992,12 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             continue
         a(f"{lab(f'trigbody_{uop}')}:")
         xs = [T + k for k in range(K)]
-        a(f"v_max3_f32 v{tx}, |v{xs[0]}|, |v{xs[1]}|, |v{xs[2]}|")
-        rest = xs[3:]
+        if K >= 3:
+            a(f"v_max3_f32 v{tx}, |v{xs[0]}|, |v{xs[1]}|, |v{xs[2]}|")
+            rest = xs[3:]
+        else:
+            a(f"v_and_b32 v{tx}, 0x7fffffff, v{xs[0]}")
+            rest = xs[1:]
         while len(rest) >= 2:
             a(f"v_max3_f32 v{tx}, v{tx}, |v{rest[0]}|, |v{rest[1]}|")
             rest = rest[2:]
@@ -1185,8 +1197,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a("s_waitcnt lgkmcnt(0)")
     a(f"s_cmp_eq_u32 s{T1}, 0")
     a(f"s_cbranch_scc1 {lab('endmo_full')}")
-    a(f"s_mul_i32 s{T4}, s{sTILE}, {256 * G}")        # ragged tile: rows >= D contribute nothing
-    a("v_lshlrev_b32 v5, 2, v0")
+    a(f"s_mul_i32 s{T4}, s{sTILE}, {64 * K}")         # ragged tile: rows >= D contribute nothing
+    a(f"v_mul_u32_u24 v5, {RPL}, v0")
     a(f"v_add_u32 v5, s{T4}, v5")
     for k in range(K):
         g, q = divmod(k, 4)
@@ -1236,8 +1248,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_cmp_eq_u32 s{T2}, 0")
         a(f"s_cbranch_scc1 {lab(f'end_full{fl}')}")
         # ragged tile: rows >= D contribute nothing
-        a(f"s_mul_i32 s{T2}, s{sTILE}, {256 * G}")
-        a("v_lshlrev_b32 v5, 2, v0")
+        a(f"s_mul_i32 s{T2}, s{sTILE}, {64 * K}")
+        a(f"v_mul_u32_u24 v5, {RPL}, v0")
         for k in range(K):
             g, q = divmod(k, 4)
             a(f"s_add_u32 s{T4}, s{T2}, {g * 256 + q}")
@@ -1401,7 +1413,7 @@ if __name__ == "__main__":
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}
-    for K, depth in ((8, 9), (4, 15)):
+    for K, depth in ((8, 9), (4, 15), (1, 44)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:
             for fast, tag in ((0, "ieee"), (1, "fast"), (2, "short")):  # division: IEEE / no range scaling / one correction
                 info = {}

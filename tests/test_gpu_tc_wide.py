@@ -183,6 +183,38 @@ def test_library_functions_in_the_threaded_code(g, oracle, rng, funcs, out_len):
     assert np.allclose(got[both], ref[both], rtol=2e-5, atol=1e-30), "threaded code vs the register kernels on the same trees"
 
 
+# ---- small datasets: one row per lane (the K = 1 interpreter) --------------------------------------------------------------
+@pytest.mark.parametrize("D", [1, 2, 7, 8, 33, 63, 64, 65])
+@pytest.mark.parametrize("funcs,out_len,L,mlc", [(ARITH, 1, 64, 6), (EXACT_WIDE, 1, 128, 4), ([ADD, SUB, MUL, MAX, NEG], 4, 64, 5)], ids=["arith", "wide-L128", "4 outputs"])
+def test_small_datasets(g, oracle, rng, D, funcs, out_len, L, mlc):
+    """Datasets of at most 64 rows (the reference's XOR-3d examples have 8) run the interpreter variant with ONE row per lane;
+    65 rows is the first size that takes the four-row variant.  IEEE-exact function sets: 1e-5 on every tree, both losses."""
+    forest = oracle.generate(3000, L, 3, out_len, 0.5, 0.5, [D, L], depth2leaf(mlc, 0.1), roulette_uniform(funcs), CS)
+    X = rng.uniform(-3, 3, (D, 3)).astype(np.float32); y = rng.uniform(-3, 3, (D, out_len)).astype(np.float32)
+    check(g, oracle, forest, X, y, f"D={D}", max_skipped=0.05)
+
+
+def test_small_dataset_library_functions_match_the_register_kernels(g, oracle, rng):
+    """the reference's notebook configuration (XOR-3d: 8 rows, + - log sqrt pow / inv, L = 128): identical NaN / inf classes
+    against the oracle, and agreement with the register kernels (which call the device library) on the same trees"""
+    funcs = [ADD, SUB, LOG, SQRT, POW, DIV, INV]
+    forest = oracle.generate(4000, 128, 3, 1, 0.5, 0.5, [8, 128], depth2leaf(5, 0.15), roulette_uniform(funcs), [-1.0, 0.0, 1.0])
+    X = np.array([[a, b, c] for a in (0., 1.) for b in (0., 1.) for c in (0., 1.)], dtype=np.float32)
+    y = (X.sum(1) % 2)[:, None].astype(np.float32)
+    got = g.sr_fitness(*forest, X, y)
+    h = handler_histogram(g, 4000)
+    assert h["skip"] <= 0.05 * 4000, f"{h['skip']} trees left to the register kernels"
+    want = oracle.sr_fitness(*forest, X, y)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    ok = np.isfinite(want)
+    assert (np.abs(got[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-6).mean() > 0.99
+    be = g.batch_evaluate(*forest, X, 1).astype(np.float64)
+    with np.errstate(all="ignore"):
+        ref = ((be - y[None, :, :].astype(np.float64)) ** 2).sum(2).mean(1)
+    both = np.isfinite(ref) & ok & (np.abs(ref) < 1e30)
+    assert np.allclose(got[both], ref[both], rtol=2e-5, atol=1e-30)
+
+
 def test_chunked_pipeline_on_a_large_population(g, oracle):
     """a population beyond the sizes of the other tests (and, with EVOGP_TC_CHUNKS set, the chunked two-stream pipeline of
     sr_tc.hip): the result must equal that of the halves run on their own, and the oracle's on a sample"""
