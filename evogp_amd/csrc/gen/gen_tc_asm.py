@@ -67,7 +67,7 @@ SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the
 OPS = ("add", "sub", "mul", "div")
 UNARY = ("neg", "abs", "sin", "cos", "tan", "sqrt", "lsqrt", "exp", "log", "llog")  # unary handlers, in the compiler kernel's numbering (sr_tc.hip)
 GBIN = ("ldiv", "max", "min", "lt", "gt", "le", "ge", "pow", "lpow")  # bodies behind the generic binary stubs, selected by the word's aux field
-GUN = ("zero", "sinh", "cosh", "tanh")                                # bodies behind the generic unary stubs
+GUN = ("zero", "sinh", "cosh", "tanh", "one", "rcp")                  # bodies behind the generic unary stubs (sr_tc.hip GU_*)
 HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top of the operand stack (the compiler keeps it free)
 SLOT = 256  # bytes per handler slot
 NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo
@@ -932,6 +932,14 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         if body == "zero":              # a unary node whose function id is unknown yields 0 (forward.cu:117)
             for k in range(K):
                 a(f"v_mov_b32 v{Q + k}, 0")
+        elif body == "one":             # pow(x, 0), pow(1, y): 1 whatever the other operand is (sr_tc.hip pow_fold_kind)
+            for k in range(K):
+                a(f"v_mov_b32 v{Q + k}, 1.0")
+        elif body == "rcp":             # pow(x, -1): the plain IEEE 1 / x (+-0 gives +-inf: not the reference's DIV rule)
+            a("v_mov_b32 v9, 1.0")
+            for k in range(K):
+                div_rows([9], [T + k], [4], nanfix=False)
+                a(f"v_div_fixup_f32 v{Q + k}, v4, v{T + k}, v9")
         elif body in ("sinh", "cosh"):  # forward.cu:129-134
             row_loop(body, BODIES[body], 1, Q)
         elif body == "tanh":            # the library's tanhf: both of its branches, then the select it makes with the exec mask

@@ -133,6 +133,55 @@ def test_generic_functions_every_operand_form(g, oracle, rng):
     check(g, oracle, (v, t, s), X, y, "operand forms", max_skipped=0.0)
 
 
+def test_pow_with_a_deciding_constant_operand(g, oracle):
+    """pow(x, 0) = 1, pow(1, y) = 1, pow(x, 1) = x, pow(x, -1) = 1 / x are compiled without the library's sequence
+    (csrc/sr_tc.hip pow_fold_kind; scripts/ubench/pow_identities.hip ran all 2^32 operands through the device library).  One
+    datapoint per special operand, labels 0, mean absolute error: the fitness IS |value|, compared bit for bit with the exact
+    result (which is what the oracle's host library returns) -- for a variable operand, a subtree operand (ADD(x, -0) keeps
+    every x but +0 -> its bits; x + x doubles) and a constant one, single- and multi-output."""
+    xs = np.array([0.0, -0.0, 1.0, -1.0, 2.5, -2.5, 1e-30, -1e-30, 3e38, -3e38, np.inf, -np.inf, np.nan, 1e-42, 0.1], np.float32)
+    cases = []   # (nodes, function of x giving the expected value)
+    def S(var): return [(3, float(ADD), 3), (0, float(var), 1), (0, float(var), 1)]                     # x + x
+    with np.errstate(all="ignore"):
+        for c, f in ((0.0, lambda x: np.float32(1)), (-0.0, lambda x: np.float32(1)), (1.0, lambda x: x), (-1.0, lambda x: np.float32(1) / x)):
+            cases.append(([(3, float(POW), 3), (0, 0.0, 1), (1, c, 1)], f))                              # pow(x, c)
+            cases.append(([(3, float(POW), 5)] + S(0) + [(1, c, 1)], (lambda f_: lambda x: f_(x + x))(f)))   # pow(x + x, c)
+            cases.append(([(3, float(POW), 3), (1, 2.5, 1), (1, c, 1)], (lambda f_: lambda x: f_(np.float32(2.5)) + 0 * np.float32(0))(f)))  # pow(2.5, c)
+            cases.append(([(3, float(POW), 3), (1, 0.0, 1), (1, c, 1)], (lambda f_: lambda x: f_(np.float32(0.0)))(f)))   # pow(0, c)
+        cases.append(([(3, float(POW), 3), (1, 1.0, 1), (0, 0.0, 1)], lambda x: np.float32(1)))          # pow(1, x)
+        cases.append(([(3, float(POW), 5), (1, 1.0, 1)] + S(0), lambda x: np.float32(1)))                # pow(1, x + x)
+        # folded nodes inside a larger tree: pow(x, 1) * pow(x + x, 0) - pow(x, -1)
+        big = [(3, float(SUB), 13), (3, float(MUL), 9), (3, float(POW), 3), (0, 0.0, 1), (1, 1.0, 1), (3, float(POW), 5)] + S(0) + [(1, 0.0, 1)] + \
+              [(3, float(POW), 3), (0, 0.0, 1), (1, -1.0, 1)]
+        cases.append((big, lambda x: x * np.float32(1) - np.float32(1) / x))
+    L = 16
+    pop = len(cases)
+    v = np.zeros((pop, L), np.float32); t = np.zeros((pop, L), np.int16); s = np.zeros((pop, L), np.int16)
+    for r, (nodes, _) in enumerate(cases):
+        for i, (ty, val, sz) in enumerate(nodes):
+            t[r, i], v[r, i], s[r, i] = ty, val, sz
+        assert oracle.validate_tree(t[r], s[r]) == 0
+    y = np.zeros((1, 1), np.float32)
+    for x in xs:
+        X = np.array([[x]], np.float32)
+        got = g.sr_fitness(v, t, s, X, y, False)
+        assert handler_histogram(g, pop)["skip"] == 0
+        with np.errstate(all="ignore"):
+            want = np.array([np.abs(np.float32(f(np.float32(x)))) for _, f in cases], np.float32)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (float(x), np.flatnonzero(~same), got[~same], want[~same])
+        # and the oracle (host pow) agrees with the exact values
+        assert_close_classes(got, oracle.sr_fitness(v, t, s, X, y, False), 1e-6, what=f"x={x}")
+    # multi-output: the same functions as OUT nodes over leaves
+    vm = np.zeros((4, L), np.float32); tm = np.zeros((4, L), np.int16); sm = np.zeros((4, L), np.int16)
+    for r, c in enumerate((0.0, 1.0, -1.0, 2.0)):
+        nodes = [(3 | 0x80, np.array([POW | (1 << 16)], np.uint32).view(np.float32)[0], 3), (0, 0.0, 1), (1, c, 1)]
+        for i, (ty, val, sz) in enumerate(nodes):
+            tm[r, i], vm[r, i], sm[r, i] = ty, val, sz
+    Xm = np.array([[0.5], [-3.0], [0.0], [7.0]], np.float32); ym = np.zeros((4, 2), np.float32)
+    assert_close_classes(g.sr_fitness(vm, tm, sm, Xm, ym, True), oracle.sr_fitness(vm, tm, sm, Xm, ym, True), 1e-6, what="multi-output pow folds")
+
+
 # ---- multi-output trees ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("out_len,D,funcs,L", [(2, 1024, ARITH, 64), (4, 1024, ARITH, 64), (6, 700, ARITH, 64), (4, 1024, EXACT_WIDE, 128),
                                                (10, 200, ARITH, 128), (12, 1797, ARITH, 64), (3, 8, ARITH, 64), (4, 1024, ARITH + [SIN, EXP, LOG], 64)])
