@@ -13,13 +13,19 @@ data-parallel axis the workload has for free:
   rank instead of the 64.5 MB of the whole shard.  On the xGMI mesh every rank sends its block to its 7 peers over 7
   direct links, so one large collective per array kind is the right granularity.
 
-After the exchange every rank holds the identical table of parents, the identical ranking (stable sort) and draws the
-identical index tensors from a generator seeded identically on all ranks, then materialises ONLY its own slice
-``[r*pop/G, (r+1)*pop/G)`` of the next generation: with the fused breeding pass (``evogp_hip_generate_masked`` +
+Nothing in a rank's step is O(global population) except one streaming pass over the gathered fitness vector: the kept set
+comes from a threshold (``torch.kthvalue`` + elementwise compares, ``select_kept``), only the kept ~30 % are sorted (their
+keys travel with their rows, ``table_order``), and the six random words of an offspring are a counter-based hash of
+(seed, generation, word, GLOBAL offspring index) (``random_words`` / ``evogp_hip_random_words``): a rank computes exactly the
+words of its own rows, and all ranks agree on them whatever the world size.
+
+After the exchange every rank holds the identical table of parents and the identical ranking, then materialises ONLY its
+own slice ``[r*pop/G, (r+1)*pop/G)`` of the next generation: with the fused breeding pass (``evogp_hip_generate_masked`` +
 ``evogp_hip_breed_default_rows``) on a GPU, or with ``tree_crossover`` / ``tree_generate`` (tree-index offset = global
-mutation rank) / ``tree_mutate`` otherwise.  By construction the union of the shards is bit-identical for every world
-size, G = 1 included (tests/test_sharded_gloo.py checks G = 2 against G = 1 on the gloo backend;
-tests/test_gpu_breed.py builds the shards of G = 1, 2, 3, 8 on one GPU).
+mutation rank) / ``tree_mutate`` and a generator seeded identically on all ranks otherwise.  By construction the union of
+the shards is bit-identical for every world size, G = 1 included (tests/test_sharded_gloo.py checks G = 2 against G = 1 on
+the gloo backend; tests/test_gpu_breed.py builds the shards of G = 1, 2, 3, 8 on one GPU; tests/test_gpu_rccl.py runs two
+ranks over RCCL where two GPUs exist).
 
 Operator semantics are those of DefaultSelection / DefaultCrossover / DefaultMutation
 (src/evogp/algorithm/{selection,crossover,mutation}/default.py): same distributions, drawn from an
