@@ -211,6 +211,19 @@ def test_sr_fitness_ragged_datapoint_counts(g, oracle, rng, D):
         assert_close_classes(g.sr_fitness(*forest, X, y, mse), oracle.sr_fitness(*forest, X, y, mse), RTOL_ARITH, what=f"D={D} mse={mse}")
 
 
+@pytest.mark.parametrize("D", [8, 100, 600])   # the 1-, 4- and 8-row interpreter builds
+def test_sr_fitness_every_population_size_is_fully_evaluated(g, oracle, rng, D):
+    """The interpreter hands most of the population out dynamically, one region and work counter per XCD: a region whose XCD
+    runs no workgroup (few workgroups: small populations) would never be worked off.  The fitness buffer is poisoned before every call, so a tree nobody evaluated shows."""
+    X = rng.uniform(-3, 3, (D, 4)).astype(np.float32); y = rng.uniform(-3, 3, (D, 1)).astype(np.float32)
+    big = oracle.generate(70001, 64, 4, 1, 0.5, 0.5, [9, D], depth2leaf(6), roulette_uniform(ARITH), CS3)
+    want = oracle.sr_fitness(*big, X, y)
+    for pop in (1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 500, 1023, 1025, 4097, 9999, 20000, 33333, 70001):
+        got = g.sr_fitness(*(a[:pop] for a in big), X, y)   # (the helper fills the fitness buffer with 12345 before the call)
+        assert not (got == 12345.0).any(), f"pop {pop}: {int((got == 12345.0).sum())} trees were not evaluated"
+        assert_close_classes(got, want[:pop], RTOL_ARITH, what=f"pop={pop}")
+
+
 @pytest.mark.parametrize("var_len,out_len", [(1, 1), (16, 1), (17, 1), (32, 2), (33, 1), (64, 10), (5, 16), (5, 17)])
 def test_sr_fitness_shapes(g, oracle, rng, var_len, out_len):
     forest = oracle.generate(500, 64, var_len, out_len, 0.5, 0.5, [5, 5], depth2leaf(6), roulette_uniform(ARITH), CS3)
