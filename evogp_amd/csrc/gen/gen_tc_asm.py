@@ -70,10 +70,13 @@ GBIN = ("ldiv", "max", "min", "lt", "gt", "le", "ge", "pow", "lpow")  # bodies b
 GUN = ("zero", "sinh", "cosh", "tanh", "one", "rcp")                  # bodies behind the generic unary stubs (sr_tc.hip GU_*)
 HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top of the operand stack (the compiler keeps it free)
 SLOT = 256  # bytes per handler slot
-NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo
+DIVIP_REGS = 5  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
+DIVIP = ("SS", "SC", "CS")  # division forms with an in-place handler (operands read where they are, temporaries above the stack)
+NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP)  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
+FMA_LOSS = False  # EVOGP_TC_GEN_FMA_LOSS=1: accumulate squared errors with one fused multiply-add (timing experiment)
 KWARM = True  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=0 at generation time disables it)
 
 
@@ -147,7 +150,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     for f, form in enumerate(FORMS):
         hid[f"gbin_{form}"] = nh + f
     hid["gun_S"], hid["gun_V"], hid["if_sss"], hid["acc_s"], hid["mo_begin"], hid["end_mo"] = (nh + 8 + i for i in range(6))
-    assert NHF == nh + 14
+    for i, form in enumerate(DIVIP):
+        hid[f"divip_{form}"] = nh + 14 + i
+    assert NHF == nh + 14 + len(DIVIP)
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -473,6 +478,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
             read_bank(T, 5)
         prefetch(nxt)
+        if form in DIVIP:
+            a(f"{lab(f'divold_{form}{fl}')}:")  # the in-place handler of this form arrives here when its block holds a zero divisor
         wait_cur()  # the current bank is overwritten or read below: its (possibly unused) prefetch must have landed
         if form == "SS":
             m0_stack(MODE["SRC0"], -2 * K)
@@ -499,9 +506,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 a(f"v_mov_b32 v{y + k}, s{sBop}")
         a(f"s_branch {lab(f'divbody_{kind}{fl}')}")
 
-    def div_rows(xs, ys, qs, nanfix=True):
-        """IEEE division rows: q = (y == 0) ? NaN : x / y  up to (not including) v_div_fixup (forward.cu:183-187)"""
-        d3, d4, d6, d7, d8 = DT
+    def opnd(o):
+        return o if isinstance(o, str) else f"v{o}"
+
+    def div_rows(xs, ys, qs, nanfix=True, temps=None):
+        """IEEE division rows: q = (y == 0) ? NaN : x / y  up to (not including) v_div_fixup (forward.cu:183-187).
+        Operands are VGPR numbers or operand strings (an SGPR holding a constant); `temps`: five VGPRs (default v18-v22)."""
+        d3, d4, d6, d7, d8 = temps or DT
+        xs, ys = [opnd(o) for o in xs], [opnd(o) for o in ys]
+        assert not nanfix or all(o.startswith("v") for o in xs)
         if fast == 2:
             # "short" division: the IEEE sequence with its range scaling (v_div_scale / v_div_fmas / v_div_fixup) but ONE
             # residual correction instead of a refined reciprocal and two corrections: 9 instead of 13 operations.  Range-
@@ -509,11 +522,11 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             # within ~2^-30 ulp of a rounding boundary (measured: 1 of 2^32 random mantissa pairs, ubench/div_faithful.hip).
             for x, y, q in zip(xs, ys, qs):
                 if nanfix:
-                    a(f"v_cmp_neq_f32 vcc, 0, v{y}")
-                    a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")
-                a(f"v_div_scale_f32 v{d3}, vcc, v{y}, v{y}, v{x}")
+                    a(f"v_cmp_neq_f32 vcc, 0, {y}")
+                    a(f"v_cndmask_b32 {x}, v8, {x}, vcc")
+                a(f"v_div_scale_f32 v{d3}, vcc, {y}, {y}, {x}")
                 a(f"v_rcp_f32 v{d4}, v{d3}")
-                a(f"v_div_scale_f32 v{d6}, vcc, v{x}, v{y}, v{x}")
+                a(f"v_div_scale_f32 v{d6}, vcc, {x}, {y}, {x}")
                 a(f"v_mul_f32 v{d7}, v{d6}, v{d4}")
                 a(f"v_fma_f32 v{d8}, -v{d3}, v{d7}, v{d6}")
                 a("s_nop 1")  # v_div_fmas reads the VCC of the second v_div_scale: 4 wait states
@@ -525,23 +538,23 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             # no range scaling: |y| > 2^126 gives 0, a quotient beyond 2^128 gives NaN.  Special operands are still put
             # right by v_div_fixup.  5 instead of 11 dependent operations per row.
             for x, y, q in zip(xs, ys, qs):
-                a(f"v_rcp_f32 v{d4}, v{y}")
+                a(f"v_rcp_f32 v{d4}, {y}")
                 if nanfix:
-                    a(f"v_cmp_neq_f32 vcc, 0, v{y}")
-                    a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")
+                    a(f"v_cmp_neq_f32 vcc, 0, {y}")
+                    a(f"v_cndmask_b32 {x}, v8, {x}, vcc")
                 else:
                     a("s_nop 0")  # gfx940+: one wait state between a transcendental and the VALU that reads its result
-                a(f"v_mul_f32 v{d7}, v{x}, v{d4}")
-                a(f"v_fma_f32 v{d8}, -v{y}, v{d7}, v{x}")
+                a(f"v_mul_f32 v{d7}, {x}, v{d4}")
+                a(f"v_fma_f32 v{d8}, -{y}, v{d7}, {x}")
                 a(f"v_fma_f32 v{q}, v{d8}, v{d4}, v{d7}")
             return
         for x, y, q in zip(xs, ys, qs):
             if nanfix:
-                a(f"v_cmp_neq_f32 vcc, 0, v{y}")
-                a(f"v_cndmask_b32 v{x}, v8, v{x}, vcc")  # a NaN numerator makes the quotient NaN
-            a(f"v_div_scale_f32 v{d3}, vcc, v{y}, v{y}, v{x}")
+                a(f"v_cmp_neq_f32 vcc, 0, {y}")
+                a(f"v_cndmask_b32 {x}, v8, {x}, vcc")  # a NaN numerator makes the quotient NaN
+            a(f"v_div_scale_f32 v{d3}, vcc, {y}, {y}, {x}")
             a(f"v_rcp_f32 v{d4}, v{d3}")
-            a(f"v_div_scale_f32 v{d6}, vcc, v{x}, v{y}, v{x}")
+            a(f"v_div_scale_f32 v{d6}, vcc, {x}, {y}, {x}")
             a(f"v_fma_f32 v{d7}, -v{d3}, v{d4}, 1.0")
             a(f"v_fmac_f32 v{d4}, v{d7}, v{d4}")
             a(f"v_mul_f32 v{d7}, v{d6}, v{d4}")
@@ -754,7 +767,59 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         begin("end_mo", fl)
         read_aux(T2)
         a(f"s_branch {lab('endmo_body')}")
+        # ---- in-place divisions: the compiler picks these where one more stack entry is free above the operands
+        for form in DIVIP:
+            begin(f"divip_{form}", fl)
+            entry()
+            if form == "CS":
+                a(f"s_movrels_b32 s{sA}, s{W + 1}")
+            if form == "SC":
+                a(f"s_movrels_b32 s{sBop}, s{W + 1}")
+            prefetch(nxt)
+            a(f"s_branch {lab(f'divip_body_{form}{fl}')}")
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
+
+    # In-place division bodies.  The gather forms above copy the operands into fixed banks because the division's temporaries
+    # are fixed registers while stack operands are M0-relative -- 16 moves for S / S.  Here EVERYTHING is relative to one base
+    # (M0 = all four REL bits | H - operands): the operands where they are, the five temporaries in the registers above
+    # them (the compiler guarantees that entry exists), a constant operand straight from its SGPR, the quotient written over
+    # the lower operand's slot row by row.  61 instead of 78 VALU instructions for S / S.  A block with a zero divisor (the
+    # reference's NaN rule, forward.cu:183-187) goes to the gather form, which handles it.
+    ALLREL = MODE["SRC0"] | MODE["SRC1"] | MODE["SRC2"] | MODE["DST"]
+    for fl in (0, 1):
+        for form in DIVIP:
+            a(f"{lab(f'divip_body_{form}{fl}')}:")
+            nops = 2 if form == "SS" else 1          # stack operands
+            m0_stack(ALLREL, -nops * K)
+            tb = S0 + nops * K                        # first register above the operands
+            tmp = [tb + i for i in range(DIVIP_REGS)]
+            q, acc = tmp[4], tmp[0]                   # the quotient replaces the residual; the zero test is over before the rows start
+            if form == "SS":  # the first operand (the numerator) is on top of the stack, the divisor below it
+                xs, ys = [S0 + K + k for k in range(K)], [S0 + k for k in range(K)]
+            elif form == "CS":
+                xs, ys = [f"s{sA}"] * K, [S0 + k for k in range(K)]
+            else:
+                xs, ys = [S0 + k for k in range(K)], [f"s{sBop}"] * K
+            if form != "SC":  # (the compiler turns a division by the constant 0 into a multiplication by NaN)
+                if K >= 3:
+                    a(f"v_min3_f32 v{acc}, |v{ys[0]}|, |v{ys[1]}|, |v{ys[2]}|")
+                    rest = ys[3:]
+                else:
+                    a(f"v_and_b32 v{acc}, 0x7fffffff, v{ys[0]}")
+                    rest = ys[1:]
+                while len(rest) >= 2:
+                    a(f"v_min3_f32 v{acc}, v{acc}, |v{rest[0]}|, |v{rest[1]}|")
+                    rest = rest[2:]
+                if rest:
+                    a(f"v_min_f32 v{acc}, v{acc}, |v{rest[0]}|")
+                a(f"v_cmp_eq_f32 vcc, 0, v{acc}")
+                a(f"s_cbranch_vccnz {lab(f'divold_{form}{fl}')}")
+            for k in range(K):
+                div_rows([xs[k]], [ys[k]], [q], nanfix=False, temps=tmp)
+                a(f"v_div_fixup_f32 v{S0 + k}, v{q}, {opnd(ys[k])}, {opnd(xs[k])}")
+            if form == "SS":
+                a(f"s_sub_u32 s{sH}, s{sH}, {K}")
+            epilogue()
 
     # shared division bodies: K rows, then the scatter through v_div_fixup with an indexed destination
     for fl in (0, 1):
@@ -1277,8 +1342,11 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_cbranch_scc1 {lab(f'end_abs{fl}')}")
         for k in range(K):
             a(f"v_sub_f32 v9, v{Y + k}, v{S0 + k}")
-            a("v_mul_f32 v9, v9, v9")
-            a("v_add_f32 v6, v6, v9")
+            if FMA_LOSS:
+                a("v_fmac_f32 v6, v9, v9")
+            else:
+                a("v_mul_f32 v9, v9, v9")
+                a("v_add_f32 v6, v6, v9")
         a(f"s_branch {lab('end_acc')}")
         a(f"{lab(f'end_abs{fl}')}:")
         for k in range(K):
@@ -1401,7 +1469,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
     if K == 8 and not stats and not fast:
-        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n#define EVOGP_TC_UNARY_MASK {(1 << len(UNARY)) - 1}\n#define EVOGP_TC_HEAVY_REGS {HEAVY_REGS}\n"
+        out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n#define EVOGP_TC_UNARY_MASK {(1 << len(UNARY)) - 1}\n#define EVOGP_TC_HEAVY_REGS {HEAVY_REGS}\n#define EVOGP_TC_DIVIP_REGS {DIVIP_REGS}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
     out += f"#define EVOGP_TC_ASM_{name}(karg_, wgid_, ldsx_, wave_, dyn_, pf_, base_) \\\n  asm volatile( \\\n"
@@ -1418,6 +1486,7 @@ if __name__ == "__main__":
     import os
     KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "1") != "0"
     NOPF = os.environ.get("EVOGP_TC_GEN_NOPF", "0") == "1"
+    FMA_LOSS = os.environ.get("EVOGP_TC_GEN_FMA_LOSS", "0") == "1"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}

@@ -182,6 +182,43 @@ def test_pow_with_a_deciding_constant_operand(g, oracle):
     assert_close_classes(g.sr_fitness(vm, tm, sm, Xm, ym, True), oracle.sr_fitness(vm, tm, sm, Xm, ym, True), 1e-6, what="multi-output pow folds")
 
 
+@pytest.mark.parametrize("D", [8, 100, 600], ids=["K1", "K4", "K8"])
+@pytest.mark.parametrize("zeros", [False, True])
+def test_division_in_place_and_gather_forms_at_every_stack_height(g, oracle, rng, D, zeros):
+    """S / S, S / c and c / S divisions have an in-place handler (operands read where they are, temporaries in the stack entries
+    above them) that the compiler picks where those entries are free, and a gather form elsewhere; a block with a zero divisor
+    is handed from the first to the second.  Trees ADD^p(DIV(..), S1 .. Sp) put the division at stack height p + 2 for every p
+    up to beyond the register stack of each build, with and without zero divisors in the rows."""
+    def S(i, j, f=MUL): return [(3, float(f), 3), (0, float(i), 1), (0, float(j), 1)]
+    rows = []
+    for p in range(0, 15):
+        for div in ([(3, float(DIV), 7)] + S(0, 1, ADD) + S(2, 3, SUB),        # (x0 + x1) / (x2 - x3)
+                    [(3, float(DIV), 5), (1, 1.5, 1)] + S(2, 3, SUB),          # 1.5 / (x2 - x3)
+                    [(3, float(DIV), 5)] + S(0, 1, ADD) + [(1, 3.0, 1)],       # (x0 + x1) / 3
+                    [(2, float(INV), 4)] + S(2, 3, SUB)):                      # inv(x2 - x3)
+            nodes = div
+            for q in range(p):
+                nodes = [(3, float(ADD), 1 + len(nodes) + 3)] + nodes + S(q % 4, (q + 1) % 4)
+            rows.append(nodes)
+    L = 64
+    assert max(len(r) for r in rows) <= L
+    v = np.zeros((len(rows), L), np.float32); t = np.zeros((len(rows), L), np.int16); s = np.zeros((len(rows), L), np.int16)
+    for r, nodes in enumerate(rows):
+        for i, (ty, val, sz) in enumerate(nodes):
+            t[r, i], v[r, i], s[r, i] = ty, val, sz
+        assert oracle.validate_tree(t[r], s[r]) == 0
+    X = rng.uniform(-3, 3, (D, 4)).astype(np.float32); y = rng.uniform(-3, 3, (D, 1)).astype(np.float32)
+    if zeros:
+        X[::7, 3] = X[::7, 2]   # x2 - x3 = 0 in every seventh row: NaN there (forward.cu:183-187), so NaN fitness for these trees
+        X[1, :] = 0.0
+    for m in (True, False):
+        assert_close_classes(g.sr_fitness(v, t, s, X, y, m), oracle.sr_fitness(v, t, s, X, y, m), RTOL, what=f"D={D} zeros={zeros} mse={m}")
+    h = handler_histogram(g, len(rows))
+    assert h["divip_SS"] > 0 and h["divip_CS"] > 0 and h["divip_SC"] > 0, h
+    if D > 64:   # (the one-row build's 44-entry stack has room above every one of these trees)
+        assert h["div_SS"] > 0 and h["div_CS"] > 0, h
+
+
 # ---- multi-output trees ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("out_len,D,funcs,L", [(2, 1024, ARITH, 64), (4, 1024, ARITH, 64), (6, 700, ARITH, 64), (4, 1024, EXACT_WIDE, 128),
                                                (10, 200, ARITH, 128), (12, 1797, ARITH, 64), (3, 8, ARITH, 64), (4, 1024, ARITH + [SIN, EXP, LOG], 64)])
