@@ -76,6 +76,7 @@ NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP)  # handlers per flavour: ... 
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
+SPLAT = False    # EVOGP_TC_GEN_SPLAT=1: copy a constant operand into a VGPR before the row loop (experiment: 1.5 % SLOWER at 1 M trees)
 FMA_LOSS = False  # EVOGP_TC_GEN_FMA_LOSS=1: accumulate squared errors with one fused multiply-add (timing experiment)
 KWARM = True  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=0 at generation time disables it)
 
@@ -395,6 +396,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     def wait_cur():
         a(f"s_waitcnt lgkmcnt({G})")  # everything but the prefetch just issued has landed (LDS returns in order)
 
+    def splat(sreg):
+        """the operand a constant takes in a K-row loop: its SGPR (default), or -- an experiment, the kernel-level ubench had an
+        SGPR source at half the issue rate -- v9 after one copy (a source-0 position that no handler addresses relative to
+        M0).  In the interpreter the copy costs more than it saves: 1.066 -> 1.081 ms at 1 M trees."""
+        if not SPLAT or K < 3:
+            return f"s{sreg}"
+        a(f"v_mov_b32 v9, s{sreg}")
+        return "v9"
+
     def arith(op, form, fl):
         cur, nxt = P[fl], P[1 - fl]
         ins = {"add": "v_add_f32", "sub": "v_sub_f32", "mul": "v_mul_f32"}[op]
@@ -423,14 +433,16 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"s_movrels_b32 s{sBop}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
+            c = splat(sBop)
             for k in range(K):
-                a(f"{rev} v{S0 + k}, s{sBop}, v{S0 + k}")
+                a(f"{rev} v{S0 + k}, {c}, v{S0 + k}")
         elif form == "CS":  # constant op stack top
             a(f"s_movrels_b32 s{sA}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
+            c = splat(sA)
             for k in range(K):
-                a(f"{ins} v{S0 + k}, s{sA}, v{S0 + k}")
+                a(f"{ins} v{S0 + k}, {c}, v{S0 + k}")
         elif form == "VV":  # a was prefetched, b is read here
             a(f"s_movrels_b32 s{sBop}, s{W + 1}")
             a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
@@ -445,17 +457,19 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"s_movrels_b32 s{sBop}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["DST"], 0)
+            c = splat(sBop)
             wait_cur()
             for k in range(K):
-                a(f"{rev} v{S0 + k}, s{sBop}, v{cur + k}")
+                a(f"{rev} v{S0 + k}, {c}, v{cur + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         elif form == "CV":  # constant op variable
             a(f"s_movrels_b32 s{sA}, s{W + 1}")
             prefetch(nxt)
             m0_stack(MODE["DST"], 0)
+            c = splat(sA)
             wait_cur()
             for k in range(K):
-                a(f"{ins} v{S0 + k}, s{sA}, v{cur + k}")
+                a(f"{ins} v{S0 + k}, {c}, v{cur + k}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         epilogue()
 
@@ -576,8 +590,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_movrels_b32 s{sA}, s{W + 1}")
         prefetch(nxt)
         m0_stack(MODE["DST"], 0)
+        c = splat(sA)
         for k in range(K):
-            a(f"v_mov_b32 v{S0 + k}, s{sA}")
+            a(f"v_mov_b32 v{S0 + k}, {c}")
         a(f"s_add_u32 s{sH}, s{sH}, {K}")
         epilogue()
         # push variable (a tree that is a single variable)
@@ -1487,6 +1502,7 @@ if __name__ == "__main__":
     KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "1") != "0"
     NOPF = os.environ.get("EVOGP_TC_GEN_NOPF", "0") == "1"
     FMA_LOSS = os.environ.get("EVOGP_TC_GEN_FMA_LOSS", "0") == "1"
+    SPLAT = os.environ.get("EVOGP_TC_GEN_SPLAT", "0") == "1"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}
