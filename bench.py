@@ -33,6 +33,7 @@ import json
 import os
 import socket
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +42,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+EXTRAS_TIMEOUT_S = 300        # N > 1: the measurements beyond the headline may take this long before every rank leaves
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 GLOBAL_POP = 1_000_000
 POP_PER_GPU = 100_000          # configs[1]
@@ -285,7 +287,91 @@ def main():
     except Exception as exc:
         valu = {"frac": None, "error": repr(exc)[:300]}
 
+    def emit(extras, with_cpu_baseline=True):
+        """rank 0's ONE JSON line: the headline fields (all known before the extras start) + whatever extras exist"""
+        with emit_lock:
+            if emitted:
+                return
+            emitted.append(True)
+        evals = float(P) * DATAPOINTS * args.steps
+        kernel_s = stage_ms["interpreter"] / 1e3 if stage_ms["calls"] else call_ms / 1e3
+        alg_bytes = 6.0 * total_nodes + 2.0 * pop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * pop  # SURVEY.md §8d, this rank's launch
+        achieved = alg_bytes / kernel_s / 1e9
+        traffic, traffic_note = None, "no PMC record for this build"
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                if pj.get("source_sha") == source_sha() and pj.get("pop_per_launch") == pop:
+                    traffic = pj.get("sr_tc_kernel_hbm_bytes_per_launch")
+                    traffic_note = f"FETCH_SIZE + WRITE_SIZE of the interpreter kernel, rocprofv3 --pmc, measured on this source ({pj.get('source_sha')}): {pj.get('files')}"
+                else:
+                    traffic_note = (f"profiles/pmc_latest.json was measured on source {pj.get('source_sha')} / {pj.get('pop_per_launch')} trees per launch, "
+                                    f"this is {source_sha()} / {pop}: not quoted")
+            except Exception:
+                pass
+        out = {
+            "metric": "tree_evals_per_s",
+            "value": evals / elapsed,
+            "unit": "tree-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1000.0,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic" if not share_gpu else "synthetic; FUNCTIONAL CHECK ONLY: ranks share a GPU over gloo",
+            "config": {
+                "workload": f"BASELINE north_star / configs[2] shape: SymbolicRegression synthetic 10-var, GLOBAL pop={P} x 1024 datapoints, "
+                            "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass over every rank's shard per step",
+                "global_pop": P, "pop_per_gpu": pop, "datapoints": DATAPOINTS, "var_len": VAR_LEN, "max_tree_len": GP_LEN,
+                "mean_tree_len": all_nodes / P, "sharding": f"trees x{world} (contiguous shards, tree-index offset), no data-path collective in the step",
+                "ranks": world, "backend": backend,
+            },
+            "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_note": traffic_note,
+                "kernel": "sr_tc_kernel<8,false,2> (threaded-code interpreter, short division), rank 0's launch; algorithmic bytes = SURVEY.md §8d "
+                          "(6 B per live node + size + dataset + fitness) x the trees of the launch",
+                "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
+                "call_ms": call_ms, "stage_ms": stage_ms,
+                "frac_whole_call": alg_bytes / (call_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                "valu_issue": valu,
+                "note": "stack-machine interpreter: ~0.16 algorithmic B per tree-eval at D=1024, so the HBM fraction is small by construction "
+                        "(SURVEY.md §7.3-1); the binding resource is VALU issue (valu_issue.frac) plus per-instruction dispatch latency. "
+                        "kernel_ms: HIP events around the interpreter launch inside the call (a second pass of the same steps); "
+                        "call_ms: event pair around the timed steps (compiler + interpreter + follow-up launches)",
+            },
+        }
+        out.update(extras)
+        if with_cpu_baseline and not args.no_cpu_baseline and world == 1 and not args.headline_only:
+            try:
+                out["cpu_baseline"] = cpu_baseline(forest, X, y, device)
+            except Exception as exc:
+                out["cpu_baseline"] = {"value": None, "error": repr(exc)[:300]}
+        print(json.dumps(out), flush=True)
+
+    # Everything below is extra: the headline is measured.  With several ranks the extras contain collectives of their own; a rank
+    # that fails or hangs there must not take the line (or the launcher) with it: after EXTRAS_TIMEOUT_S every rank leaves, rank 0
+    # printing the line with the extras it has.
     extras = {}
+    emit_lock, emitted = threading.Lock(), []
+
+    def bail():
+        if rank == 0:
+            emit(dict(extras, extras_aborted=f"the extra measurements did not finish within {EXTRAS_TIMEOUT_S} s"), with_cpu_baseline=False)
+        sys.stdout.flush()
+        os._exit(0)
+
+    watchdog = None
+    if world > 1:
+        watchdog = threading.Timer(EXTRAS_TIMEOUT_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
     if not args.headline_only:
         # the same launch in the other division modes of the fitness path (include/evogp_hip.h), for the record
         div_ms = {}
@@ -386,69 +472,12 @@ def main():
             extras["vis_ipynb_config"] = {"error": repr(exc)[:300]}
 
     if rank == 0:
-        evals = float(P) * DATAPOINTS * args.steps
-        kernel_s = stage_ms["interpreter"] / 1e3 if stage_ms["calls"] else call_ms / 1e3
-        alg_bytes = 6.0 * total_nodes + 2.0 * pop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * pop  # SURVEY.md §8d, this rank's launch
-        achieved = alg_bytes / kernel_s / 1e9
-        traffic, traffic_note = None, "no PMC record for this build"
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                if pj.get("source_sha") == source_sha() and pj.get("pop_per_launch") == pop:
-                    traffic = pj.get("sr_tc_kernel_hbm_bytes_per_launch")
-                    traffic_note = f"FETCH_SIZE + WRITE_SIZE of the interpreter kernel, rocprofv3 --pmc, measured on this source ({pj.get('source_sha')}): {pj.get('files')}"
-                else:
-                    traffic_note = (f"profiles/pmc_latest.json was measured on source {pj.get('source_sha')} / {pj.get('pop_per_launch')} trees per launch, "
-                                    f"this is {source_sha()} / {pop}: not quoted")
-            except Exception:
-                pass
-        out = {
-            "metric": "tree_evals_per_s",
-            "value": evals / elapsed,
-            "unit": "tree-evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1000.0,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic" if not share_gpu else "synthetic; FUNCTIONAL CHECK ONLY: ranks share a GPU over gloo",
-            "config": {
-                "workload": f"BASELINE north_star / configs[2] shape: SymbolicRegression synthetic 10-var, GLOBAL pop={P} x 1024 datapoints, "
-                            "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass over every rank's shard per step",
-                "global_pop": P, "pop_per_gpu": pop, "datapoints": DATAPOINTS, "var_len": VAR_LEN, "max_tree_len": GP_LEN,
-                "mean_tree_len": all_nodes / P, "sharding": f"trees x{world} (contiguous shards, tree-index offset), no data-path collective in the step",
-                "ranks": world, "backend": backend,
-            },
-            "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_note": traffic_note,
-                "kernel": "sr_tc_kernel<8,false,2> (threaded-code interpreter, short division), rank 0's launch; algorithmic bytes = SURVEY.md §8d "
-                          "(6 B per live node + size + dataset + fitness) x the trees of the launch",
-                "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
-                "call_ms": call_ms, "stage_ms": stage_ms,
-                "frac_whole_call": alg_bytes / (call_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
-                "valu_issue": valu,
-                "note": "stack-machine interpreter: ~0.16 algorithmic B per tree-eval at D=1024, so the HBM fraction is small by construction "
-                        "(SURVEY.md §7.3-1); the binding resource is VALU issue (valu_issue.frac) plus per-instruction dispatch latency. "
-                        "kernel_ms: HIP events around the interpreter launch inside the call (a second pass of the same steps); "
-                        "call_ms: event pair around the timed steps (compiler + interpreter + follow-up launches)",
-            },
-        }
-        out.update(extras)
-        if not args.no_cpu_baseline and world == 1 and not args.headline_only:
-            try:
-                out["cpu_baseline"] = cpu_baseline(forest, X, y, device)
-            except Exception as exc:
-                out["cpu_baseline"] = {"value": None, "error": repr(exc)[:300]}
-        print(json.dumps(out), flush=True)
+        emit(extras)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":
