@@ -58,14 +58,14 @@ class StandardPipeline(BasePipeline):
             if self.is_show_details:
                 self.show_details(tic, generation, self.fitness)
             if self.fitness_target is not None and self.best_fitness >= self.fitness_target:
-                print("Fitness target reached!")
+                print(f"stopped: best fitness {float(self.best_fitness):.6g} reached the target {self.fitness_target}")
                 break
             if self.time_limit is not None and time.time() - start > self.time_limit:
-                print("Time limit reached!")
+                print(f"stopped: {self.time_limit} s time limit")
                 break
             generation += 1
             if generation >= self.generation_limit:
-                print("Generation limit reached!")
+                print(f"stopped: {self.generation_limit} generations")
                 break
         return self.best_tree
 
@@ -73,9 +73,8 @@ class StandardPipeline(BasePipeline):
         b = self.valid_fitness_boundry
         valid = fitness[(fitness < b) & (fitness > -b)]
         ms = (time.time() - tic) * 1000
+        line = f"gen {generation:4d}  {ms:8.2f} ms  {len(valid)} of {len(fitness)} finite"
         if len(valid):
-            stats = (f"max: {float(valid.max()):.4f}, min: {float(valid.min()):.4f}, "
-                     f"mean: {float(valid.mean()):.4f}, std: {float(valid.std(unbiased=False)):.4f}")
-        else:
-            stats = "no valid fitness"
-        print(f"Generation: {generation}, Cost time: {ms:.2f}ms\n", f"\tfitness: valid cnt: {len(valid)}, {stats}\n")
+            line += (f"  best {float(valid.max()):.4f}  mean {float(valid.mean()):.4f} +- {float(valid.std(unbiased=False)):.4f}"
+                     f"  worst {float(valid.min()):.4f}")
+        print(line)

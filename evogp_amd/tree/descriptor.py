@@ -17,23 +17,24 @@ from torch import Tensor
 from .utils import FUNCS_NAMES, MAX_FULL_DEPTH, MAX_STACK, Func, check_tensor, default_device, dict2prob, func_arity
 
 
+def _need(ok: bool, message: str) -> None:
+    """argument errors are AssertionErrors, as in the reference (its constructor is a chain of asserts)"""
+    if not ok:
+        raise AssertionError(message)
+
+
 def check_tree_length(max_tree_len, using_funcs, max_layer_cnt, layer_leaf_prob) -> Tensor:
-    """Assert that a full tree of ``max_layer_cnt`` layers with the largest arity in use fits in
-    ``max_tree_len`` nodes, and build ``depth2leaf_probs`` (descriptor.py:8-39)."""
-    for name in using_funcs:
-        assert name in FUNCS_NAMES, f"Unknown function name: {name}, total functions are {FUNCS_NAMES}"
-    max_arity = max(func_arity(FUNCS_NAMES.index(name)) for name in using_funcs)
-    if max_arity > 1:
-        full_len = int((max_arity**max_layer_cnt - 1) / (max_arity - 1))
-    else:
-        full_len = max_layer_cnt
-    assert max_tree_len >= full_len, (
-        f"max_tree_len={max_tree_len} is too small\n"
-        f"max_tree_len should >={full_len}\n"
-        f"as the max arity of funcs is {max_arity} and the max layer is {max_layer_cnt}."
-    )
-    inner = max_layer_cnt - 1
-    return torch.tensor([layer_leaf_prob] * inner + [1.0] * (MAX_FULL_DEPTH - inner), device=default_device())
+    """``depth2leaf_probs`` for trees of at most ``max_layer_cnt`` layers — after checking that the LARGEST such tree (every
+    node a function of the widest arity in use) fits a row of ``max_tree_len`` nodes (descriptor.py:8-39)."""
+    unknown = [name for name in using_funcs if name not in FUNCS_NAMES]
+    _need(not unknown, f"function name(s) {unknown} not among {FUNCS_NAMES}")
+    widest = max(func_arity(FUNCS_NAMES.index(name)) for name in using_funcs)
+    # 1 + a + a^2 + ... + a^(layers - 1) nodes
+    largest = max_layer_cnt if widest <= 1 else (widest**max_layer_cnt - 1) // (widest - 1)
+    _need(max_tree_len >= largest,
+          f"a full tree of {max_layer_cnt} layers of arity-{widest} functions has {largest} nodes: max_tree_len={max_tree_len} cannot hold it")
+    function_layers = max_layer_cnt - 1
+    return torch.tensor([layer_leaf_prob] * function_layers + [1.0] * (MAX_FULL_DEPTH - function_layers), device=default_device())
 
 
 class GenerateDescriptor:
@@ -55,65 +56,65 @@ class GenerateDescriptor:
     ):
         self._ctor_kwargs = {k: v for k, v in locals().items() if k not in ("self", "__class__")}
 
-        assert max_tree_len <= MAX_STACK, f"max_tree_len={max_tree_len} is too large, MAX_STACK={MAX_STACK}"
-        assert isinstance(input_len, int) and input_len > 0, "input_len should be a positive integer"
-        assert isinstance(output_len, int) and output_len > 0, "output_len should be a positive integer"
-        assert 0.0 <= const_prob <= 1.0, "const_prob should be in [0.0, 1.0]"
-        assert 0.0 <= out_prob <= 1.0, "out_prob should be in [0.0, 1.0]"
+        _need(max_tree_len <= MAX_STACK, f"rows of {max_tree_len} nodes exceed the operand-stack bound of the kernels ({MAX_STACK})")
+        for name, n in (("input_len", input_len), ("output_len", output_len)):
+            _need(isinstance(n, int) and n > 0, f"{name} must be a positive int, got {n!r}")
+        for name, q in (("const_prob", const_prob), ("out_prob", out_prob)):
+            _need(0.0 <= q <= 1.0, f"{name} is a probability, got {q}")
         if output_len > 1 and out_prob == 0.0:
-            warnings.warn(f"output_len={output_len} > 1, but out_prob={out_prob} is 0.0.")
+            warnings.warn(f"{output_len} outputs but out_prob = 0: no generated node will ever write one")
 
-        dev = default_device()
-        if depth2leaf_probs is None:
-            assert max_layer_cnt is not None, "max_layer_cnt should not be None when depth2leaf_probs is None"
-            assert layer_leaf_prob is not None, "layer_leaf_prob should not be None when depth2leaf_probs is None"
-            depth2leaf_probs = check_tree_length(max_tree_len, using_funcs, max_layer_cnt, layer_leaf_prob)
+        self.max_tree_len, self.input_len, self.output_len = max_tree_len, input_len, output_len
+        self.const_prob, self.out_prob = const_prob, out_prob
+        self.depth2leaf_probs = self._leaf_probabilities(depth2leaf_probs, max_tree_len, using_funcs, max_layer_cnt, layer_leaf_prob)
+        self.roulette_funcs, self.roulette_ufuncs, self.roulette_bfuncs, self.roulette_tfuncs = self._roulettes(roulette_funcs, using_funcs)
+        self.const_samples = self._constants(const_samples, const_range, sample_cnt)
 
-        roulette_ufuncs = roulette_bfuncs = roulette_tfuncs = None
-        if roulette_funcs is None:
-            assert using_funcs is not None, "func_prob should not be None when roulette_funcs is None"
-            assert isinstance(using_funcs, (dict, list)), "func_prob should be a dictionary or a list"
-            weights = {f: 1.0 for f in using_funcs} if isinstance(using_funcs, list) else using_funcs
+    @staticmethod
+    def _as_f32(t, what, shape=None) -> Tensor:
+        t = check_tensor(t).to(torch.float32).contiguous()
+        if shape is not None:
+            _need(tuple(t.shape) == shape, f"{what} must have shape {shape}, got {tuple(t.shape)}")
+        return t
+
+    def _leaf_probabilities(self, given, max_tree_len, using_funcs, max_layer_cnt, layer_leaf_prob) -> Tensor:
+        """f32[10]: probability that a node generated at depth d is a leaf (descriptor.py:33-38, 93-100)"""
+        if given is None:
+            _need(max_layer_cnt is not None and layer_leaf_prob is not None,
+                  "without depth2leaf_probs, max_layer_cnt and layer_leaf_prob define the tree shape: both are required")
+            given = check_tree_length(max_tree_len, using_funcs, max_layer_cnt, layer_leaf_prob)
+        return self._as_f32(given, "depth2leaf_probs", (MAX_FULL_DEPTH,))
+
+    def _roulettes(self, given, using_funcs):
+        """f32[29] cumulative function weights (descriptor.py:106-111) and, when built from ``using_funcs``, one cumulative
+        table per arity class for the point mutations (:113-139: the class's weights in place, zeros elsewhere)"""
+        per_arity = (None, None, None)
+        if given is None:
+            _need(isinstance(using_funcs, (dict, list)), "without roulette_funcs, using_funcs (a list of names or a name -> weight dict) is required")
+            weights = dict.fromkeys(using_funcs, 1.0) if isinstance(using_funcs, list) else using_funcs
             prob = dict2prob(weights)
-            roulette_funcs = torch.cumsum(prob, dim=0, dtype=torch.float32).to(dev)
+            dev = default_device()
+            given = torch.cumsum(prob, dim=0, dtype=torch.float32).to(dev)
 
-            def masked_roulette(lo, hi):
-                part = torch.zeros_like(prob)
-                part[lo:hi] = prob[lo:hi]
-                return torch.cumsum(part, dim=0, dtype=torch.float32).to(dev)
+            def of_class(lo, hi):
+                only = torch.zeros_like(prob)
+                only[lo:hi] = prob[lo:hi]
+                return torch.cumsum(only, dim=0, dtype=torch.float32).to(dev)
 
-            roulette_tfuncs = masked_roulette(Func.TF_START, Func.BF_START)
-            roulette_bfuncs = masked_roulette(Func.BF_START, Func.UF_START)
-            roulette_ufuncs = masked_roulette(Func.UF_START, Func.END)
+            per_arity = (of_class(Func.UF_START, Func.END), of_class(Func.BF_START, Func.UF_START), of_class(Func.TF_START, Func.BF_START))
+        return (self._as_f32(given, "roulette_funcs", (Func.END,)),) + per_arity
 
-        if const_samples is None:
-            assert const_range is not None, "const_range should not be None when const_samples is None"
-            assert sample_cnt is not None, "sample_cnt should not be None when const_samples is None"
-            const_samples = torch.rand(sample_cnt, device=dev) * (const_range[1] - const_range[0]) + const_range[0]
-        if isinstance(const_samples, list):
-            const_samples = torch.tensor(const_samples, dtype=torch.float32, device=dev)
-
-        depth2leaf_probs = check_tensor(depth2leaf_probs).to(torch.float32).contiguous()
-        roulette_funcs = check_tensor(roulette_funcs).to(torch.float32).contiguous()
-        const_samples = check_tensor(const_samples).to(torch.float32).contiguous()
-
-        assert depth2leaf_probs.shape == (MAX_FULL_DEPTH,), (
-            f"depth2leaf_probs shape should be ({MAX_FULL_DEPTH}), but got {depth2leaf_probs.shape}")
-        assert roulette_funcs.shape == (Func.END,), (
-            f"roulette_funcs shape should be ({Func.END}), but got {roulette_funcs.shape}")
-        assert const_samples.dim() == 1, f"const_samples dim should be 1, but got {const_samples.dim()}"
-
-        self.max_tree_len = max_tree_len
-        self.input_len = input_len
-        self.output_len = output_len
-        self.const_prob = const_prob
-        self.out_prob = out_prob
-        self.depth2leaf_probs = depth2leaf_probs
-        self.roulette_funcs = roulette_funcs
-        self.roulette_ufuncs = roulette_ufuncs
-        self.roulette_bfuncs = roulette_bfuncs
-        self.roulette_tfuncs = roulette_tfuncs
-        self.const_samples = const_samples
+    def _constants(self, given, const_range, sample_cnt) -> Tensor:
+        """f32[n]: the pool constants are drawn from — given, or ``sample_cnt`` uniform draws in ``const_range``"""
+        if given is None:
+            _need(const_range is not None and sample_cnt is not None, "without const_samples, const_range and sample_cnt are required")
+            lo, hi = const_range
+            given = torch.rand(sample_cnt, device=default_device()) * (hi - lo) + lo
+        elif isinstance(given, list):
+            given = torch.tensor(given, dtype=torch.float32, device=default_device())
+        given = self._as_f32(given, "const_samples")
+        _need(given.dim() == 1, f"const_samples is a flat pool of values, got {given.dim()} dimensions")
+        return given
 
     def update(self, **kwargs) -> "GenerateDescriptor":
         """A new descriptor built from the stored constructor arguments overridden by ``kwargs``
