@@ -72,7 +72,7 @@ HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top o
 SLOT = 256  # bytes per handler slot
 DIVIP_REGS = 5  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
 DIVIP = ("SS", "SC", "CS")  # division forms with an in-place handler (operands read where they are, temporaries above the stack)
-NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP)  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions
+NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
@@ -134,7 +134,10 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     CUR, END_, STRIDE, DYN, PF, BASE = "%[cur]", "%[lim]", "%[stride]", "%[dyn]", "%[pf]", "%[base]"
     uid = "%="
     L = []
-    a = L.append
+    sect = [L]   # the list instructions are appended to (the program's tail is generated late but placed early, see below)
+
+    def a(line):
+        sect[0].append(line)
 
     def lab(n):
         return f".Ltc_{n}_{uid}"
@@ -153,7 +156,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     hid["gun_S"], hid["gun_V"], hid["if_sss"], hid["acc_s"], hid["mo_begin"], hid["end_mo"] = (nh + 8 + i for i in range(6))
     for i, form in enumerate(DIVIP):
         hid[f"divip_{form}"] = nh + 14 + i
-    assert NHF == nh + 14 + len(DIVIP)
+    hid["end_cls"] = nh + 14 + len(DIVIP)
+    assert NHF == nh + 14 + len(DIVIP) + 1
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -792,6 +796,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 a(f"s_movrels_b32 s{sBop}, s{W + 1}")
             prefetch(nxt)
             a(f"s_branch {lab(f'divip_body_{form}{fl}')}")
+        # ---- end of a CLASSIFIER program (no counterpart in forward.cu: the reference's Classification problem computes
+        # batch_forward + soft-max + arg-max + compare in torch, classification.py:62-75): the class labels of the tile's rows
+        # were prefetched into this flavour's bank like the regression labels of END; they move to the T bank for the shared body
+        begin("end_cls", fl)
+        read_aux(T2)
+        a("s_waitcnt lgkmcnt(0)")
+        for k in range(K):
+            a(f"v_mov_b32 v{T + k}, v{P[fl] + k}")
+        a(f"s_branch {lab('endcls_body')}")
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # In-place division bodies.  The gather forms above copy the operands into fixed banks because the division's temporaries
@@ -1093,7 +1106,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"v_max_f32 v{tx}, v{tx}, |v{rest[0]}|")
         a(f"s_mov_b32 s{T1}, 0x48000000")             # 2^17
         a(f"v_cmp_le_f32 vcc, s{T1}, v{tx}")
-        a(f"s_cbranch_vccnz {lab('bail')}")
+        a(f"s_cbranch_vccnz {lab('bail_far')}")
         for k in range(K):
             x, res = T + k, Q + k
             a(f"s_mov_b32 s{T1}, 0x3f22f983")         # 2 / pi
@@ -1237,6 +1250,18 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         for k in range(K):
             a(f"v_mov_b32 v{S0 + k}, v{Q + k}")
         epilogue()
+    # The bodies above sit behind the 64-KiB-aligned handler table; the wave's outer loops sit in front of it, up to 64 KiB of
+    # padding away.  A branch reaches 128 KiB: the pieces that jump BACK into the outer loops -- the run-time bail-out and
+    # everything from the END handlers to the end of the kernel -- are therefore placed in front of the padding (reached from the
+    # table's slots), and the one jump to them from a body behind the table goes through a computed address.
+    a(f"{lab('bail_far')}:")
+    a(f"s_getpc_b64 s[{T1}:{T2}]")
+    a(f"{lab('bail_pc')}:")
+    a(f"s_add_u32 s{T1}, s{T1}, {lab('bail')}-{lab('bail_pc')}")
+    a(f"s_addc_u32 s{T2}, s{T2}, -1")             # (the distance is negative: sign extension of its low word)
+    a(f"s_setpc_b64 s[{T1}:{T2}]")
+    tail = []
+    sect[0] = tail
     # runtime bail-out: this tree needs something the handlers do not carry.  Its fitness word gets the sentinel of the
     # register kernels, their pending flag is raised (flags bit 16: the call has a marks block, 128 bytes in front of the
     # first counter line), and the wave goes on with its next tree.
@@ -1313,6 +1338,89 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"v_add_u32 v4, s{sA}, v4")
     a(f"s_cmp_lt_u32 s{sX}, s{T2}")
     a(f"s_cbranch_scc1 {lab('endmo_loop')}")
+    a("s_set_gpr_idx_off")
+    a(f"s_add_u32 s{T1}, s{sTILE}, 1")
+    a(f"s_branch {lab('end_acc')}")
+
+    # end of a classifier program: per row the arg-max over the out_len accumulators as torch.argmax(clip(softmax(x))) sees it
+    # -- the FIRST maximum; index 0 when any output is NaN or the maximum is infinite (the soft-max row is then NaN or 0/1 only) --
+    # compared with the row's label; v6 counts the hits (as a float: exact below 2^24 rows).  aux = K * out_len is in T2, the
+    # labels (int32 bits) in the T bank.  Row registers: maximum M in P0, sum in P1 (a NaN sum <=> a NaN output, or both
+    # infinities -- which the infinite maximum already covers), arg-max in Q.
+    Mx, Sm, Bx = P[0], P[1], Q
+    a(f"{lab('endcls_body')}:")
+    a(f"s_mov_b32 m0, {hex(MODE['SRC0'] << 12)}")     # output 0
+    for k in range(K):
+        a(f"v_mov_b32 v{Mx + k}, v{S0 + k}")
+    for k in range(K):
+        a(f"v_mov_b32 v{Sm + k}, v{Mx + k}")
+        a(f"v_mov_b32 v{Bx + k}, 0")
+    a("s_mov_b32 m0, 0")
+    a(f"s_mov_b32 s{sX}, {K}")                         # K * output index
+    a(f"s_cmp_lt_u32 s{sX}, s{T2}")
+    a(f"s_cbranch_scc0 {lab('endcls_first')}")
+    a(f"{lab('endcls_max')}:")
+    a(f"s_add_u32 m0, s{sX}, {hex(MODE['SRC0'] << 12)}")
+    for k in range(K):
+        a(f"v_max_f32 v{Mx + k}, v{S0 + k}, v{Mx + k}")
+        a(f"v_add_f32 v{Sm + k}, v{S0 + k}, v{Sm + k}")
+    a(f"s_add_u32 s{sX}, s{sX}, {K}")
+    a(f"s_cmp_lt_u32 s{sX}, s{T2}")
+    a(f"s_cbranch_scc1 {lab('endcls_max')}")
+    # the first output that equals the maximum: from the last output down to output 1, a later hit overwritten by an earlier one
+    a(f"s_sub_u32 s{sX}, s{T2}, {K}")
+    a(f"{lab('endcls_arg')}:")
+    a(f"s_add_u32 m0, s{sX}, {hex(MODE['SRC0'] << 12)}")
+    a(f"s_lshr_b32 s{T1}, s{sX}, {K.bit_length() - 1}")   # output index = sX / K (K is a power of two)
+    for k in range(K):
+        # (source 0 is M0-relative inside this loop, so the running arg-max cannot be a select's source there, and an SGPR index
+        # plus VCC would be two constant-bus operands: the compare writes EXEC instead and the index is moved under it)
+        a(f"v_cmpx_eq_f32 exec, v{S0 + k}, v{Mx + k}")
+        a(f"v_mov_b32 v{Bx + k}, s{T1}")
+        a("s_mov_b64 exec, -1")
+    a(f"s_sub_u32 s{sX}, s{sX}, {K}")
+    a(f"s_cmp_ge_i32 s{sX}, 0")
+    a(f"s_cbranch_scc1 {lab('endcls_arg')}")
+    a(f"{lab('endcls_first')}:")
+    a("s_mov_b32 m0, 0")
+    a(f"s_movk_i32 s{T1}, 0x204")                      # -inf | +inf
+    for k in range(K):
+        a(f"v_cmp_class_f32_e64 vcc, v{Mx + k}, s{T1}")
+        a("s_nop 1")
+        a(f"v_cndmask_b32_e64 v{Bx + k}, v{Bx + k}, 0, vcc")
+        a(f"v_cmp_u_f32 vcc, v{Sm + k}, v{Sm + k}")
+        a("s_nop 1")
+        a(f"v_cndmask_b32_e64 v{Bx + k}, v{Bx + k}, 0, vcc")
+    # hits: rows of this tile that exist (flags bit 1 / bit 4 as in END) and whose arg-max is their label
+    a(f"s_add_u32 s{T1}, s{sTILE}, 1")
+    a(f"s_cmp_lt_u32 s{T1}, s15")
+    a(f"s_cselect_b32 s{T1}, 0, s17")
+    a("s_bitcmp1_b32 s17, 4")
+    a(f"s_cselect_b32 s{T1}, s17, s{T1}")
+    a(f"s_and_b32 s{T1}, s{T1}, 2")
+    a(f"s_cmp_eq_u32 s{T1}, 0")
+    a(f"s_cbranch_scc1 {lab('endcls_full')}")
+    a(f"s_mul_i32 s{T4}, s{sTILE}, {64 * K}")
+    a(f"v_mul_u32_u24 v5, {RPL}, v0")
+    a(f"v_add_u32 v5, s{T4}, v5")
+    for k in range(K):
+        g, q = divmod(k, 4)
+        a(f"v_add_u32 v9, {g * 256 + q}, v5")
+        a(f"v_cmp_eq_u32 vcc, v{Bx + k}, v{T + k}")
+        a("s_nop 1")
+        a("v_cndmask_b32_e64 v4, 0, 1.0, vcc")
+        a("v_cmp_gt_u32 vcc, s13, v9")
+        a("s_nop 1")
+        a("v_cndmask_b32 v4, 0, v4, vcc")
+        a("v_add_f32 v6, v6, v4")
+    a(f"s_branch {lab('endcls_done')}")
+    a(f"{lab('endcls_full')}:")
+    for k in range(K):
+        a(f"v_cmp_eq_u32 vcc, v{Bx + k}, v{T + k}")
+        a("s_nop 1")
+        a("v_cndmask_b32_e64 v4, 0, 1.0, vcc")
+        a("v_add_f32 v6, v6, v4")
+    a(f"{lab('endcls_done')}:")
     a("s_set_gpr_idx_off")
     a(f"s_add_u32 s{T1}, s{sTILE}, 1")
     a(f"s_branch {lab('end_acc')}")
@@ -1473,6 +1581,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"global_atomic_add_x2 v[10:11], v[12:13], off offset:{8 * i}")
         a("s_waitcnt vmcnt(0)")
     a("s_endpgm")
+    sect[0] = L
+    at = L.index(".p2align 16")
+    L[at:at] = tail
 
     if info is not None:
         info["K"], info["depth"], info["nhandlers"], info["slot"] = K, DEPTH, NHF, SLOT

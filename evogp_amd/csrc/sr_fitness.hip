@@ -494,6 +494,26 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
 
 } // namespace evogp
 
+namespace evogp {
+
+hipError_t run_argmax_count_threaded(const SrParams &p_in, const int *labels, unsigned *counts, unsigned *wide_marks, hipStream_t stream, bool *handled) {
+    *handled = false;
+    static const int asm_depth = env_int("EVOGP_SR_ASM", EVOGP_SR_DEFAULT_ASM);
+    if (asm_depth != 3) return hipSuccess;
+    SrParams p = p_in;
+    std::lock_guard<std::mutex> chain_lock(g_chain_mu);   // (the call-scratch chain of run_population)
+    hipError_t e;
+    p.marks = acquire_call_scratch(stream, &p.zero_next, &e);
+    if (!p.marks) return e;
+    if ((e = launch_threaded_code(p, stream, handled, &p.mark_sample, &p.mark_chunks)) != hipSuccess) return e;
+    if (!*handled) {  // not eligible: the scratch block stays clean for the next call, nothing to undo
+        return hipSuccess;
+    }
+    return launch_tc_count(counts, p.pop, labels, p.D, wide_marks, stream);
+}
+
+} // namespace evogp
+
 using namespace evogp;
 
 extern "C" int evogp_hip_sr_fitness(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len,

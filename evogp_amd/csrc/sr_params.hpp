@@ -22,6 +22,8 @@ struct SrParams {
     unsigned *counter; // batch counter (zeroed before the launch)
     int pop, D, gp_len, var_len, out_len;
     int use_mse;
+    int classify;    // threaded code only: y holds ONE column of int32 class labels; fitness[t] receives the number of rows whose
+                     // arg-max output is their label (as a float; tc_count_kernel turns the words into the caller's counts)
     int batch;       // trees per batch, <= kMaxBatch
     int ntiles;      // ceil(D / (64*K))
     int only_marked; // != 0: only trees whose output word holds kSentinelHeavy are evaluated
@@ -38,6 +40,13 @@ struct SrParams {
 // assembly core.  Returns hipSuccess and sets *handled when it took the launch (trees it could not take are
 // marked kSentinelHeavy / NaN in p.fitness for the follow-up kernels); *handled == false means "not eligible".
 hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled, int *mark_sample, int *mark_chunks);
+
+// Classification epilogue on the threaded code (sr_fitness.hip: it shares the call-scratch chain with the fitness calls):
+// counts[t] = rows whose arg-max output equals labels[row]; trees the path cannot take come back with kDeepCountBit set and
+// wide_marks[1] raised for sr_wide.hip's recount kernel.  *handled == false: not eligible, nothing was launched.
+constexpr unsigned kDeepCountBit = 0x80000000u;  // set in counts[t] for a tree that wide_deep_count_kernel still has to count
+hipError_t run_argmax_count_threaded(const SrParams &p, const int *labels, unsigned *counts, unsigned *wide_marks, hipStream_t stream, bool *handled);
+hipError_t launch_tc_count(unsigned *counts, int pop, const int *labels, int D, unsigned *wide_marks, hipStream_t stream);
 
 // Tile-group kernel for shapes the register kernels cannot keep resident (sr_wide.hip): STORE mode of batch_evaluate.
 hipError_t launch_wide_store(const SrParams &p, hipStream_t stream);

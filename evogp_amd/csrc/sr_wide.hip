@@ -42,7 +42,6 @@ struct WideParams {
 
 constexpr int kWideWaves = 8;
 struct __attribute__((packed, aligned(4))) Unaligned4 { float x, y, z, w; };  // 16-byte store at 4-byte alignment
-constexpr unsigned kDeepCountBit = 0x80000000u;  // MODE 1: set in counts[t] for a tree the register stack cannot hold
 
 // MODE 1 follow-up: trees marked deep are counted with the scratch-stack interpreter, one wave per tree, lanes over rows
 __global__ __launch_bounds__(64) void wide_deep_count_kernel(WideParams p) {
@@ -286,12 +285,28 @@ extern "C" int evogp_hip_batch_argmax_count(unsigned pop_size, unsigned data_poi
     if (!value || !type || !size || !variables || !labels || !counts) return EVOGP_E_NULLPTR;
     if (out_len > (unsigned)kMaxOutRegs || (size_t)var_len * 256 > 150 * 1024) return EVOGP_E_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
-    hipError_t e = hipMemsetAsync(counts, 0, (size_t)pop_size * sizeof(unsigned), stream);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e;
     WideParams p{};
     p.marks = acquire_counter(stream, &e);  // [1] != 0: some tree was too deep for the register stack
     if (!p.marks) return (int)e;
     p.value = value; p.type = type; p.size = size; p.X = variables; p.labels = labels; p.counts = counts;
     p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len; p.out_len = (int)out_len;
+    // first choice: compiled programs on the threaded-code interpreter with the classifier's END handler (3-4 x the tile-group
+    // kernel at the UCI classifier shape); what it leaves marked is recounted by wide_deep_count_kernel
+    static const bool tc_ok = [] { const char *v = getenv("EVOGP_TC_CLASSIFY"); return !(v && v[0] == '0'); }();
+    if (tc_ok) {
+        SrParams s{};
+        s.value = value; s.type = type; s.size = size; s.X = variables; s.y = (const float *)labels; s.fitness = (float *)counts;
+        s.pop = p.pop; s.D = p.D; s.gp_len = p.gp_len; s.var_len = p.var_len; s.out_len = p.out_len; s.use_mse = 0; s.classify = 1;
+        bool handled = false;
+        if ((e = run_argmax_count_threaded(s, labels, counts, p.marks, stream, &handled)) != hipSuccess) return (int)e;
+        if (handled) {
+            long blocks = (long)device_info().num_cus * 4;
+            if (blocks > p.pop) blocks = p.pop;
+            hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, p);
+            return (int)hipGetLastError();
+        }
+    }
+    if ((e = hipMemsetAsync(counts, 0, (size_t)pop_size * sizeof(unsigned), stream)) != hipSuccess) return (int)e;
     return (int)launch_wide<true, 1>(p, stream);
 }

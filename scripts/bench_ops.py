@@ -108,6 +108,17 @@ def acc():
 us = timed(acc, 5)
 row("batch_argmax_count (C4 shape, pop 20k)", us, 6.0 * cs_[:, 0].to(torch.int64).sum().item() + 4.0 * pc + 4.0 * Dc * 65, f"fused classification epilogue: {pc * Dc / us / 1e3:.1f} G tree-evals/s, only the per-tree counts leave the chip")
 
+# BASELINE configs[3] in full: pop 200k (example/uci_classifier.py), the fitness pass of the Classification problem
+pf_ = 200_000
+fv = torch.empty((pf_, Lc), dtype=torch.float32, device=g.DEV); ft = torch.empty((pf_, Lc), dtype=torch.int16, device=g.DEV); fs = torch.empty((pf_, Lc), dtype=torch.int16, device=g.DEV)
+assert L_.evogp_hip_generate(pf_, Lc, 64, 10, 3, 0.5, 0.5, keys.data_ptr(), d2l6.data_ptr(), rou.data_ptr(), cs.data_ptr(), fv.data_ptr(), ft.data_ptr(), fs.data_ptr(), 0, S()) == 0
+fcounts = torch.empty(pf_, dtype=torch.int32, device=g.DEV)
+def accf():
+    assert L_.evogp_hip_batch_argmax_count(pf_, Dc, Lc, 64, 10, fv.data_ptr(), ft.data_ptr(), fs.data_ptr(), Xc.data_ptr(), labels.data_ptr(), fcounts.data_ptr(), S()) == 0
+us = timed(accf, 5)
+row("batch_argmax_count (configs[3]: pop 200k)", us, 6.0 * fs[:, 0].to(torch.int64).sum().item() + 4.0 * pf_ + 4.0 * Dc * 65, f"pop {pf_}, L {Lc}, in 64, out 10, D {Dc}: {pf_ * Dc / us / 1e3:.1f} G tree-evals/s")
+del fv, ft, fs
+
 # single-output batch evaluation over a long dataset (Transformation / torch-mode SR): pop 50k, L 64, in 10, D 4096
 ps, Ds = 50_000, 4096
 Xs = torch.rand(Ds, 10, device=g.DEV) * 10 - 5; outs_ = torch.empty((ps, Ds, 1), dtype=torch.float32, device=g.DEV)

@@ -301,6 +301,31 @@ def test_small_dataset_library_functions_match_the_register_kernels(g, oracle, r
     assert np.allclose(got[both], ref[both], rtol=2e-5, atol=1e-30)
 
 
+# ---- classification epilogue on the threaded code ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("var_len,out_len,D", [(4, 2, 8), (4, 3, 64), (4, 3, 65), (4, 3, 200), (3, 5, 512), (4, 3, 700), (64, 10, 300), (64, 10, 1797), (30, 6, 2500)])
+def test_classifier_count_on_the_threaded_code(g, oracle, rng, var_len, out_len, D):
+    """evogp_hip_batch_argmax_count through compiled programs and the END_CLS handler (one column of int32 class labels staged
+    behind X, per row the arg-max over the output accumulators as torch.argmax(clip(softmax(x))) sees it, hits counted per tree;
+    datasets beyond LDS in pieces whose counts add up) against the torch rule on the oracle's outputs.  IEEE-exact function set
+    with divisions: rows with NaN / infinite outputs (arg-max 0) occur; exact ties between soft-max probabilities that differ
+    before rounding are the only legitimate difference."""
+    import torch
+
+    funcs = [ADD, SUB, MUL, DIV, MAX, NEG]
+    pop = 1200
+    f = oracle.generate(pop, 64, var_len, out_len, 0.5, 0.5, [D, out_len], depth2leaf(5, 0.1), roulette_uniform(funcs), [-1.0, 0.0, 1.0, 0.5])
+    X = rng.uniform(-4, 4, (D, var_len)).astype(np.float32)
+    X[rng.random((D, var_len)) < 0.05] = 0.0
+    labels = rng.integers(0, out_len, D).astype(np.int32)
+    got = g.batch_argmax_count(*f, X, labels, out_len)
+    h = handler_histogram(g, pop)
+    assert h["end_cls"] >= 0.9 * pop, f"only {h['end_cls']} of {pop} programs end in the classifier handler"
+    outs = torch.from_numpy(oracle.batch_evaluate(*f, X, out_len))
+    pred = torch.argmax(torch.clip(torch.softmax(outs, dim=2), 1e-15, 1 - 1e-15), dim=2)
+    want = (pred == torch.from_numpy(labels.astype(np.int64))[None, :]).sum(1).numpy()
+    assert np.abs(got - want).max() <= 2 and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())
+
+
 def test_chunked_pipeline_on_a_large_population(g, oracle):
     """a population beyond the sizes of the other tests (and, with EVOGP_TC_CHUNKS set, the chunked two-stream pipeline of
     sr_tc.hip): the result must equal that of the halves run on their own, and the oracle's on a sample"""
