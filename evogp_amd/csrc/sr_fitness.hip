@@ -287,7 +287,10 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
 template <bool MO, bool STORE>
 __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_marked) {
     const int lane = threadIdx.x & 63;
-    if (only_marked && p.marks && uni((int)p.marks[1]) == 0) return;  // no tree needs the general path
+    // only_marked 1: behind the register kernels, the trees they marked too deep; 2: behind the threaded code alone (more
+    // variables than the register kernels take), every tree it left marked
+    if (only_marked == 1 && p.marks && uni((int)p.marks[1]) == 0) return;  // no tree needs the general path
+    if (only_marked == 2 && p.marks && !marks_pending(p, 0) && uni((int)p.marks[1]) == 0) return;
     float stk[kMaxStack + 2];
     float outs[MO ? kGeneralOuts : 1];
     auto process = [&](int t) {
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
         bool hit = false;
         if (t < c1) {
             const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
-            hit = f2bits(*mark) == kSentinelDeep;
+            hit = f2bits(*mark) == kSentinelDeep || (only_marked == 2 && f2bits(*mark) == kSentinelHeavy);
         }
         unsigned long long m = __ballot(hit);
         while (m) {
@@ -433,11 +436,20 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         return (int)launch_general<STORE>(p, 1, stream);
     }
     const bool fast_ok = p.var_len <= 32 && p.out_len <= kMaxOutRegs && !forced;
-    if (!fast_ok) return (int)launch_general<STORE>(p, 0, stream);
-    const bool mo = p.out_len > 1;
-    hipError_t e;
     // EVOGP_SR_ASM: 0 = C++ interpreter only, 3 = threaded code (default)
     static const int asm_depth = env_int("EVOGP_SR_ASM", EVOGP_SR_DEFAULT_ASM);
+    hipError_t e;
+    if (!fast_ok) {
+        // more variables (or outputs) than the register kernels hold: the threaded code keeps its dataset in LDS and does not
+        // mind; what it leaves marked goes to the scratch-stack kernel
+        if (!STORE && !forced && asm_depth == 3) {
+            bool done = false;
+            if ((e = launch_threaded_code(p, stream, &done, &p.mark_sample, &p.mark_chunks)) != hipSuccess) return (int)e;
+            if (done) return (int)launch_general<STORE>(p, 2, stream);
+        }
+        return (int)launch_general<STORE>(p, 0, stream);
+    }
+    const bool mo = p.out_len > 1;
     bool tc_done = false;
     ProfCall prof{};
     bool profiling = false;

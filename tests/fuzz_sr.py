@@ -35,7 +35,7 @@ def main():
         while ((3 if has_if else 2) ** (mlc + 1) - 1) // (2 if has_if else 1) <= L and mlc < 9:
             mlc += 1
         out_len = int(rng.choice([1, 1, 1, 2, 3, 5]))
-        var_len = int(rng.choice([1, 2, 3, 7, 10, 16]))
+        var_len = int(rng.choice([1, 2, 3, 7, 10, 16, 33, 64]))
         D = int(rng.choice([1, 3, 8, 33, 64, 65, 200, 256, 257, 700, 1024, 1500, 6000]))
         pop = int(rng.choice([1, 5, 64, 300, 1000, 2500, 7000]))
         consts = [-1.0, 0.0, 1.0, 0.5, 2.0, 3.0, -0.25, 1e-10, 1e20]

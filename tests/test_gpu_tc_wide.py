@@ -320,10 +320,19 @@ def test_classifier_count_on_the_threaded_code(g, oracle, rng, var_len, out_len,
     got = g.batch_argmax_count(*f, X, labels, out_len)
     h = handler_histogram(g, pop)
     assert h["end_cls"] >= 0.9 * pop, f"only {h['end_cls']} of {pop} programs end in the classifier handler"
-    outs = torch.from_numpy(oracle.batch_evaluate(*f, X, out_len))
-    pred = torch.argmax(torch.clip(torch.softmax(outs, dim=2), 1e-15, 1 - 1e-15), dim=2)
+    outs_np = oracle.batch_evaluate(*f, X, out_len)                       # (pop, D, out); IEEE-exact functions: the device's bits
+    # the handler's rule, exactly: first maximum of the raw outputs; class 0 when an output is NaN or the maximum is infinite
+    with np.errstate(all="ignore"):
+        mx = np.nanmax(np.where(np.isnan(outs_np), -np.inf, outs_np), axis=2)
+    poisoned = np.isnan(outs_np).any(2) | np.isinf(mx)
+    best = np.where(poisoned, 0, np.argmax(np.where(np.isnan(outs_np), -np.inf, outs_np), axis=2))
+    exact = (best == labels[None, :]).sum(1)
+    assert np.array_equal(got, exact), (np.abs(got - exact).max(), np.flatnonzero(got != exact)[:5])
+    # ... which is torch.argmax(clip(softmax(x))) (classification.py:62-75) except where two soft-max probabilities that differ
+    # before rounding come out equal (torch then takes the earlier class): a few rows per thousand at most
+    pred = torch.argmax(torch.clip(torch.softmax(torch.from_numpy(outs_np), dim=2), 1e-15, 1 - 1e-15), dim=2)
     want = (pred == torch.from_numpy(labels.astype(np.int64))[None, :]).sum(1).numpy()
-    assert np.abs(got - want).max() <= 2 and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())
+    assert np.abs(got - want).max() <= max(2, D // 400) and (got != want).mean() < 0.01, (np.abs(got - want).max(), (got != want).mean())
 
 
 def test_chunked_pipeline_on_a_large_population(g, oracle):
