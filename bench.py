@@ -471,6 +471,40 @@ def main():
         except Exception as exc:
             extras["vis_ipynb_config"] = {"error": repr(exc)[:300]}
 
+        # BASELINE configs[3]: the classifier of example/uci_classifier.py at its shape -- pop 200 000 multi-output trees, output_len 10,
+        # max_tree_len 128; 64 features x 1797 rows (the size of sklearn's digits; the example's UCI table needs the network) -- fitness =
+        # fused arg-max count (compiled programs + END_CLS handler), then the default generation step
+        try:
+            from evogp_amd.problem import Classification
+
+            cdesc = GenerateDescriptor(max_tree_len=128, input_len=64, output_len=10, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6,
+                                       const_samples=[-1, 0, 1])
+            cg = torch.Generator().manual_seed(5)
+            cX = (torch.rand(1797, 64, generator=cg) * 16).to(device)
+            cy = torch.randint(0, 10, (1797,), generator=cg).to(torch.float32).to(device)
+            cprob = Classification(cX, cy)
+            cpop = 200_000
+            calgo = GeneticProgramming(Forest.random_generate(cpop, cdesc, keys=torch.tensor([7, 0], dtype=torch.uint32, device=device)),
+                                       DefaultCrossover(), DefaultMutation(0.2, cdesc.update(max_layer_cnt=3)), DefaultSelection(0.3, elite_rate=0.01))
+            for _ in range(2):
+                cprob.evaluate(calgo.forest)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5):
+                cprob.evaluate(calgo.forest)
+            torch.cuda.synchronize(); fit_ms = (time.perf_counter() - t0) / 5 * 1000
+            cms = []
+            for _ in range(6):
+                torch.cuda.synchronize(); g0 = time.perf_counter()
+                calgo.step(cprob.evaluate(calgo.forest))
+                torch.cuda.synchronize(); cms.append((time.perf_counter() - g0) * 1000)
+            extras["configs3"] = {
+                "workload": "BASELINE configs[3] shape: classifier trees, pop 200k, output_len 10, max_tree_len 128, 64 features x 1797 rows (synthetic), "
+                            "accuracy fitness + default operators",
+                "fitness_ms": fit_ms, "tree_evals_per_s": cpop * 1797 / (fit_ms / 1e3), "generation_ms": {"median": float(np.median(cms[1:])), "first": cms[0]}}
+            del calgo, cprob
+        except Exception as exc:
+            extras["configs3"] = {"error": repr(exc)[:300]}
+
     if rank == 0:
         emit(extras)
     if dist is not None:
