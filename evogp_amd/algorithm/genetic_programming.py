@@ -91,7 +91,12 @@ class GeneticProgramming:
         pop, L = f.pop_size, f.max_tree_len
         n_elite, n_surv = self.selection.counts(pop)
         n_new = pop - n_elite
-        order = torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv)].to(torch.int32).contiguous()
+        # elites first, then the other survivors (each group by tree index): ONE launch instead of a sort of the whole vector --
+        # nothing downstream uses the order inside the two sets (csrc/select.hip)
+        if n_elite <= n_surv and fitness.dtype == torch.float32 and os.environ.get("EVOGP_NATIVE_SELECT", "1") != "0":
+            order = torch.ops.evogp_hip.select_survivors(fitness.contiguous(), n_elite, n_surv)
+        else:
+            order = torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv)].to(torch.int32).contiguous()
         rnd = torch.randint(0, 2**31 - 1, (6, n_new), dtype=torch.int32, device=dev)
         below = int(min(max(self.mutation.mutation_rate, 0.0), 1.0) * (2**31 - 1))
         d = self.mutation.descriptor

@@ -285,6 +285,21 @@ Tensor random_words(int64_t seed, int64_t generation, int64_t rows, int64_t n_co
     return out;
 }
 
+// int32[n_keep]: the n_elite best trees, then the other survivors, each group in ascending index (select.hip)
+Tensor select_survivors(const Tensor &fitness, int64_t n_elite, int64_t n_keep) {
+    TORCH_CHECK(fitness.is_cuda() && fitness.is_contiguous() && fitness.scalar_type() == at::kFloat && fitness.dim() == 1,
+                "fitness must be a contiguous float32 CUDA vector");
+    const int64_t n = fitness.size(0);
+    TORCH_CHECK(n > 0 && n_keep > 0 && n_keep <= n && n_elite >= 0 && n_elite <= n_keep, "need 0 <= n_elite <= n_keep <= n, got ", n_elite, ", ", n_keep, ", ", n);
+    const c10::Device dev = fitness.device();
+    c10::DeviceGuard guard(dev);
+    Tensor order = at::empty({n_keep}, at::TensorOptions().dtype(at::kInt).device(dev));
+    Tensor ws = at::zeros({(int64_t)(evogp_hip_select_workspace_bytes() / 4)}, at::TensorOptions().dtype(at::kInt).device(dev));
+    check_rc(evogp_hip_select((unsigned)n, (unsigned)n_elite, (unsigned)n_keep, fitness.data_ptr<float>(), order.data_ptr<int>(), ws.data_ptr(),
+                              current_stream(dev)), "select_survivors");
+    return order;
+}
+
 void check_order(const Tensor &order, int64_t need, const c10::Device &dev) {
     TORCH_CHECK(order.is_cuda() && order.is_contiguous() && order.scalar_type() == at::kInt && order.dim() == 1 && order.size(0) >= need &&
                     order.device() == dev,
@@ -388,6 +403,7 @@ TORCH_LIBRARY(evogp_hip, m) {
     m.def("tree_evaluate_prepared(int pop_size, int gp_len, int var_len, int out_len, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor workspace, bool with_fallback, Tensor variables) -> Tensor results");
     m.def("random_words(int seed, int generation, int rows, int n_cols, int lo, int hi, Device device) -> Tensor");
+    m.def("select_survivors(Tensor fitness, int n_elite, int n_keep) -> Tensor");
     m.def("breed_default(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
           " bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)");
@@ -407,4 +423,5 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("tree_evaluate_prepared", &tree_evaluate_prepared);
     m.impl("breed_default", &breed_default);
     m.impl("breed_default_rows", &breed_default_rows);
+    m.impl("select_survivors", &select_survivors);
 }

@@ -13,9 +13,9 @@ data-parallel axis the workload has for free:
   rank instead of the 64.5 MB of the whole shard.  On the xGMI mesh every rank sends its block to its 7 peers over 7
   direct links, so one large collective per array kind is the right granularity.
 
-Nothing in a rank's step is O(global population) except one streaming pass over the gathered fitness vector: the kept set
-comes from a threshold (``torch.kthvalue`` + elementwise compares, ``select_kept``), only the kept ~30 % are sorted (their
-keys travel with their rows, ``table_order``), and the six random words of an offspring are a counter-based hash of
+Nothing in a rank's step is O(global population) except streaming passes over the gathered fitness vector: the elite and
+survivor SETS come from an exact radix select in one launch (``select_order`` / csrc/select.hip; nothing is sorted), a kept tree's
+row in the gathered table is index arithmetic on the kept mask, and the six random words of an offspring are a counter-based hash of
 (seed, generation, word, GLOBAL offspring index) (``random_words`` / ``evogp_hip_random_words``): a rank computes exactly the
 words of its own rows, and all ranks agree on them whatever the world size.
 
@@ -62,47 +62,40 @@ def _unpack(buf: torch.Tensor, L: int, input_len: int, output_len: int) -> Fores
     return Forest(input_len, output_len, value, ntype, size)
 
 
-def _sort_key(fit: torch.Tensor) -> torch.Tensor:
-    """float32 -> int64 key with the same order (NaN-free input); every real key is > 0, so 0 can mark padding rows"""
-    u = fit.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
-    return torch.where(u >= 0x80000000, 0xFFFFFFFF - u, u + 0x80000000) + 1
+def select_order(fit: torch.Tensor, n_elite: int, n_keep: int) -> torch.Tensor:
+    """int32[n_keep]: the n_elite best trees, then the other survivors, each group in ascending tree index; ties at a threshold go
+    to the lower index, i.e. the two SETS are those of a stable descending sort.  Nothing downstream uses an order inside the sets
+    (elites are copied, parents are drawn uniformly), so no sort of the population is needed: on a GPU this is ONE launch of an
+    exact radix select (csrc/select.hip: 25 us at 100 k values, 40 us at 1 M; torch.sort takes 61 / 219 us, torch.kthvalue 0.39 /
+    3.8 ms); elsewhere the same result from torch ops.  Every rank runs it on the identical gathered vector."""
+    n_elite = min(n_elite, n_keep)
+    if fit.is_cuda and fit.dtype == torch.float32 and os.environ.get("EVOGP_NATIVE_SELECT", "1") != "0":
+        return torch.ops.evogp_hip.select_survivors(fit.contiguous(), n_elite, n_keep)
+    best = torch.sort(fit, descending=True, stable=True).indices[:n_keep]
+    return torch.cat([torch.sort(best[:n_elite]).values, torch.sort(best[n_elite:]).values]).to(torch.int32)
 
 
-def select_kept(fit_all: torch.Tensor, n_keep: int) -> torch.Tensor:
-    """bool[pop]: the best n_keep trees in stable descending order of fitness (ties: lower global index first) WITHOUT
-    sorting the population: the k-th largest value comes from a radix select (torch.kthvalue), the rest is elementwise.
-    Every rank runs this on the identical gathered vector; the work is O(pop) streaming, not an O(pop log pop) sort of
-    keys and indices."""
+def plan_exchange(fit_all: torch.Tensor, n_elite: int, n_keep: int, world: int):
+    """From the gathered fitness of the whole population (rank-major): which trees are kept, how many rows every rank contributes,
+    and where each kept tree lands in the gathered table.  -> (per_rank bool[world][n_local], cap, order int32[n_keep] of TABLE rows,
+    elites first).  ``cap`` -- the largest number of kept trees on any rank, the row count every rank pads its block to -- is the
+    step's one host sync (one integer); a bound that needs none would have to be min(n_local, n_keep), i.e. gather the whole
+    population at world sizes where n_keep > n_local."""
     pop = fit_all.shape[0]
-    if n_keep >= pop:
-        return torch.ones(pop, dtype=torch.bool, device=fit_all.device)
-    thr = -torch.kthvalue(-fit_all, n_keep).values               # the n_keep-th largest fitness
-    above = fit_all > thr
-    ties = fit_all == thr
-    room = n_keep - above.sum()                                   # how many of the tied trees still fit (device scalar)
-    return above | (ties & (torch.cumsum(ties.to(torch.int64), 0) <= room))
-
-
-def plan_exchange(fit_all: torch.Tensor, n_keep: int, world: int):
-    """From the gathered fitness of the whole population (rank-major): which trees are kept and how many rows every rank
-    contributes.  -> (per_rank bool[world][n_local], cap).  ``cap`` — the largest number of kept trees on any rank, the row
-    count every rank pads its block to — is the step's one host sync (eight integers); a bound that needs none would have to
-    be min(n_local, n_keep), i.e. gather the whole population at world sizes where n_keep > n_local."""
-    pop = fit_all.shape[0]
-    per_rank = select_kept(fit_all, n_keep).view(world, pop // world)
+    chosen = select_order(fit_all, n_elite, n_keep).long()
+    kept = torch.zeros(pop, dtype=torch.bool, device=fit_all.device)
+    kept[chosen] = True
+    per_rank = kept.view(world, pop // world)
     cap = int(per_rank.sum(1).max())
-    return per_rank, cap
+    # a rank sends its kept trees in ascending local index (kept_rows): tree g of rank r is row r * cap + (kept trees of r below g)
+    below = torch.cumsum(per_rank.to(torch.int64), dim=1) - 1
+    table_row = (below + torch.arange(world, device=fit_all.device)[:, None] * cap).view(-1)
+    return per_rank, cap, table_row[chosen].to(torch.int32).contiguous()
 
 
 def kept_rows(mine: torch.Tensor, cap: int) -> torch.Tensor:
     """local indices of this rank's kept trees in ascending order, padded with other local trees up to ``cap`` rows"""
     return torch.argsort((~mine).to(torch.int8), stable=True)[:cap]
-
-
-def table_order(table_key: torch.Tensor, n_keep: int) -> torch.Tensor:
-    """ranking of the gathered table (rank-major, within a rank ascending tree index, padding rows key 0): stable descending
-    sort of the kept trees' keys = the order a stable descending sort of the whole population gives them"""
-    return torch.sort(table_key, descending=True, stable=True).indices[:n_keep].to(torch.int32).contiguous()
 
 
 # ---- counter-based random words ------------------------------------------------------------------------------------------
@@ -155,26 +148,20 @@ class ShardedGeneticProgramming:
 
     # -- the exchange step -------------------------------------------------------------------------
     def exchange(self, local_fitness: torch.Tensor):
-        """-> (table Forest, order int32[n_keep] of table rows in descending fitness order, global pop)"""
+        """-> (table Forest, order int32[n_keep] of table rows: the elites, then the other survivors, global pop)"""
         n_elite, n_surv = self.selection.counts(self.pop_size)
         n_keep = max(n_elite, n_surv, 1)
         f = self.forest
         fit = local_fitness.to(torch.float32).contiguous()
         if self.world == 1:
-            order = torch.sort(fit, descending=True, stable=True).indices[:n_keep].to(torch.int32).contiguous()
-            return f, order, self.pop_size
+            return f, select_order(fit, n_elite, n_keep), self.pop_size
         fit_all = torch.empty(self.pop_size, dtype=torch.float32, device=fit.device)
         dist.all_gather_into_tensor(fit_all, fit, group=self.group)
-        per_rank, cap = plan_exchange(fit_all, n_keep, self.world)
-        mine = per_rank[self.rank]
-        rows = kept_rows(mine, cap)
-        # a kept row travels with its sort key (8 bytes in front of the 8 L bytes of the tree); padding rows carry key 0
-        key = torch.where(mine[rows], _sort_key(fit[rows]), torch.zeros(cap, dtype=torch.int64, device=fit.device))
-        send = torch.cat([key.view(torch.uint8).view(cap, 8), _pack(f, rows)], dim=1).contiguous()
+        per_rank, cap, order = plan_exchange(fit_all, n_elite, n_keep, self.world)
+        send = _pack(f, kept_rows(per_rank[self.rank], cap))
         table = torch.empty((self.world * cap, send.shape[1]), dtype=torch.uint8, device=send.device)
         dist.all_gather_into_tensor(table, send, group=self.group)
-        order = table_order(table[:, :8].contiguous().view(torch.int64).view(-1), n_keep)
-        return _unpack(table[:, 8:], f.max_tree_len, f.input_len, f.output_len), order, self.pop_size
+        return _unpack(table, f.max_tree_len, f.input_len, f.output_len), order, self.pop_size
 
     def step(self, local_fitness: torch.Tensor) -> Forest:
         assert local_fitness.shape == (self.n_local,)
@@ -190,7 +177,7 @@ class ShardedGeneticProgramming:
 
     def _order_of(self, full: Forest, fitness: torch.Tensor) -> torch.Tensor:
         n_elite, n_surv = self.selection.counts(full.pop_size)
-        return torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv, 1)].to(torch.int32).contiguous()
+        return select_order(fitness.to(torch.float32), n_elite, max(n_elite, n_surv, 1))
 
     def next_slice_native(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
         """rows [lo, hi) of the next generation from the WHOLE population and its fitness (tests, single-table use)"""

@@ -151,6 +151,15 @@ int evogp_hip_breed_default_table(int pop_size, int table_rows, int gp_len, int 
 int evogp_hip_random_words(long long seed, long long generation, int rows, long long n_cols, long long lo, long long hi,
                            int *out, evogp_stream_t stream);
 
+/* Selection in one launch (no counterpart in the reference, whose DefaultSelection sorts the whole fitness vector,
+ * src/evogp/algorithm/selection/default.py:21-39): order[0 .. n_elite) = the n_elite trees of highest fitness, order[n_elite ..
+ * n_keep) = the next n_keep - n_elite, each group in ascending tree index.  Ties at a threshold go to the lower index, so both
+ * SETS are those of a stable descending sort; NaN is the worst fitness.  n_elite <= n_keep <= n.  `zeroed_workspace`:
+ * evogp_hip_select_workspace_bytes() bytes, all zero (the kernel's grid barrier and histograms live there). */
+size_t evogp_hip_select_workspace_bytes(void);
+int evogp_hip_select(unsigned n, unsigned n_elite, unsigned n_keep, const float *fitness, int *order, void *zeroed_workspace,
+                     evogp_stream_t stream);
+
 /* Non-replicating batch evaluation (replaces the repeat_interleave + tree_evaluate
  * composition of src/evogp/tree/forest.py:143-176): results[t][d][:] = tree_t(variables[d][:]),
  * variables: f32[D][var_len], results: f32[pop][D][out_len]. */

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for sym in declared_symbols():
         assert hasattr(lib, sym), f"libevogp_hip.so does not export {sym}"
-    assert set(_lib.PROTOTYPES) | {"evogp_hip_error_string", "evogp_hip_evaluate_workspace_bytes"} == set(declared_symbols())
+    assert set(_lib.PROTOTYPES) | {"evogp_hip_error_string", "evogp_hip_evaluate_workspace_bytes", "evogp_hip_select_workspace_bytes"} == set(declared_symbols())
     assert lib.evogp_hip_abi_version() == _lib.ABI_VERSION
 
 

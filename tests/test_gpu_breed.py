@@ -108,8 +108,10 @@ def test_genetic_programming_default_step_uses_the_fused_path_and_stays_valid(g)
         best.append(float(fit.max()))
         top = algo.forest[int(torch.argmax(fit))]
         new = algo.step(fit)
-        # the elite (best tree) survives verbatim in row 0; every row is a structurally valid tree
-        assert str(new[0]) == str(top)
+        # the elites survive verbatim in the first rows (by tree index, not by fitness: nothing uses an order among them); every
+        # row is a structurally valid tree
+        n_elite = DefaultSelection(0.3, elite_rate=0.01).counts(pop)[0]
+        assert str(top) in {str(new[i]) for i in range(n_elite)}
         sizes = new.batch_subtree_size[:, 0].to(torch.int64)
         assert int(sizes.min()) >= 1 and int(sizes.max()) <= 64
         ntype = new.batch_node_type.to(torch.int64)
@@ -220,20 +222,17 @@ def test_sharded_native_step_union_equals_single_device(g):
                                b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), f"G = {G}"
     # the exchange of a sharded run gathers only the trees that can be parents or elites: the slices built from that
     # compact table (ranking expressed in table rows) are the same rows again
-    from evogp_amd.parallel import _pack, _sort_key, _unpack, kept_rows, plan_exchange, table_order
+    from evogp_amd.parallel import _pack, _unpack, kept_rows, plan_exchange
 
     for G in (2, 8):
         n_local = pop // G
         sel = DefaultSelection(0.3, elite_rate=0.01)
         n_elite, n_surv = sel.counts(pop)
         n_keep = max(n_elite, n_surv)
-        per_rank, cap = plan_exchange(fitness, n_keep, G)
+        per_rank, cap, order = plan_exchange(fitness, n_elite, n_keep, G)
         assert cap < n_local
         rows = [kept_rows(per_rank[r], cap) for r in range(G)]
         table = _unpack(torch.cat([_pack(full[r * n_local:(r + 1) * n_local], rows[r]) for r in range(G)]), 64, 5, 1)
-        keys = torch.cat([torch.where(per_rank[r][rows[r]], _sort_key(fitness[r * n_local:(r + 1) * n_local][rows[r]]),
-                                      torch.zeros(cap, dtype=torch.int64, device=dev)) for r in range(G)])
-        order = table_order(keys, n_keep)
         parts = []
         for r in range(G):
             sg = ShardedGeneticProgramming(full[:n_local], 0.2, desc.update(max_layer_cnt=3), sel, seed=5)
@@ -246,6 +245,46 @@ def test_sharded_native_step_union_equals_single_device(g):
     sg = ShardedGeneticProgramming(full, 0.2, desc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=5)
     nxt = sg.next_slice_torch(full, fitness, 0, pop)
     assert nxt.pop_size == pop
+
+
+def test_select_survivors_equals_the_sets_of_a_stable_sort(g):
+    """csrc/select.hip (exact radix select + compaction in one cooperative launch) against its definition in torch ops
+    (evogp_amd.parallel.select_order on the CPU): the n_elite best, then the other survivors, each group by ascending index; ties at
+    a threshold to the lower index; NaN worst; every size from one value to a million, heavy ties, infinities."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.parallel import select_order
+
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(11)
+    cases = []
+    for n in (1, 2, 3, 255, 256, 257, 1000, 4097, 65536, 100_000, 333_333, 1_000_003):
+        x = torch.randn(n, generator=gen)
+        cases.append((x, (0, 1, n // 100, n // 3)))
+        q = torch.round(torch.randn(n, generator=gen) * 3)          # few distinct values: long runs of ties at every threshold
+        q[torch.rand(n, generator=gen) < 0.05] = float("nan")
+        q[torch.rand(n, generator=gen) < 0.05] = float("-inf")
+        q[torch.rand(n, generator=gen) < 0.01] = float("inf")
+        cases.append((q, (0, 1, n // 100, n // 3)))
+        cases.append((torch.zeros(n), (0, n // 2)))               # all equal
+        cases.append((-torch.arange(n, dtype=torch.float32) * 1e-3 - 1e-40, (1,)))   # descending incl. denormal steps near zero
+    for x, elites in cases:
+        n = x.shape[0]
+        xd = x.to(dev)
+        # the ranking the kernel implements: value descending, NaN behind everything (also behind -inf), equal values by index
+        nan = torch.isnan(x)
+        by_value = torch.sort(torch.where(nan, torch.full_like(x, float("-inf")), x), descending=True, stable=True).indices
+        rank = by_value[torch.sort(nan[by_value].to(torch.int8), stable=True).indices]
+        if not nan.any():
+            assert torch.equal(select_order(x, 3 if n > 3 else 0, n).long().sort().values, torch.arange(n))   # (the CPU definition: a permutation)
+        for n_elite in elites:
+            for n_keep in sorted({max(n_elite, 1), max(n_elite, n * 3 // 10, 1), n}):
+                got = torch.ops.evogp_hip.select_survivors(xd, n_elite, n_keep).cpu()
+                want = torch.cat([torch.sort(rank[:n_elite]).values, torch.sort(rank[n_elite:n_keep]).values]).to(torch.int32)
+                assert torch.equal(got, want), (n, n_elite, n_keep, int((got != want).sum()))
+                if not nan.any():
+                    assert torch.equal(select_order(x, n_elite, n_keep), want)   # the torch definition used off the GPU agrees
 
 
 def test_native_random_words_equal_the_python_definition(g):

@@ -84,7 +84,7 @@ def test_pack_unpack_roundtrip():
 
 
 def _roundtrip(Forest, GenerateDescriptor, set_default_device, _pack, _unpack):
-    from evogp_amd.parallel import _sort_key, kept_rows, plan_exchange, table_order
+    from evogp_amd.parallel import kept_rows, plan_exchange, select_order
 
     set_default_device("cpu")
     desc = GenerateDescriptor(max_tree_len=L, input_len=3, output_len=2, using_funcs=["+", "*", "sin"], max_layer_cnt=4,
@@ -98,16 +98,17 @@ def _roundtrip(Forest, GenerateDescriptor, set_default_device, _pack, _unpack):
     torch.manual_seed(4)
     fit = torch.randn(60)
     fit[7] = fit[31]  # a tie: the stable sort prefers the lower index on every rank
-    world, n_keep = 3, 17
-    per_rank, cap = plan_exchange(fit, n_keep, world)       # selection by the k-th value, no sort of the population
+    world, n_elite, n_keep = 3, 4, 17
+    per_rank, cap, order = plan_exchange(fit, n_elite, n_keep, world)   # the sets by selection, table rows by index arithmetic
     assert per_rank.shape == (3, 20) and int(per_rank.sum()) == n_keep and cap == int(per_rank.sum(1).max())
     rows = [kept_rows(per_rank[r], cap) for r in range(world)]
     sends = [_pack(f[r * 20:(r + 1) * 20], rows[r]) for r in range(world)]
-    keys = torch.cat([torch.where(per_rank[r][rows[r]], _sort_key(fit[r * 20:(r + 1) * 20][rows[r]]), torch.zeros(cap, dtype=torch.int64))
-                      for r in range(world)])
-    order = table_order(keys, n_keep)                       # the ranking comes from the keys that travel with the rows
     table = _unpack(torch.cat(sends), L, 3, 2)
     assert table.pop_size == world * cap
-    best = torch.sort(fit, descending=True, stable=True).indices[:n_keep]
+    # order names the elites first, then the other survivors, each group by tree index: the sets of a stable descending sort
+    ranked = torch.sort(fit, descending=True, stable=True).indices
+    best = torch.cat([torch.sort(ranked[:n_elite]).values, torch.sort(ranked[n_elite:n_keep]).values])
+    assert torch.equal(select_order(fit, n_elite, n_keep).long(), best)
+    assert 7 in best.tolist() or 31 not in best.tolist()       # of two equal values the lower index is taken first
     assert torch.equal(table.batch_node_value[order.long()].view(torch.int32), f.batch_node_value[best].view(torch.int32))
     assert torch.equal(table.batch_subtree_size[order.long()], f.batch_subtree_size[best])
