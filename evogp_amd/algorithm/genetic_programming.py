@@ -92,7 +92,8 @@ class GeneticProgramming:
         n_elite, n_surv = self.selection.counts(pop)
         n_new = pop - n_elite
         # elites first, then the other survivors (each group by tree index): ONE launch instead of a sort of the whole vector --
-        # nothing downstream uses the order inside the two sets (csrc/select.hip)
+        # nothing downstream uses the order inside the two sets (csrc/select.hip).  (Drawing the words and generating the donors
+        # on a second stream meanwhile was measured twice: the stream hand-over costs more than the 25 us it hides.)
         if n_elite <= n_surv and fitness.dtype == torch.float32 and os.environ.get("EVOGP_NATIVE_SELECT", "1") != "0":
             order = torch.ops.evogp_hip.select_survivors(fitness.contiguous(), n_elite, n_surv)
         else:
