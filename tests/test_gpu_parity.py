@@ -202,6 +202,25 @@ def test_malformed_trees_yield_nan(g):
     assert np.isnan(ev[:3]).all() and ev[3, 0] == 3.0
 
 
+def test_malformed_trees_in_a_classifier_count_as_class_zero(g):
+    """a malformed tree has NaN outputs in every row; the arg-max of a NaN row is class 0 (torch.argmax(clip(softmax(NaN)))), so
+    its count is the number of rows labelled 0 -- on the compiled-program path and on the tile-group kernel alike"""
+    L = 16
+    v = np.zeros((4, L), np.float32); t = np.zeros((4, L), np.int16); s = np.zeros((4, L), np.int16)
+    t[0, :2] = [3, 0]; s[0, :2] = [2, 1]; v[0, 0] = 1          # ADD with one operand
+    t[1, :2] = [0, 0]; s[1, 0] = 2                             # two leaves
+    s[2, 0] = 0                                                # empty tree
+    # valid, two outputs: OUT0 += x0 + 2 (root: ADD flagged OUT, output 0)
+    t[3, :3] = [3 | 0x80, 0, 1]; s[3, :3] = [3, 1, 1]
+    v[3, 0] = np.array([1 | (0 << 16)], np.uint32).view(np.float32)[0]; v[3, 1:3] = [0, 2]
+    X = np.array([[1.0], [-5.0], [0.5], [-2.5], [3.0]], np.float32)
+    labels = np.array([0, 1, 0, 0, 1], np.int32)
+    cnt = g.batch_argmax_count(v, t, s, X, labels, 2)
+    # tree 3: outputs (x0 + 2, 0): class 0 where x0 + 2 >= 0 (ties go to the first class), class 1 elsewhere
+    want3 = int((((X[:, 0] + 2) >= 0).astype(np.int32) == (labels == 0)).sum())
+    assert cnt[:3].tolist() == [3, 3, 3] and int(cnt[3]) == want3, (cnt, want3)
+
+
 # ---- SR fitness ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("D", [1, 8, 63, 64, 65, 256, 1000, 1024, 1025, 2500, 5000])
 def test_sr_fitness_ragged_datapoint_counts(g, oracle, rng, D):
