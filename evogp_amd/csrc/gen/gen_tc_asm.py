@@ -16,7 +16,7 @@ DESIGN.md section 3.1 has the numbers):
     the 64-SGPR window (four s_load_dwordx16); dispatch = s_movrels_b32 (next word) + s_pack_lh_b32_b16 (handler address) +
     s_setpc_b64 — no v_readlane, no decode, no compare chain.  Longer programs chain blocks: word 31 is then NEXT (refill
     from the tree's record in the next array of records);
-  * K = 8 rows per lane: one tree instruction = 8 VALU (a division ~70, sin / cos ~200);
+  * K rows per lane (8; 4 and 1 for small datasets): one tree instruction = K VALU (a division ~8 K, sin / cos ~25 K);
   * handlers: + - * / in the eight operand forms {S stack, V variable, C constant}^2 minus CC (folded by the compiler);
     unary neg abs sin cos tan sqrt loose-sqrt exp log loose-log in the forms S (in place) and V (push); the
     transcendental ones are the device math library's instruction sequences (taken from hipcc's output for sinf, ...),
@@ -27,7 +27,10 @@ DESIGN.md section 3.1 has the numbers):
     library's transcribed sequences (gen/ocml_transcribe.py -> ocml_bodies.py, 120-190 instructions each) — pow, loose pow,
     sinh, cosh; tanh inline; IF with its three operands on the stack;
   * multi-output programs (forward.cu:237-243): the first out_len stack entries are the output accumulators; mo_begin clears
-    them, acc_s adds the top of the stack to one of them, end_mo folds the errors of all outputs;
+    them, acc_s adds the top of the stack to one of them, end_mo folds the errors of all outputs; end_cls instead takes the
+    arg-max over them per row and counts the rows whose arg-max is their class label (the Classification problem's fitness);
+  * divisions of S / S, S / c, c / S have in-place handlers (operands read where they are -- every operand position M0-relative --,
+    temporaries in the registers above the stack top), used where the compiler finds that entry free;
   * the division comes in three selectable row sequences (ieee / short / fast, evogp_hip_set_sr_division); the
     reference's "b == 0 -> NaN" is tested once per K x 64 block (min |b|), not per row;
   * the dataset lives in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per four rows.
