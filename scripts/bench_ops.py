@@ -7,10 +7,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import gpu_capi as g
-from helpers import depth2leaf, roulette_uniform
-from oracle.pyoracle import Oracle
 
-o = Oracle("port")
+
+def depth2leaf(max_layer_cnt, leaf_prob=0.2):
+    """f32[10]: leaf probability per depth (descriptor.py:33-38)"""
+    return np.array([leaf_prob] * (max_layer_cnt - 1) + [1.0] * (10 - (max_layer_cnt - 1)), np.float32)
+
+
+def roulette_uniform(funcs):
+    """f32[29]: cumulative weights of the functions in use, equal shares (descriptor.py:106-111)"""
+    w = np.zeros(29, np.float64)
+    w[list(funcs)] = 1.0 / len(funcs)
+    return np.cumsum(w.astype(np.float32), dtype=np.float32)
+
 L_ = g.L
 S = g._stream
 

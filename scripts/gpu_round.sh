@@ -13,7 +13,7 @@ echo "== device"; rocminfo | grep -E "Marketing Name|gfx9|Compute Unit" | head -
 python -c "import torch;print('torch', torch.__version__, 'gpus', torch.cuda.device_count())"
 echo "== smoke"; timeout 900 python __graft_entry__.py smoke; echo "smoke rc=$?"
 } > $OUT/${TAG}_00_smoke.log 2>&1
-for K in 8 4; do timeout 240 python scripts/tc_smoke.py $K > $OUT/${TAG}_01_tc_smoke_$K.log 2>&1; echo "tc_smoke $K rc=$?" >> $OUT/${TAG}_01_tc_smoke_$K.log; done
+for K in 8 4; do timeout 240 python tests/tools/tc_smoke.py $K > $OUT/${TAG}_01_tc_smoke_$K.log 2>&1; echo "tc_smoke $K rc=$?" >> $OUT/${TAG}_01_tc_smoke_$K.log; done
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_02_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_02_pytest_gpu.log
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_03_bench.json 2> $OUT/${TAG}_03_bench.err; echo "bench rc=$?" >> $OUT/${TAG}_03_bench.err
 { for A in "EVOGP_SR_ASM=3" "EVOGP_SR_ASM=0" "EVOGP_NATIVE_STEP=0"; do echo "== $A"; env $A timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/${TAG}_04_ab.log 2>&1
@@ -23,7 +23,7 @@ timeout 300 python scripts/bench_ops.py > $OUT/${TAG}_09_ops.md 2>&1
 timeout 300 python scripts/div_modes.py > $OUT/${TAG}_10_div_modes.log 2>&1
 { timeout 100 scripts/ubench/div_faithful; timeout 100 scripts/ubench/valu_rates; } > $OUT/${TAG}_11_ubench.log 2>&1
 timeout 200 python scripts/tc_cycles.py > $OUT/${TAG}_05_cycles.json 2>/dev/null
-timeout 300 python scripts/tc_mix.py > $OUT/${TAG}_06_mix.log 2>/dev/null
+timeout 300 python tests/tools/tc_mix.py > $OUT/${TAG}_06_mix.log 2>/dev/null
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o tr -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_07_rocprof.log 2>&1
 python $R/scripts/rocpd_summary.py $(find $OUT/prof_$TAG -name "*.db" | head -1) > $OUT/${TAG}_07_kernel_stats.md 2>&1

@@ -5,7 +5,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-timeout 240 python scripts/tc_smoke.py 8 > $OUT/20_tc_smoke_8.log 2>&1; echo "tc_smoke 8 rc=$?" >> $OUT/20_tc_smoke_8.log
+timeout 240 python tests/tools/tc_smoke.py 8 > $OUT/20_tc_smoke_8.log 2>&1; echo "tc_smoke 8 rc=$?" >> $OUT/20_tc_smoke_8.log
 if ! grep -q TC_SMOKE_OK $OUT/20_tc_smoke_8.log; then echo "TC K8 FAILED"; tail -5 $OUT/20_tc_smoke_8.log; exit 0; fi
 { for cfg in "$@"; do echo "== $cfg"; env $(echo $cfg | tr ',' ' ') timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline; done; } > $OUT/21_sweep.log 2>&1
 timeout 200 python scripts/tc_cycles.py > $OUT/22_cycles.log 2>&1; tail -1 $OUT/22_cycles.log

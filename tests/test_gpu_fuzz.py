@@ -1,7 +1,7 @@
 """Randomised cross-check (fixed seeds) of tree_SR_fitness against the per-datapoint outputs of batch_evaluate: random
 subsets of the functions the threaded code handles, dataset sizes on both sides of the K = 4 / K = 8 switch and of the
 tile boundaries, variable counts, constants, tree lengths.  Both sides run the device math library, so the only
-difference allowed is the summation order (scripts/fuzz_tc.py is the open-ended version)."""
+difference allowed is the summation order (tests/tools/fuzz_tc.py is the open-ended version)."""
 import numpy as np
 import pytest
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised sweep of evogp_hip_sr_fitness against the CPU oracle (test infrastructure, run by hand on a GPU box; not collected
-by pytest):   python tests/fuzz_sr.py [iterations] [seed]
+by pytest):   python tests/tools/fuzz_sr.py [iterations] [seed]
 
 Every iteration draws a shape -- population, row length, inputs, outputs, datapoints (so all three interpreter builds, the
 pieces path and ragged tiles come up), an IEEE-exact function subset, constants with special values -- generates the forest
@@ -11,8 +11,8 @@ import sys
 
 import numpy as np
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(TESTS)); sys.path.insert(0, TESTS)
 from helpers import assert_close_classes, depth2leaf, roulette_uniform  # noqa: E402
 from oracle.pyoracle import Oracle  # noqa: E402
 import gpu_capi as g  # noqa: E402

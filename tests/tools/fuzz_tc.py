@@ -2,7 +2,7 @@
 """Randomised cross-check of the threaded-code fitness path against the per-datapoint outputs of batch_evaluate (the C++
 interpreter with the device math library): random function subsets, dataset sizes, variable counts, constants."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import gpu_capi as g

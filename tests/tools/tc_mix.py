@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch time of the SR-fitness path for forests with different operator mixes (what bounds the interpreter?)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import gpu_capi as g
