@@ -14,7 +14,7 @@ from evogp_amd.tree import GenerateDescriptor
 
 dev = torch.device("cuda", 0)
 gens = int(os.environ.get("GENS", "40"))
-forest, Xd, yd, X, y = bench.c2_inputs(0, 100_000, dev)
+forest, Xd, yd, X, y = bench.sr_inputs(0, 100_000, dev)
 mdesc = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=3, const_samples=[-1, 0, 1])
 algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
