@@ -42,6 +42,15 @@ def test_error_strings_and_argument_errors_without_gpu():
     assert rc == -2
     rc = _lib.lib.evogp_hip_crossover(4, 4, 0, None, None, None, None, None, None, None, None, None, None, None)
     assert rc == -1
+    # the entry points without a counterpart in the reference validate the same way
+    assert _lib.lib.evogp_hip_select(0, 0, 1, None, None, None, None) == -1          # empty vector
+    assert _lib.lib.evogp_hip_select(10, 5, 4, None, None, None, None) == -1         # more elites than kept trees
+    assert _lib.lib.evogp_hip_select(10, 1, 11, None, None, None, None) == -1        # more kept trees than trees
+    assert _lib.lib.evogp_hip_select(10, 1, 3, None, None, None, None) == -2         # null pointers
+    assert _lib.lib.evogp_hip_select_workspace_bytes() > 0
+    assert _lib.lib.evogp_hip_batch_argmax_count(4, 8, 32, 3, 1, None, None, None, None, None, None, None) == -1   # one output: no arg-max
+    assert _lib.lib.evogp_hip_batch_argmax_count(4, 8, 32, 3, 2, None, None, None, None, None, None, None) == -2
+    assert _lib.lib.evogp_hip_evaluate_prepare(4, 32, 3, 1, None, None, None, None, 0, None) == -1               # prepared lists are for multi-output forests
 
 
 def test_ops_are_registered_with_reference_schemas():
