@@ -11,7 +11,8 @@ sys.argv = [sys.argv[0]]
 import bench
 
 dev = torch.device("cuda", 0)
-forest, Xd, yd, X, y = bench.c2_inputs(0, 100_000, dev)
+POP = int(os.environ.get("POP", "100000"))
+forest, Xd, yd, X, y = bench.sr_inputs(0, POP, dev)
 stats = torch.zeros(8, dtype=torch.int64, device=dev)
 for _ in range(3):
     forest.SR_fitness(Xd, yd)
