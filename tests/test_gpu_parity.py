@@ -374,6 +374,23 @@ def test_full_size_properties(g, oracle):
     assert_close_classes(full[pick], ref.astype(np.float32), 1e-4, what="fused vs batch_evaluate")
 
 
+def test_north_star_population_against_the_oracle_and_its_eight_shards(g, oracle):
+    """BASELINE north_star in full: 1 M trees x 1024 datapoints (the forest and dataset bench.py times).
+    (1) every fitness word against the oracle at 1e-5 with identical NaN / inf classes;
+    (2) the population cut into the 8 contiguous shards `bench.py --gpus 8` gives its ranks returns the same bits:
+        the interpreter's work distribution (static share, per-XCD dynamic batches, batch sizes that depend on the
+        population size) must not show in the results."""
+    rou, d2l = roulette_uniform(ARITH), depth2leaf(6)
+    pop = 1_000_000
+    forest = g.generate(pop, 64, 10, 1, 0.5, 0.5, [42, 0], d2l, rou, CS3)
+    X, y = c2_dataset()
+    full = g.sr_fitness(*forest, X, y)
+    assert not (full == 12345.0).any()
+    shards = np.concatenate([g.sr_fitness(*(a[r * pop // 8:(r + 1) * pop // 8] for a in forest), X, y) for r in range(8)])
+    assert np.array_equal(bits(full), bits(shards))
+    assert_close_classes(full, oracle.sr_fitness(*forest, X, y), RTOL_ARITH, what="north star, 1 M trees")
+
+
 @pytest.mark.parametrize("var_len,out_len,D,L,pop", [(64, 10, 1797, 128, 600), (40, 1, 300, 64, 800), (8, 3, 2500, 64, 700),
                                                      (5, 1, 1100, 64, 900), (100, 16, 130, 32, 300)])
 def test_batch_evaluate_wide_inputs_and_long_datasets(g, oracle, rng, var_len, out_len, D, L, pop):
