@@ -54,6 +54,26 @@ struct SelectParams {
     int n, n_elite, n_keep;
 };
 
+// Inclusive scan over the workgroup's 1024 threads: the DPP scan inside each wave, the 16 wave totals through LDS -- two
+// workgroup barriers where a Hillis-Steele scan in LDS takes twenty (the kernel was bound by its ~250 barriers, not by the data).
+// `tot_s`: 16 words.  Every thread of the workgroup must call it.
+__device__ inline unsigned block_scan_incl(unsigned v, unsigned *tot_s, unsigned *total) {
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+    const unsigned incl = (unsigned)wave_scan_incl((int)v);
+    if (lane == 63) tot_s[w] = incl;
+    __syncthreads();
+    unsigned before = 0u, all = 0u;
+#pragma unroll
+    for (int q = 0; q < kSelThreads / 64; ++q) {
+        const unsigned tq = tot_s[q];
+        all += tq;
+        before += q < w ? tq : 0u;
+    }
+    __syncthreads();
+    *total = all;
+    return incl + before;
+}
+
 // bin of `hist` (bins counted from the TOP) in which the rank-th largest element falls, and the rank inside that bin
 __device__ inline void find_bin(const unsigned *hist, int bins, unsigned rank, unsigned *scan_s, int *bin_out, unsigned *rank_out) {
     // every thread sums a contiguous run of bins from the top
@@ -66,17 +86,10 @@ __device__ inline void find_bin(const unsigned *hist, int bins, unsigned rank, u
     unsigned mine = 0;
     for (int j = 0; j < per; ++j) mine += hv[j];
     // inclusive scan of the partial sums (top bins first); the thread whose run contains the rank walks its bins
-    scan_s[threadIdx.x] = mine;
-    __syncthreads();
-    for (int s = 1; s < kSelThreads; s <<= 1) {
-        const unsigned add = (int)threadIdx.x >= s ? scan_s[threadIdx.x - s] : 0u;
-        __syncthreads();
-        scan_s[threadIdx.x] += add;
-        __syncthreads();
-    }
+    unsigned all;
+    const unsigned incl = block_scan_incl(mine, scan_s, &all);
     __shared__ int s_bin;
     __shared__ unsigned s_rank;
-    const unsigned incl = scan_s[threadIdx.x];
     unsigned before = incl - mine;
     if (before < rank && rank <= incl) {   // exactly one thread (ranks beyond the total: none, the caller never asks)
         int bb = top;
@@ -96,8 +109,7 @@ __device__ inline void find_bin(const unsigned *hist, int bins, unsigned rank, u
 
 __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
     __shared__ unsigned hist_s[2 * kSelBins];
-    __shared__ unsigned scan_s[kSelThreads];
-    __shared__ unsigned long long scan64_s[kSelThreads];
+    __shared__ unsigned scan_s[4 * (kSelThreads / 64)];   // wave totals of the workgroup scans (four at a time in the compaction)
     unsigned *bar = p.ws;
     unsigned *g0 = p.ws + kSelHist, *g1e = g0 + kSelBins, *g1k = g1e + kSelBins, *g2e = g1k + kSelBins, *g2k = g2e + kSelBins;
     unsigned *counts = p.ws + kSelCounts;
@@ -162,23 +174,34 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
         const uint32_t k = select_key(p.fitness[i]);
         c[0] += ke && k > te; c[1] += ke && k == te; c[2] += k > tk; c[3] += k == tk;
     }
-    for (int j = 0; j < 4; ++j) {
-        scan_s[tid] = c[j];
+    {
+        const int lane = tid & 63, w = tid >> 6;
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ws = (unsigned)__builtin_amdgcn_readlane(wave_scan_incl((int)c[j]), 63);
+            if (lane == 0) scan_s[j * (kSelThreads / 64) + w] = ws;
+        }
         __syncthreads();
-        for (int s = kSelThreads / 2; s > 0; s >>= 1) { if (tid < s) scan_s[tid] += scan_s[tid + s]; __syncthreads(); }
-        if (tid == 0) counts[4 * b + j] = scan_s[0];
+        if (tid < 4) {
+            unsigned v = 0;
+            for (int q = 0; q < kSelThreads / 64; ++q) v += scan_s[tid * (kSelThreads / 64) + q];
+            counts[4 * b + tid] = v;
+        }
         __syncthreads();
     }
     grid_barrier(bar, 4u * (unsigned)nb);
     // what the workgroups in front of this one hold
     unsigned pre[4] = {0u, 0u, 0u, 0u};
-    for (int j = 0; j < 4; ++j) {
-        unsigned v = 0;
-        for (int q = tid; q < b; q += kSelThreads) v += ld(counts + 4 * q + j);
-        scan_s[tid] = v;
+    {
+        static_assert(kSelMaxBlocks <= 64, "one wave sums the counts of the workgroups in front");
+        if (tid < 64) {
+            for (int j = 0; j < 4; ++j) {
+                const unsigned v = tid < b ? ld(counts + 4 * tid + j) : 0u;
+                const unsigned ws = (unsigned)__builtin_amdgcn_readlane(wave_scan_incl((int)v), 63);
+                if (tid == 0) scan_s[j] = ws;
+            }
+        }
         __syncthreads();
-        for (int s = kSelThreads / 2; s > 0; s >>= 1) { if (tid < s) scan_s[tid] += scan_s[tid + s]; __syncthreads(); }
-        pre[j] = scan_s[0];
+        for (int j = 0; j < 4; ++j) pre[j] = scan_s[j];
         __syncthreads();
     }
     // walk the slice one workgroup-width at a time; ranks inside a step by a scan over the workgroup
@@ -188,20 +211,12 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
         const uint32_t k = i < hi ? select_key(p.fitness[i]) : 0u;
         const bool in = i < hi;
         const unsigned f[4] = {(unsigned)(in && ke && k > te), (unsigned)(in && ke && k == te), (unsigned)(in && k > tk), (unsigned)(in && k == tk)};
-        // one exclusive scan over the workgroup for all four flags: 16-bit fields of a 64-bit word (a field counts to 1024 at most)
-        const unsigned long long mine = (unsigned long long)f[0] | ((unsigned long long)f[1] << 16) | ((unsigned long long)f[2] << 32) | ((unsigned long long)f[3] << 48);
-        scan64_s[tid] = mine;
-        __syncthreads();
-        for (int s = 1; s < kSelThreads; s <<= 1) {
-            const unsigned long long add = tid >= s ? scan64_s[tid - s] : 0ull;
-            __syncthreads();
-            scan64_s[tid] += add;
-            __syncthreads();
-        }
-        const unsigned long long incl = scan64_s[tid], all = scan64_s[kSelThreads - 1];
-        __syncthreads();
-        unsigned ex[4], tot[4];
-        for (int j = 0; j < 4; ++j) { ex[j] = (unsigned)((incl >> (16 * j)) & 0xFFFFull) - f[j]; tot[j] = (unsigned)((all >> (16 * j)) & 0xFFFFull); }
+        // exclusive scans over the workgroup for all four flags: two 16-bit fields per word (a field counts to 1024 at most)
+        unsigned all_lo, all_hi;
+        const unsigned incl_lo = block_scan_incl(f[0] | (f[1] << 16), scan_s, &all_lo);
+        const unsigned incl_hi = block_scan_incl(f[2] | (f[3] << 16), scan_s, &all_hi);
+        const unsigned ex[4] = {(incl_lo & 0xFFFFu) - f[0], (incl_lo >> 16) - f[1], (incl_hi & 0xFFFFu) - f[2], (incl_hi >> 16) - f[3]};
+        const unsigned tot[4] = {all_lo & 0xFFFFu, all_lo >> 16, all_hi & 0xFFFFu, all_hi >> 16};
         if (in) {
             const unsigned above_e = run[0] + ex[0], tie_e = run[1] + ex[1], above_k = run[2] + ex[2], tie_k = run[3] + ex[3];
             const bool elite = ke && (k > te || (k == te && tie_e < re));
