@@ -142,19 +142,24 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
 //   * the constant table, the leaf probabilities and the pending/open frames live in LDS; the 29-entry roulette table is
 //     reduced once per wave to its non-dominated thresholds (entry i can only be the "largest i with r >= roulette[i]"
 //     if every later entry is strictly larger) — with an ordinary cumulative table that is one entry per function in use.
+//   * masked launches (the mutation donors of a generation: one row in five is generated) first GATHER the rows to generate:
+//     a workgroup looks at 64 * G consecutive rows (G = 0.8 / the expected share of live rows) and works through the list of
+//     live ones 64 at a time, so the serial loop runs with ~80 % of its lanes live instead of 20 % (1 M rows: 152 -> 82 us, DESIGN
+//     section 3.3).  Which lane generates a tree does not matter: the draw order belongs to the tree (its index seeds the stream).
 constexpr int kGenChunk = 16;
+constexpr int kGenMaxGather = 16;     // G: at most 1024 rows per workgroup
 constexpr int kGenPitch = 68;         // == 4 (mod 64): the 16x4 flush pattern and the per-lane pattern are both conflict-free
 constexpr int kGenConstLds = 256;
 constexpr int kGenThr = 8;
 constexpr int kStagedMaxLen = 256;
 
-static size_t staged_lds_bytes(unsigned gp_len) {
+static size_t staged_lds_bytes(unsigned gp_len, unsigned gather) {
     return (size_t)kGenChunk * kGenPitch * 4 + (size_t)kGenChunk * kGenPitch * 2 + (size_t)gp_len * kGenPitch * 2 +
-           2 * (size_t)kLevels * kWave * 2 + kGenConstLds * 4 + 64 * 4;
+           2 * (size_t)kLevels * kWave * 2 + kGenConstLds * 4 + 64 * 4 + (size_t)gather * kWave * 4;
 }
 
 template <bool MO>
-__global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p) {
+__global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, unsigned gather) {
     extern __shared__ uint32_t gen_lds[];
     float *ring_v = reinterpret_cast<float *>(gen_lds);                                // [kGenChunk][kGenPitch]
     uint16_t *ring_t = reinterpret_cast<uint16_t *>(ring_v + kGenChunk * kGenPitch);   // [kGenChunk][kGenPitch]
@@ -163,13 +168,28 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p) {
     uint16_t *open_s = frame_s + kLevels * kWave;                                      // [kLevels][64]
     float *const_s = reinterpret_cast<float *>(open_s + kLevels * kWave);              // [kGenConstLds]
     float *misc_s = const_s + kGenConstLds;                                            // leaf probs [11], roulette [29]
+    unsigned *rows_s = reinterpret_cast<unsigned *>(misc_s + 64);                      // [64 * gather]: the rows to generate
 
     const int lane = threadIdx.x;
-    const unsigned wave_first = blockIdx.x * kWave;
-    const unsigned n = wave_first + lane;
-    const bool active = n < p.pop && (p.active_word == nullptr || (unsigned)p.active_word[n] < p.active_below);
-    const unsigned long long amask = __ballot(active);
-    if (amask == 0ull) return;  // nothing to generate in these 64 rows: they stay untouched
+    // ---- the rows of this workgroup's 64 * gather that are to be generated, in index order ----
+    unsigned n_rows = 0;
+    unsigned word[kGenMaxGather];   // all loads first: one memory latency, not one per 64 rows
+#pragma unroll
+    for (unsigned g = 0; g < (unsigned)kGenMaxGather; ++g) {
+        const unsigned idx = (blockIdx.x * gather + g) * kWave + lane;
+        word[g] = 0u;
+        if (g < gather && idx < p.pop && p.active_word != nullptr) word[g] = (unsigned)p.active_word[idx];
+    }
+#pragma unroll
+    for (unsigned g = 0; g < (unsigned)kGenMaxGather; ++g) {
+        if (g >= gather) break;
+        const unsigned idx = (blockIdx.x * gather + g) * kWave + lane;
+        const bool a = idx < p.pop && (p.active_word == nullptr || word[g] < p.active_below);
+        const unsigned long long m = __ballot(a);
+        if (a) rows_s[n_rows + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = idx;
+        n_rows += (unsigned)__popcll(m);
+    }
+    if (n_rows == 0u) return;  // nothing to generate in these rows: they stay untouched
 
     // ---- tables ----
     if (lane < kMaxFullDepth) misc_s[lane] = p.leaf_probs[lane];
@@ -203,6 +223,10 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p) {
         }
     }
 
+    for (unsigned b0 = 0; b0 < n_rows; b0 += kWave) {   // 64 rows of the list at a time
+    const bool active = b0 + lane < n_rows;
+    const unsigned n = active ? rows_s[b0 + lane] : 0u;
+    const unsigned long long amask = __ballot(active);
     auto flush_chunk = [&](unsigned chunk, unsigned filled) {
         // lanes: 16 columns x 4 rows per instruction
         const unsigned j = lane & 15, rs = lane >> 4;
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p) {
                 t = ring_t[j * kGenPitch + row];
             }
             if (in_row && ((amask >> row) & 1ull)) {
-                const size_t at = (size_t)(wave_first + row) * p.gp_len + node;
+                const size_t at = (size_t)rows_s[b0 + row] * p.gp_len + node;
                 p.value[at] = v;
                 p.type[at] = (int16_t)t;
             }
@@ -318,9 +342,12 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p) {
                 const unsigned len = (unsigned)__shfl((int)cnt, (int)row, 64);
                 uint16_t sz = 0;
                 if (node < len && node < p.gp_len) sz = size_s[node * kGenPitch + row];
-                if (node < p.gp_len && ((amask >> row) & 1ull)) p.size[(size_t)(wave_first + row) * p.gp_len + node] = (int16_t)sz;
+                if (node < p.gp_len && ((amask >> row) & 1ull)) p.size[(size_t)rows_s[b0 + row] * p.gp_len + node] = (int16_t)sz;
             }
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the rings and frames are reused by the next 64 rows
+    __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -360,10 +387,25 @@ extern "C" int evogp_hip_generate_masked(unsigned pop_size, unsigned gp_len, uns
     hipStream_t stream = (hipStream_t)stream_;
     static const bool staged_ok = [] { const char *e = getenv("EVOGP_GEN_STAGED"); return !(e && e[0] == '0'); }();
     if (staged_ok && gp_len <= (unsigned)kStagedMaxLen) {
-        const size_t lds = staged_lds_bytes(gp_len);
-        const unsigned wgs = (pop_size + kWave - 1) / kWave;
-        if (out_len > 1) hipLaunchKernelGGL(generate_staged_kernel<true>, dim3(wgs), dim3(kWave), lds, stream, p);
-        else hipLaunchKernelGGL(generate_staged_kernel<false>, dim3(wgs), dim3(kWave), lds, stream, p);
+        // masked launches gather their live rows: 64 * G rows per workgroup hold ~51 live ones on average (the spread of a
+        // binomial keeps all but ~2 % of the workgroups at one pass of the serial loop); EVOGP_GEN_GATHER=1 switches it off
+        static const int env_gather = [] { const char *e = getenv("EVOGP_GEN_GATHER"); return e ? atoi(e) : 0; }();
+        unsigned gather = 1;
+        if (active_word) {
+            const double share = (double)active_below / 2147483648.0;
+            gather = share > 0.0 ? (unsigned)(0.8 / share) : (unsigned)kGenMaxGather;
+            // ... but only as far as the gathered grid still fills the chip: a launch whose workgroups are all resident at once
+            // (pop 100 k: 1563 of them) lasts as long as one workgroup, and a gathered workgroup lasts longer (22.7 -> 37.5 us)
+            const unsigned resident = (unsigned)device_info().num_cus * 8u;
+            const unsigned rounds = ((pop_size + kWave - 1) / kWave) / resident;
+            if (gather > rounds) gather = rounds;
+            if (env_gather > 0) gather = (unsigned)env_gather;
+            gather = gather < 1u ? 1u : (gather > (unsigned)kGenMaxGather ? (unsigned)kGenMaxGather : gather);
+        }
+        const unsigned wgs = (pop_size + kWave * gather - 1) / (kWave * gather);
+        const size_t lds = staged_lds_bytes(gp_len, gather);
+        if (out_len > 1) hipLaunchKernelGGL(generate_staged_kernel<true>, dim3(wgs), dim3(kWave), lds, stream, p, gather);
+        else hipLaunchKernelGGL(generate_staged_kernel<false>, dim3(wgs), dim3(kWave), lds, stream, p, gather);
         return (int)hipGetLastError();
     }
     const unsigned blocks = (pop_size + kGenBlock - 1) / kGenBlock;
