@@ -98,13 +98,13 @@ class GeneticProgramming:
             order = torch.ops.evogp_hip.select_survivors(fitness.contiguous(), n_elite, n_surv)
         else:
             order = torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv)].to(torch.int32).contiguous()
-        rnd = torch.randint(0, 2**31 - 1, (6, n_new), dtype=torch.int32, device=dev)
+        # one draw: six 31-bit words per offspring, and two more as the keys of the donor trees' streams (the reference draws
+        # the keys below 10^6, tree/forest.py:51-57; they only seed a hash, and a launch of their own costs 4-5 us)
+        words = torch.randint(0, 2**31 - 1, (6 * n_new + 2,), dtype=torch.int32, device=dev)
+        rnd = words[:6 * n_new].view(6, n_new)
+        keys = words[6 * n_new:].view(torch.uint32)
         below = int(min(max(self.mutation.mutation_rate, 0.0), 1.0) * (2**31 - 1))
         d = self.mutation.descriptor
-        try:
-            keys = torch.randint(low=0, high=1000000, size=(2,), dtype=torch.uint32, device=dev)
-        except RuntimeError:
-            keys = torch.randint(0, 1000000, (2,), device=dev).to(torch.uint32)
         value, ntype, size = f._tensors()
         donors = torch.ops.evogp_hip.tree_generate_masked(
             n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
