@@ -398,28 +398,42 @@ def main():
         mdesc = GenerateDescriptor(max_tree_len=GP_LEN, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/"],
                                    max_layer_cnt=3, const_samples=[-1, 0, 1])
 
-        # one generation of the GLOBAL population: local fitness, all-gathers of the fitness values and of the
-        # survivor rows, identical selection / random words on every rank, every rank breeds its own rows
-        sharded_ms, sharded_err = [], None
-        try:
-            from evogp_amd.parallel import ShardedGeneticProgramming
+        # one generation of the GLOBAL population: local fitness, the exchange, identical selection / random words on
+        # every rank, every rank breeds its own rows.  Measured for DefaultSelection and for the TournamentSelection BASELINE
+        # configs[2] names (the reference's own setting, example/uci_sr.py:73-75), and for each form of the exchange: two
+        # all-gathers (fitness, then the rows the selection names; exact or sync-free row count) or ONE packed all-gather.
+        from evogp_amd.algorithm.selection import TournamentSelection
+        from evogp_amd.parallel import ShardedGeneticProgramming
 
-            sg = ShardedGeneticProgramming(forest, 0.2, mdesc, DefaultSelection(0.3, elite_rate=0.01), seed=1234)
-            neg_inf = torch.full((pop,), float("-inf"), dtype=torch.float32, device=device)
-            for _ in range(5):
-                barrier(); g0 = time.perf_counter()
-                f = -sg.forest.SR_fitness(Xd, yd, True, "auto")
-                f = torch.where(torch.isnan(f), neg_inf, f)
-                sg.step(f)
-                barrier(); sharded_ms.append(max_over_ranks((time.perf_counter() - g0) * 1000))
-            del sg
-        except Exception as exc:  # the fitness line must survive a failure of the exchange step
-            sharded_err = repr(exc)[:300]
+        def sharded_generation(selection, sel_name, exchange, cap):
+            ms, err, sent = [], None, None
+            try:
+                sg = ShardedGeneticProgramming(forest, 0.2, mdesc, selection, seed=1234, exchange=exchange, cap=cap)
+                neg_inf = torch.full((pop,), float("-inf"), dtype=torch.float32, device=device)
+                for _ in range(5):
+                    barrier(); g0 = time.perf_counter()
+                    f = -sg.forest.SR_fitness(Xd, yd, True, "auto")
+                    f = torch.where(torch.isnan(f), neg_inf, f)
+                    sg.step(f)
+                    barrier(); ms.append(max_over_ranks((time.perf_counter() - g0) * 1000))
+                sent = dict(sg.last_exchange)
+                del sg
+            except Exception as exc:  # the fitness line must survive a failure of the exchange step
+                err = repr(exc)[:300]
+            return {"selection": sel_name, "exchange": "none (one rank)" if world == 1 else (exchange if exchange == "packed" else f"rows/{cap}"),
+                    "median": float(np.median(ms[1:])) if len(ms) > 1 else None, "last_exchange": sent, "error": err}
+
+        default_sel = lambda: DefaultSelection(0.3, elite_rate=0.01)                                             # noqa: E731
+        tournament_sel = lambda: TournamentSelection(tournament_size=20, survivor_rate=0.5, elite_rate=0.1)       # noqa: E731
+        modes = [("rows", "exact")] if world == 1 else [("rows", "exact"), ("rows", "bound"), ("packed", "exact")]
+        runs = [sharded_generation(default_sel(), "DefaultSelection(0.3, elite_rate=0.01)", e, c) for e, c in modes]
+        runs += [sharded_generation(tournament_sel(), "TournamentSelection(20, survivor_rate=0.5, elite_rate=0.1)", e, c) for e, c in modes]
         extras["generation_ms_sharded"] = {
-            "median": float(np.median(sharded_ms[1:])) if len(sharded_ms) > 1 else None, "global_pop": P, "ranks": world,
-            "exchange": ("none (one rank)" if world == 1 else f"all_gather_into_tensor x2 over {backend}"), "error": sharded_err,
-            "what": "whole population: local fitness + all-gather of the fitness values + all-gather of the survivor rows + selection + "
-                    "breeding pass for the local rows, max over ranks, barriers on both sides"}
+            "median": runs[0]["median"], "selection": runs[0]["selection"], "exchange": runs[0]["exchange"], "error": runs[0]["error"],
+            "global_pop": P, "ranks": world, "backend": backend, "runs": runs,
+            "what": "whole population: local fitness + exchange (rows: all-gather of the fitness values, selection, all-gather of the rows the "
+                    "selection names; packed: ONE all-gather of {fitness|value|type|size} per tree, then selection) + breeding pass for the local "
+                    "rows, max over ranks, barriers on both sides; DefaultMutation(0.2); last_exchange.bytes_sent = bytes this rank contributes"}
 
         # BASELINE configs[1]: 100k trees per GPU (weak), same protocol
         pop1 = args.pop_per_gpu

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "evogp_hip_breed_default": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_breed_default_rows": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_breed_default_table": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "evogp_hip_breed_lists": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_batch_argmax_count": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_evaluate_prepare": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_size_t, _vp],

@@ -67,21 +67,24 @@ class GeneticProgramming:
 
     # ---- fused default step ------------------------------------------------------------
     def _native_default_ok(self) -> bool:
-        """The three default operators on a device forest: one sort, one randint, masked donor generation and ONE
-        breeding pass instead of ~90 small launches and two host syncs (same distribution of offspring; the random
-        words come from one torch.randint instead of the reference's seven draws).  EVOGP_NATIVE_STEP=0 disables it."""
+        """DefaultCrossover + DefaultMutation on a device forest, under ANY selection operator: one selection (a single
+        launch for DefaultSelection; the operator's own torch program otherwise — its survivor list may repeat trees,
+        selection/tournament.py:59-133), one randint, masked donor generation and ONE breeding pass instead of ~90 small
+        launches and two host syncs (same distribution of offspring; the random words come from one torch.randint instead
+        of the reference's seven draws).  EVOGP_NATIVE_STEP=0 disables it."""
         from .crossover import DefaultCrossover
         from .mutation import DefaultMutation
         from .selection import DefaultSelection
 
         if os.environ.get("EVOGP_NATIVE_STEP", "1") == "0":
             return False
-        if type(self.selection) is not DefaultSelection or type(self.crossover) is not DefaultCrossover \
-                or type(self.mutation) is not DefaultMutation:
+        if type(self.crossover) is not DefaultCrossover or type(self.mutation) is not DefaultMutation:
             return False
         f = self.forest
         if not f.batch_node_value.is_cuda or self.mutation.descriptor.max_tree_len != f.max_tree_len:
             return False
+        if type(self.selection) is not DefaultSelection:
+            return True
         n_elite, n_surv = self.selection.counts(f.pop_size)
         return 0 <= n_elite < f.pop_size and 0 < n_surv <= f.pop_size
 
@@ -89,15 +92,20 @@ class GeneticProgramming:
         f = self.forest
         dev = f.batch_node_value.device
         pop, L = f.pop_size, f.max_tree_len
-        n_elite, n_surv = self.selection.counts(pop)
-        n_new = pop - n_elite
-        # elites first, then the other survivors (each group by tree index): ONE launch instead of a sort of the whole vector --
-        # nothing downstream uses the order inside the two sets (csrc/select.hip).  (Drawing the words and generating the donors
+        # DefaultSelection: elites first, then the other survivors (each group by tree index) from ONE launch instead of a sort of
+        # the whole vector -- nothing downstream uses the order inside the two sets (csrc/select.hip; parallel.default_lists also
+        # covers more elites than parents).  Any other operator: its own two lists.  (Drawing the words and generating the donors
         # on a second stream meanwhile was measured twice: the stream hand-over costs more than the 25 us it hides.)
-        if n_elite <= n_surv and fitness.dtype == torch.float32 and os.environ.get("EVOGP_NATIVE_SELECT", "1") != "0":
-            order = torch.ops.evogp_hip.select_survivors(fitness.contiguous(), n_elite, n_surv)
+        from ..parallel import default_lists
+        from .selection import DefaultSelection
+
+        if type(self.selection) is DefaultSelection:
+            elites, parents = default_lists(fitness.to(torch.float32), *self.selection.counts(pop))
         else:
-            order = torch.sort(fitness, descending=True, stable=True).indices[:max(n_elite, n_surv)].to(torch.int32).contiguous()
+            elites, parents = self.selection(f, fitness)
+            elites, parents = elites.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous()
+        n_elite = elites.numel()
+        n_new = pop - n_elite
         # one draw: six 31-bit words per offspring, and two more as the keys of the donor trees' streams (the reference draws
         # the keys below 10^6, tree/forest.py:51-57; they only seed a hash, and a launch of their own costs 4-5 us)
         words = torch.randint(0, 2**31 - 1, (6 * n_new + 2,), dtype=torch.int32, device=dev)
@@ -109,7 +117,6 @@ class GeneticProgramming:
         donors = torch.ops.evogp_hip.tree_generate_masked(
             n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
             d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, rnd[4], below)
-        nv, nt, ns, _ = torch.ops.evogp_hip.breed_default(pop, L, n_elite, n_surv, value, ntype, size, order, rnd, below,
-                                                          *donors, False)
+        nv, nt, ns = torch.ops.evogp_hip.breed_rows(pop, L, value, ntype, size, elites, parents, rnd, below, *donors, 0, pop)
         self.forest = Forest(f.input_len, f.output_len, nv, nt, ns)
         return self.forest

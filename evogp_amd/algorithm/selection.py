@@ -99,9 +99,13 @@ class TruncationSelector(BaseSelector):
 
 
 class TournamentSelector(BaseSelector):
-    """``choosed_num`` tournaments of ``tournament_size`` contenders; the k-th best contender wins with probability
-    p (1 - p)^k (ranks past the tournament fall back to the best, tournament.py:98-104).  ``replace=False`` forms the
-    tournaments of one pass from a random permutation, so nobody enters twice in a pass."""
+    """``choosed_num`` tournaments of ``tournament_size`` contenders (selection/tournament.py:59-133): the k-th best contender
+    wins with probability p (1 - p)^k, ranks past the tournament fall back to the best (:98-104).  The contenders come in
+    PASSES of ``n // tournament_size`` tournaments, as in the reference (:117-121: one ``torch.multinomial`` row of
+    ``n_tournament * t_size`` uniform draws per pass): with ``replace=False`` nobody enters twice in a pass.
+
+    Split into ``draw`` (the random numbers) and ``apply`` (deterministic), like the mutation operators:
+    tests/golden/make_tournament_golden.py records the reference's own draws, ``apply`` must return its survivors."""
 
     def __init__(self, tournament_size: int, best_probability: float = 1, replace: bool = True):
         assert tournament_size >= 1
@@ -109,30 +113,47 @@ class TournamentSelector(BaseSelector):
         self.best_p = best_probability
         self.replace = replace
 
+    def passes(self, n: int, count: int):
+        """-> (tournaments per pass, number of passes) -- tournament.py:117-119"""
+        per_pass = max(n // self.t_size, 1)
+        return per_pass, (count - 1) // per_pass + 1
+
     def contenders(self, n: int, count: int, device) -> torch.Tensor:
+        """int64[count][t_size]: the tournaments' members"""
         t = self.t_size
+        per_pass, passes = self.passes(n, count)
         if self.replace:
-            return torch.randint(0, n, (count, t), device=device)
-        per_pass = max(n // t, 1)
-        passes = (count - 1) // per_pass + 1
+            return torch.randint(0, n, (passes * per_pass, t), device=device)[:count]
         perm = torch.rand((passes, n), device=device).argsort(dim=1)[:, : per_pass * t]
         if perm.shape[1] < per_pass * t:  # population smaller than one tournament
             perm = perm.repeat(1, (per_pass * t) // perm.shape[1] + 1)[:, : per_pass * t]
         return perm.reshape(-1, t)[:count]
 
-    def __call__(self, fitness, choosed_num):
+    def draw(self, n: int, count: int, device):
+        """-> (contenders int64[count][t], u float32[count] or None when the best always wins)"""
+        c = self.contenders(n, count, device)
+        u = None if (self.best_p >= 1 and self.t_size > 1000) else torch.rand(count, device=device)
+        return c, u
+
+    def apply(self, fitness: torch.Tensor, contenders: torch.Tensor, u: Optional[torch.Tensor]) -> torch.Tensor:
         f = _clean(fitness)
-        c = self.contenders(f.shape[0], choosed_num, f.device)
+        c = contenders.to(torch.int64)
         cf = f[c]
-        if self.best_p >= 1:
+        if u is None or self.best_p >= 1:
+            # p = 1: log(u) / log(0) = -0 -> rank 0, the best (tournament.py:98-104); :123-124 takes the arg-max directly
+            # for tournaments above 1000 contenders
             pick = cf.argmax(dim=1, keepdim=True)
         else:
-            rank = cf.argsort(dim=1, descending=True)
-            u = torch.rand(choosed_num, device=f.device).clamp(min=1e-30)
-            nth = (torch.log(u) / torch.log(torch.tensor(1.0 - self.best_p, device=f.device))).to(torch.int64)
+            rank = cf.argsort(dim=1, descending=True, stable=True)
+            one_minus_p = 1 - torch.tensor(self.best_p, dtype=torch.float32, device=f.device)   # in float32, as :100-101
+            nth = (torch.log(u.to(torch.float32)) / torch.log(one_minus_p)).to(torch.int64)
             nth = torch.where((nth >= self.t_size) | (nth < 0), torch.zeros_like(nth), nth)
             pick = rank.gather(1, nth[:, None])
         return c.gather(1, pick).squeeze(1).to(torch.int32)
+
+    def __call__(self, fitness, choosed_num):
+        c, u = self.draw(fitness.shape[0], choosed_num, fitness.device)
+        return self.apply(fitness, c, u)
 
 
 class _SelectorSelection(BaseSelection):

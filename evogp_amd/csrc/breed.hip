@@ -29,7 +29,8 @@ namespace evogp {
 
 struct BreedParams {
     const float *v; const int16_t *t; const int16_t *s;    // current generation [pop][gp_len]
-    const int *order;                                        // [n_surv] descending fitness order
+    const int *order;                                        // [n_elite] rows copied unchanged (the elites)
+    const int *parents;                                      // [n_surv] rows the parents are drawn from (repeats allowed)
     const int *rnd;                                          // [6][n_new] raw words in [0, 2^31 - 1)
     const float *dv; const int16_t *dt; const int16_t *ds;  // donors [n_new][gp_len] (rows of mutating offspring only)
     float *ov; int16_t *ot; int16_t *os;                    // next generation [pop][gp_len]
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
                 const unsigned r0 = (unsigned)a.rnd[i], r1 = (unsigned)a.rnd[a.n_new + i], r2 = (unsigned)a.rnd[2 * a.n_new + i],
                                r3 = (unsigned)a.rnd[3 * a.n_new + i], r4 = (unsigned)a.rnd[4 * a.n_new + i];
                 r5 = (unsigned)a.rnd[5 * a.n_new + i];
-                li = a.order[r0 % (unsigned)a.n_surv];
-                ri = a.order[r1 % (unsigned)a.n_surv];
+                li = a.parents[r0 % (unsigned)a.n_surv];
+                ri = a.parents[r1 % (unsigned)a.n_surv];
                 li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
                 ri = ri < 0 ? 0 : (ri >= a.table_rows ? a.table_rows - 1 : ri);
                 const int16_t *ls = a.s + (size_t)li * a.gp_len, *rs = a.s + (size_t)ri * a.gp_len;
@@ -181,8 +182,8 @@ __global__ __launch_bounds__(kRepBlock) void breed_group_kernel(BreedParams a) {
                 const unsigned r0 = (unsigned)a.rnd[i], r1 = (unsigned)a.rnd[a.n_new + i], r2 = (unsigned)a.rnd[2 * a.n_new + i],
                                r3 = (unsigned)a.rnd[3 * a.n_new + i], r4 = (unsigned)a.rnd[4 * a.n_new + i];
                 r5 = (unsigned)a.rnd[5 * a.n_new + i];
-                li = a.order[r0 % (unsigned)a.n_surv];
-                ri = a.order[r1 % (unsigned)a.n_surv];
+                li = a.parents[r0 % (unsigned)a.n_surv];
+                ri = a.parents[r1 % (unsigned)a.n_surv];
                 li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
                 ri = ri < 0 ? 0 : (ri >= a.table_rows ? a.table_rows - 1 : ri);
                 const int16_t *ls = a.s + (size_t)li * a.gp_len, *rs = a.s + (size_t)ri * a.gp_len;
@@ -289,15 +290,28 @@ extern "C" int evogp_hip_breed_default_table(int pop_size, int table_rows, int g
                                              const int16_t *donor_type, const int16_t *donor_size, float *value_res,
                                              int16_t *type_res, int16_t *size_res, int *decisions, int row_begin, int row_count,
                                              evogp_stream_t stream_) {
-    if (pop_size <= 0 || table_rows <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0 ||
-        n_surv > pop_size)
+    // elites and parents are both prefixes of one ranking
+    if (n_surv > pop_size) return EVOGP_E_BADARG;
+    return evogp_hip_breed_lists(pop_size, table_rows, gp_len, n_elite, n_surv, value, type, size, order, order, rnd, mutate_below,
+                                 donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions, row_begin, row_count,
+                                 stream_);
+}
+
+extern "C" int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
+                                     const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
+                                     const int *rnd, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                                     const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
+                                     int *decisions, int row_begin, int row_count, evogp_stream_t stream_) {
+    const int *order = elite_rows;
+    // n_surv may exceed pop_size: a selection that draws with replacement may name more parents than there are trees
+    if (pop_size <= 0 || table_rows <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0)
         return EVOGP_E_BADARG;
-    if (!value || !type || !size || !order || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
+    if (!value || !type || !size || !parent_rows || (n_elite > 0 && !order) || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
     const int n_new = pop_size - n_elite;
     if (n_new > 0 && !rnd) return EVOGP_E_NULLPTR;
     if (mutate_below != 0 && n_new > 0 && (!donor_value || !donor_type || !donor_size)) return EVOGP_E_NULLPTR;
     if (row_begin < 0 || row_count <= 0 || row_begin + row_count > pop_size) return EVOGP_E_BADARG;
-    BreedParams a{value, type, size, order, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
+    BreedParams a{value, type, size, order, parent_rows, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
                   decisions, pop_size, gp_len, n_elite, n_surv, n_new, table_rows, mutate_below, row_begin, row_count};
     const DeviceInfo &dev = device_info();
     long blocks = ((long)row_count + 63) / 64;  // one workgroup per 64 rows

@@ -15,6 +15,7 @@
 // so all workgroups are resident and the barrier (an atomic counter in the caller's zeroed workspace) cannot deadlock.
 #include "evogp_defs.hpp"
 #include "launch.hpp"
+#include <cstdlib>
 
 namespace evogp {
 
@@ -27,9 +28,12 @@ constexpr int kSelHist = 16;
 constexpr int kSelCounts = kSelHist + 5 * kSelBins;
 constexpr int kSelWords = kSelCounts + 4 * kSelMaxBlocks;
 
-__device__ inline uint32_t select_key(float f) {  // larger fitness <=> larger key; NaN -> 0
-    const uint32_t u = f2bits(f);
+// larger fitness <=> larger key; NaN -> 0 (worse than -inf); -0 and +0 share a key, so ties between them go by index as in a
+// stable sort of the float values (evogp_amd/parallel.py select_order computes the same key in torch where there is no GPU)
+__device__ inline uint32_t select_key(float f) {
+    uint32_t u = f2bits(f);
     if (f != f) return 0u;
+    if (f == 0.0f) u = 0u;
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
@@ -247,10 +251,29 @@ extern "C" int evogp_hip_select(unsigned n, unsigned n_elite, unsigned n_keep, c
     if (n == 0 || n_keep == 0 || n_keep > n || n_elite > n_keep) return EVOGP_E_BADARG;
     if (!fitness || !order || !zeroed_workspace) return EVOGP_E_NULLPTR;
     SelectParams p{fitness, order, (unsigned *)zeroed_workspace, (int)n, (int)n_elite, (int)n_keep};
+    // The grid barrier needs every workgroup resident at once: never launch more than the occupancy calculator says fit
+    // (CU masks and partitioned modes shrink the chip), and ask the runtime for a cooperative launch, which fails instead of
+    // hanging when they would not.  EVOGP_SELECT_COOP=0: plain launch of the same clamped grid.
+    static const int per_cu = [] {
+        int b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, select_kernel, kSelThreads, 0) != hipSuccess) b = 0;
+        return b;
+    }();
+    static const bool coop = [] { const char *e = getenv("EVOGP_SELECT_COOP"); return !(e && e[0] == '0'); }();
+    if (per_cu < 1) return EVOGP_E_UNSUPPORTED;
     int blocks = device_info().num_cus;
     if (blocks > kSelMaxBlocks) blocks = kSelMaxBlocks;
+    const long fit = (long)per_cu * device_info().num_cus;
+    if (blocks > fit) blocks = (int)fit;
     const int need = ((int)n + kSelThreads - 1) / kSelThreads;
     if (blocks > need) blocks = need;
+    if (coop) {
+        void *args[] = {(void *)&p};
+        const hipError_t e = hipLaunchCooperativeKernel((const void *)select_kernel, dim3((unsigned)blocks), dim3(kSelThreads), args, 0,
+                                                        (hipStream_t)stream_);
+        if (e == hipSuccess) return EVOGP_OK;
+        (void)hipGetLastError();   // not supported on this device / in this context: the clamped plain launch below
+    }
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, (hipStream_t)stream_, p);
     return (int)hipGetLastError();
 }

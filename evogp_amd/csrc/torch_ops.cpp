@@ -368,6 +368,42 @@ Tensor3 breed_default_rows(int64_t pop_size, int64_t gp_len, int64_t n_elite, in
     return out;
 }
 
+// The same rows for ANY selection operator: the elites and the parents are two lists of table rows (parents may repeat, as
+// the survivor indices of a tournament selection do); n_elite / n_surv are the lists' lengths.
+Tensor3 breed_rows(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
+                   const Tensor &parent_rows, const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value, const Tensor &donor_type,
+                   const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
+    check_sizes(pop_size, gp_len);
+    TORCH_CHECK(row_begin >= 0 && row_count > 0 && row_begin + row_count <= pop_size, "row range out of the population");
+    TORCH_CHECK(mutate_below >= 0 && mutate_below < (1LL << 32), "mutate_below must fit in 32 bits");
+    TORCH_CHECK(value.dim() == 2 && value.size(0) > 0, "value must be a (rows, gp_len) tensor");
+    const int64_t table_rows = value.size(0);
+    const c10::Device dev = value.device();
+    check_forest(table_rows, gp_len, value, type, size, dev);
+    TORCH_CHECK(elite_rows.dim() == 1 && parent_rows.dim() == 1, "elite_rows / parent_rows must be vectors");
+    const int64_t n_elite = elite_rows.size(0), n_surv = parent_rows.size(0);
+    TORCH_CHECK(n_elite <= pop_size && n_surv > 0, "need n_elite <= pop_size and at least one parent, got ", n_elite, ", ", n_surv);
+    check_order(parent_rows, n_surv, dev);
+    if (n_elite > 0) check_order(elite_rows, n_elite, dev);
+    check_tensor(rnd, {6, pop_size - n_elite}, "rnd", dev, at::kInt);
+    const int64_t head = std::max<int64_t>(0, std::min(row_begin + row_count, n_elite) - row_begin);
+    const int64_t drows = donor_value.dim() == 2 ? donor_value.size(0) : -1;
+    TORCH_CHECK(drows == row_count || drows == row_count - head, "donor arrays must have ", row_count, " or ", row_count - head,
+                " rows, but got ", drows);
+    check_forest(drows, gp_len, donor_value, donor_type, donor_size, dev, " (donor)");
+    const int64_t skip = drows == row_count - head ? head : 0;
+    c10::DeviceGuard guard(dev);
+    Tensor3 out = empty_forest(row_count, gp_len, dev);
+    const int rc = evogp_hip_breed_lists(
+        (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),
+        size.data_ptr<int16_t>(), n_elite > 0 ? elite_rows.data_ptr<int>() : nullptr, parent_rows.data_ptr<int>(), rnd.data_ptr<int>(),
+        (unsigned)mutate_below, donor_value.data_ptr<float>() - skip * gp_len, donor_type.data_ptr<int16_t>() - skip * gp_len,
+        donor_size.data_ptr<int16_t>() - skip * gp_len, std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
+        std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, current_stream(dev));
+    check_rc(rc, "breed_rows");
+    return out;
+}
+
 }  // namespace
 
 // schemas of the reference, verbatim (torch_wrapper.cu:294-298)
@@ -410,6 +446,9 @@ TORCH_LIBRARY(evogp_hip, m) {
     m.def("breed_default_rows(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
           " int row_begin, int row_count) -> (Tensor value, Tensor node_type, Tensor subtree_size)");
+    m.def("breed_rows(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows, Tensor parent_rows,"
+          " Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin, int row_count)"
+          " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
 }
 
 TORCH_LIBRARY_IMPL(evogp_hip, CompositeExplicitAutograd, m) { m.impl("random_words", &random_words); }  // no tensor argument to dispatch on
@@ -423,5 +462,6 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("tree_evaluate_prepared", &tree_evaluate_prepared);
     m.impl("breed_default", &breed_default);
     m.impl("breed_default_rows", &breed_default_rows);
+    m.impl("breed_rows", &breed_rows);
     m.impl("select_survivors", &select_survivors);
 }

@@ -39,7 +39,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from .algorithm.selection import DefaultSelection
+from .algorithm.selection import BaseSelection, DefaultSelection
 from .tree import MAX_STACK, Forest, GenerateDescriptor
 
 
@@ -62,35 +62,57 @@ def _unpack(buf: torch.Tensor, L: int, input_len: int, output_len: int) -> Fores
     return Forest(input_len, output_len, value, ntype, size)
 
 
+def _select_key(fit: torch.Tensor) -> torch.Tensor:
+    """the order-preserving integer key of csrc/select.hip (select_key) as int64: larger fitness <=> larger key, NaN -> 0 (worse
+    than -inf), -0 and +0 share a key"""
+    f = fit.to(torch.float32)
+    u = f.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    u = torch.where(f == 0, torch.zeros_like(u), u)
+    key = torch.where(u >= 0x80000000, 0xFFFFFFFF - u, u + 0x80000000)
+    return torch.where(f != f, torch.zeros_like(key), key)
+
+
 def select_order(fit: torch.Tensor, n_elite: int, n_keep: int) -> torch.Tensor:
     """int32[n_keep]: the n_elite best trees, then the other survivors, each group in ascending tree index; ties at a threshold go
-    to the lower index, i.e. the two SETS are those of a stable descending sort.  Nothing downstream uses an order inside the sets
-    (elites are copied, parents are drawn uniformly), so no sort of the population is needed: on a GPU this is ONE launch of an
-    exact radix select (csrc/select.hip: 25 us at 100 k values, 40 us at 1 M; torch.sort takes 61 / 219 us, torch.kthvalue 0.39 /
-    3.8 ms); elsewhere the same result from torch ops.  Every rank runs it on the identical gathered vector."""
+    to the lower index, i.e. the two SETS are those of a stable descending sort (NaN ranks worst, -0 = +0).  Nothing downstream uses
+    an order inside the sets (elites are copied, parents are drawn uniformly), so no sort of the population is needed: on a GPU this
+    is ONE launch of an exact radix select (csrc/select.hip: 25 us at 100 k values, 40 us at 1 M; torch.sort takes 61 / 219 us,
+    torch.kthvalue 0.39 / 3.8 ms); elsewhere the same result from torch ops.  Every rank runs it on the identical gathered vector."""
     n_elite = min(n_elite, n_keep)
     if fit.is_cuda and fit.dtype == torch.float32 and os.environ.get("EVOGP_NATIVE_SELECT", "1") != "0":
         return torch.ops.evogp_hip.select_survivors(fit.contiguous(), n_elite, n_keep)
-    best = torch.sort(fit, descending=True, stable=True).indices[:n_keep]
+    best = torch.sort(_select_key(fit), descending=True, stable=True).indices[:n_keep]
     return torch.cat([torch.sort(best[:n_elite]).values, torch.sort(best[n_elite:]).values]).to(torch.int32)
 
 
-def plan_exchange(fit_all: torch.Tensor, n_elite: int, n_keep: int, world: int):
-    """From the gathered fitness of the whole population (rank-major): which trees are kept, how many rows every rank contributes,
-    and where each kept tree lands in the gathered table.  -> (per_rank bool[world][n_local], cap, order int32[n_keep] of TABLE rows,
-    elites first).  ``cap`` -- the largest number of kept trees on any rank, the row count every rank pads its block to -- is the
-    step's one host sync (one integer); a bound that needs none would have to be min(n_local, n_keep), i.e. gather the whole
-    population at world sizes where n_keep > n_local."""
-    pop = fit_all.shape[0]
-    chosen = select_order(fit_all, n_elite, n_keep).long()
-    kept = torch.zeros(pop, dtype=torch.bool, device=fit_all.device)
-    kept[chosen] = True
+def default_lists(fit: torch.Tensor, n_elite: int, n_surv: int):
+    """DefaultSelection (selection/default.py:42-71) without a sort: -> (elites int32[n_elite], parents int32[n_surv]), both
+    prefixes of ONE select_order call.  The smaller set is selected first, so the prefixes are right whichever is larger
+    (DefaultSelection(survival_rate=0.3, elite_cnt=large) is legal: the elites are then the n_elite best, the parents the n_surv
+    best of them)."""
+    order = select_order(fit, min(n_elite, n_surv), max(n_elite, n_surv, 1))
+    return order[:n_elite], order[:n_surv]
+
+
+def plan_exchange(elites: torch.Tensor, parents: torch.Tensor, pop: int, world: int, cap: Optional[int] = None):
+    """From the selection's two lists of GLOBAL tree indices (rank-major population): which trees are kept (read by the next
+    generation), how many rows every rank contributes, and where each kept tree lands in the gathered table.
+    -> (per_rank bool[world][n_local], cap, elite_rows int32, parent_rows int32 — the lists as TABLE rows).
+    ``cap`` — the row count every rank pads its block to — is, when not given, the largest number of kept trees on any rank:
+    the step's one host sync (one integer).  A caller that passes a bound (``min(n_local, len(elites) + len(parents))`` never
+    overflows) avoids the sync and gathers more rows."""
+    dev = parents.device
+    kept = torch.zeros(pop, dtype=torch.bool, device=dev)
+    kept[parents.long()] = True
+    if elites.numel():
+        kept[elites.long()] = True
     per_rank = kept.view(world, pop // world)
-    cap = int(per_rank.sum(1).max())
+    if cap is None:
+        cap = int(per_rank.sum(1).max())
     # a rank sends its kept trees in ascending local index (kept_rows): tree g of rank r is row r * cap + (kept trees of r below g)
     below = torch.cumsum(per_rank.to(torch.int64), dim=1) - 1
-    table_row = (below + torch.arange(world, device=fit_all.device)[:, None] * cap).view(-1)
-    return per_rank, cap, table_row[chosen].to(torch.int32).contiguous()
+    table_row = (below + torch.arange(world, device=dev)[:, None] * cap).view(-1)
+    return per_rank, cap, table_row[elites.long()].to(torch.int32).contiguous(), table_row[parents.long()].to(torch.int32).contiguous()
 
 
 def kept_rows(mine: torch.Tensor, cap: int) -> torch.Tensor:
@@ -121,19 +143,55 @@ def random_words(seed: int, generation: int, rows: int, lo: int, hi: int, device
     return (((x >> 33) & 0x7FFFFFFF) % (2**31 - 1)).to(torch.int32)
 
 
+class _Population:
+    """what a selection operator may read of the (sharded) population: its size"""
+
+    def __init__(self, pop_size: int):
+        self.pop_size = pop_size
+
+    def __len__(self):
+        return self.pop_size
+
+    def __getattr__(self, name):
+        raise AttributeError(f"a selection operator of a sharded run sees the gathered fitness vector and pop_size only, not "
+                             f"Forest.{name}: the trees live on other ranks")
+
+
 class ShardedGeneticProgramming:
     """GeneticProgramming over a population sharded across the ranks of ``group``.
 
-    ``local_forest`` is this rank's block of the population (equal sizes on all ranks).  ``step``
-    takes the fitness of the LOCAL trees and returns the local block of the next generation.
-    """
+    ``local_forest`` is this rank's block of the population (equal sizes on all ranks).  ``step`` takes the fitness of the
+    LOCAL trees and returns the local block of the next generation.
+
+    ``selection``: any ``BaseSelection`` (genetic_programming.py:110: ``elite_indices, next_indices = self.selection(forest,
+    fitness)``).  Every rank holds the identical gathered fitness vector and runs the operator on it under a generator seeded
+    with (seed, generation), so all ranks — and every world size — get the same two index lists; the
+    survivor list may repeat trees (TournamentSelection, selection/tournament.py:59-133) and is used exactly as
+    crossover/default.py:37-58 uses it: parents are drawn uniformly from the LIST.  ``DefaultSelection`` takes the
+    one-launch radix select instead of a sort (same sets).
+
+    ``exchange``: "rows" — all-gather the fitness (4 B per tree), select, all-gather only the rows the lists name;
+    "packed" — ONE all-gather of {fitness | value | type | size} per tree (4 + 8 L bytes, SURVEY.md §8e's exact-semantics
+    variant, the north star's "single all-gather"), then select on the gathered table.
+    ``cap`` (rows mode): "exact" — every rank pads its block to the largest kept count of any rank (one host sync per step);
+    "bound" — to ``min(n_local, n_elite + n_surv)`` (``max`` for DefaultSelection, whose lists nest): no host sync, more rows.
+    ``last_exchange`` records what the step sent."""
 
     def __init__(self, local_forest: Forest, mutation_rate: float, mutation_descriptor: GenerateDescriptor,
-                 selection: Optional[DefaultSelection] = None, seed: int = 0, group=None):
+                 selection: Optional[BaseSelection] = None, seed: int = 0, group=None, exchange: str = "rows", cap: str = "exact"):
+        if selection is None:
+            selection = DefaultSelection(survival_rate=0.3, elite_rate=0.01)
+        if not isinstance(selection, BaseSelection):
+            raise TypeError(f"selection must be a BaseSelection, got {type(selection).__name__}: the sharded step has no "
+                            "deterministic way to run it on every rank")
+        assert exchange in ("rows", "packed"), f"exchange should be 'rows' or 'packed', but got {exchange}"
+        assert cap in ("exact", "bound"), f"cap should be 'exact' or 'bound', but got {cap}"
         self.forest = local_forest
         self.mutation_rate = mutation_rate
         self.descriptor = mutation_descriptor
-        self.selection = selection or DefaultSelection(survival_rate=0.3, elite_rate=0.01)
+        self.selection = selection
+        self.exchange_mode = exchange
+        self.cap_mode = cap
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -145,57 +203,91 @@ class ShardedGeneticProgramming:
         self.generation = 0
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)  # identical on every rank: the draws of the torch composition (slice_torch) agree
+        self.last_exchange = {}
+
+    # -- selection, identical on every rank --------------------------------------------------------
+    def select(self, fit_all: torch.Tensor):
+        """-> (elites int32[n_elite], parents int32[n_surv]): global tree indices; parents may repeat"""
+        pop = fit_all.shape[0]
+        if type(self.selection) is DefaultSelection:
+            n_elite, n_surv = self.selection.counts(pop)
+            assert n_surv >= 1, "the selection leaves no parent (crossover/default.py:40 draws from an empty range)"
+            return default_lists(fit_all, n_elite, n_surv)
+        dev = fit_all.device
+        with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else [], enabled=True):
+            torch.manual_seed(int(_mix64(torch.tensor([self.seed * 1000003 + self.generation], dtype=torch.int64))[0]) & 0x7FFFFFFFFFFF)
+            try:
+                elites, parents = self.selection(_Population(pop), fit_all)
+            except AttributeError as e:
+                raise TypeError(f"{type(self.selection).__name__} cannot run in a sharded step: {e}") from None
+        assert parents.numel() >= 1, "the selection leaves no parent (crossover/default.py:40 draws from an empty range)"
+        return elites.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous()
+
+    def _cap_bound(self, n_elite: int, n_surv: int) -> int:
+        both = max(n_elite, n_surv) if type(self.selection) is DefaultSelection else n_elite + n_surv
+        return max(1, min(self.n_local, both))
 
     # -- the exchange step -------------------------------------------------------------------------
     def exchange(self, local_fitness: torch.Tensor):
-        """-> (table Forest, order int32[n_keep] of table rows: the elites, then the other survivors, global pop)"""
-        n_elite, n_surv = self.selection.counts(self.pop_size)
-        n_keep = max(n_elite, n_surv, 1)
+        """-> (table Forest, elite_rows int32[n_elite], parent_rows int32[n_surv] — rows of the table, global pop)"""
         f = self.forest
         fit = local_fitness.to(torch.float32).contiguous()
+        L = f.max_tree_len
         if self.world == 1:
-            return f, select_order(fit, n_elite, n_keep), self.pop_size
+            elites, parents = self.select(fit)
+            self.last_exchange = dict(mode="none", collectives=0, bytes_sent=0)
+            return f, elites, parents, self.pop_size
+        if self.exchange_mode == "packed":
+            # ONE collective: {fitness | value | type | size} of every local tree
+            send = torch.cat([fit.view(-1, 1).view(torch.uint8), _pack(f)], dim=1).contiguous()
+            table = torch.empty((self.pop_size, send.shape[1]), dtype=torch.uint8, device=send.device)
+            dist.all_gather_into_tensor(table, send, group=self.group)
+            fit_all = table[:, :4].contiguous().view(torch.float32).view(-1)
+            elites, parents = self.select(fit_all)
+            self.last_exchange = dict(mode="packed", collectives=1, bytes_sent=send.numel(), rows_sent=self.n_local)
+            return _unpack(table[:, 4:], L, f.input_len, f.output_len), elites, parents, self.pop_size
         fit_all = torch.empty(self.pop_size, dtype=torch.float32, device=fit.device)
         dist.all_gather_into_tensor(fit_all, fit, group=self.group)
-        per_rank, cap, order = plan_exchange(fit_all, n_elite, n_keep, self.world)
+        elites, parents = self.select(fit_all)
+        cap = None if self.cap_mode == "exact" else self._cap_bound(elites.numel(), parents.numel())
+        per_rank, cap, elite_rows, parent_rows = plan_exchange(elites, parents, self.pop_size, self.world, cap)
         send = _pack(f, kept_rows(per_rank[self.rank], cap))
         table = torch.empty((self.world * cap, send.shape[1]), dtype=torch.uint8, device=send.device)
         dist.all_gather_into_tensor(table, send, group=self.group)
-        return _unpack(table, f.max_tree_len, f.input_len, f.output_len), order, self.pop_size
+        self.last_exchange = dict(mode="rows", cap=self.cap_mode, collectives=2, bytes_sent=fit.numel() * 4 + send.numel(), rows_sent=cap)
+        return _unpack(table, L, f.input_len, f.output_len), elite_rows, parent_rows, self.pop_size
 
     def step(self, local_fitness: torch.Tensor) -> Forest:
         assert local_fitness.shape == (self.n_local,)
-        table, order, pop = self.exchange(local_fitness)
+        table, elite_rows, parent_rows, pop = self.exchange(local_fitness)
         lo, hi = self.rank * self.n_local, (self.rank + 1) * self.n_local
         if local_fitness.is_cuda and self.descriptor.max_tree_len == table.max_tree_len \
                 and os.environ.get("EVOGP_NATIVE_STEP", "1") != "0":
-            self.forest = self.slice_native(table, order, pop, lo, hi)
+            self.forest = self.slice_native(table, elite_rows, parent_rows, pop, lo, hi)
         else:
-            self.forest = self.slice_torch(table, order, pop, lo, hi)
+            self.forest = self.slice_torch(table, elite_rows, parent_rows, pop, lo, hi)
         self.generation += 1
         return self.forest
 
-    def _order_of(self, full: Forest, fitness: torch.Tensor) -> torch.Tensor:
-        n_elite, n_surv = self.selection.counts(full.pop_size)
-        return select_order(fitness.to(torch.float32), n_elite, max(n_elite, n_surv, 1))
-
     def next_slice_native(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
         """rows [lo, hi) of the next generation from the WHOLE population and its fitness (tests, single-table use)"""
-        return self.slice_native(full, self._order_of(full, fitness), full.pop_size, lo, hi)
+        elites, parents = self.select(fitness.to(torch.float32))
+        return self.slice_native(full, elites, parents, full.pop_size, lo, hi)
 
     def next_slice_torch(self, full: Forest, fitness: torch.Tensor, lo: int, hi: int) -> Forest:
-        return self.slice_torch(full, self._order_of(full, fitness), full.pop_size, lo, hi)
+        elites, parents = self.select(fitness.to(torch.float32))
+        return self.slice_torch(full, elites, parents, full.pop_size, lo, hi)
 
-    def slice_native(self, table: Forest, order: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:
+    def slice_native(self, table: Forest, elite_rows: torch.Tensor, parent_rows: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:
         """Rows [lo, hi) of the next generation with the fused breeding pass (csrc/breed.hip).  ``table`` holds the trees
-        that can be parents or elites, ``order`` ranks them (table rows, best first), ``pop`` is the size of the WHOLE
-        population.  Every rank draws the SAME six random words per offspring and the same generation keys from its
-        generator, generates donors only for its own mutating offspring (tree index = global offspring index) and builds
-        only its own rows.  The union over the ranks is the single-device result for the same generator state."""
+        that can be parents or elites, ``elite_rows`` / ``parent_rows`` name them (table rows; parents may repeat), ``pop``
+        is the size of the WHOLE population.  Every rank computes the SAME six random words per offspring and the same
+        generation keys (counter-based), generates donors only for its own mutating offspring (tree index = global
+        offspring index) and builds only its own rows.  The union over the ranks is the single-device result."""
         full = table
-        dev = order.device
+        dev = parent_rows.device
         L = full.max_tree_len
-        n_elite, n_surv = self.selection.counts(pop)
+        n_elite = elite_rows.numel()
         n_new = pop - n_elite
         below = int(min(max(self.mutation_rate, 0.0), 1.0) * (2**31 - 1))
         d = self.descriptor
@@ -209,21 +301,20 @@ class ShardedGeneticProgramming:
             donors = torch.ops.evogp_hip.tree_generate_masked(
                 o_hi - o_lo, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
                 d.depth2leaf_probs, d.roulette_funcs, d.const_samples, o_lo, rnd[4, o_lo:o_hi].contiguous(), below)
-            # donors cover my offspring rows only; breed_default_rows skips the elite rows at the head of the range
+            # donors cover my offspring rows only; the breeding pass skips the elite rows at the head of the range
         else:  # a slice of elites only: donors are never read
             donors = (torch.empty((rows, L), dtype=torch.float32, device=dev), torch.empty((rows, L), dtype=torch.int16, device=dev),
                       torch.empty((rows, L), dtype=torch.int16, device=dev))
         value, ntype, size = full._tensors()
-        nv, nt, ns = torch.ops.evogp_hip.breed_default_rows(pop, L, n_elite, n_surv, value, ntype, size, order, rnd, below,
-                                                            *donors, lo, rows)
+        nv, nt, ns = torch.ops.evogp_hip.breed_rows(pop, L, value, ntype, size, elite_rows, parent_rows, rnd, below, *donors, lo, rows)
         return Forest(full.input_len, full.output_len, nv, nt, ns)
 
-    def slice_torch(self, table: Forest, order: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:
-        """The same slice composed from the reference's operators (any device)."""
+    def slice_torch(self, table: Forest, elite_rows: torch.Tensor, parent_rows: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:
+        """The same slice composed from the reference's operators (any device): genetic_programming.py:110-122."""
         full = table
-        dev = order.device
-        n_elite, n_surv = self.selection.counts(pop)
-        elite_idx, surv_idx = order[:n_elite], order[:n_surv]     # identical on every rank
+        dev = parent_rows.device
+        n_elite = elite_rows.numel()
+        elite_idx, surv_idx = elite_rows, parent_rows             # identical on every rank
         target = pop - n_elite
         parents = full[surv_idx.to(torch.int64)]
         sizes = parents.batch_subtree_size[:, 0].to(torch.int64)

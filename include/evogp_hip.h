@@ -144,6 +144,19 @@ int evogp_hip_breed_default_table(int pop_size, int table_rows, int gp_len, int 
                                   const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
                                   int *decisions, int row_begin, int row_count, evogp_stream_t stream);
 
+/* The same pass for ANY selection operator (src/evogp/algorithm/genetic_programming.py:110-122 with e.g.
+ * selection/tournament.py:59-133): the elites and the parents are two separate lists of table rows,
+ *     res[0 .. n_elite)  = table[elite_rows[0 .. n_elite)]
+ *     child_i            = crossover(table[parent_rows[r0 % n_surv]] at r2 % size, table[parent_rows[r1 % n_surv]] at r3 % size)
+ * parent_rows: i32[n_surv], repeats allowed (a tournament winner that won k times is k entries, exactly the
+ * `forest[survivor_indices]` gather of crossover/default.py:37; n_surv is not bounded by pop_size); elite_rows: i32[n_elite]
+ * (may be NULL when n_elite == 0).  evogp_hip_breed_default_table is this call with both lists = order. */
+int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
+                          const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
+                          const int *rnd, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                          const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
+                          int *decisions, int row_begin, int row_count, evogp_stream_t stream);
+
 /* Counter-based random words for the breeding pass of a sharded run (no counterpart in the reference, which draws with
  * torch's generator): out[k][i] for k < rows, i in [lo, hi) = hash(seed, generation, k, i) mapped to [0, 2^31 - 1), the value
  * evogp_amd/parallel.py random_words computes on any device; out: i32[rows][n_cols], only columns [lo, hi) are written.  Every

@@ -121,6 +121,27 @@ def breed_default(value, type_, size, order, rnd, mutate_below, n_elite, n_surv,
     return out, dec.cpu().numpy()
 
 
+def breed_lists(value, type_, size, elite_rows, parent_rows, rnd, mutate_below, dvalue, dtype_, dsize, pop=None, row_begin=0, row_count=None):
+    """evogp_hip_breed_lists: the breeding pass under any selection (separate elite / parent lists, parents may repeat)
+    -> ((value, type, size) of rows [row_begin, row_begin + row_count), decisions int32[row_count][6])"""
+    table_rows, gp_len = value.shape
+    pop = table_rows if pop is None else pop
+    row_count = pop if row_count is None else row_count
+    n_elite, n_surv = len(elite_rows), len(parent_rows)
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(elite_rows if n_elite else [0], np.int32),
+         dev(parent_rows, np.int32), dev(rnd, np.int32)]
+    d = [dev(dvalue, np.float32), dev(dtype_, np.int16), dev(dsize, np.int16)]     # row_count rows: row k belongs to row row_begin + k
+    v, t, s = _out3(row_count, gp_len)
+    dec = torch.full((row_count, 6), -9, dtype=torch.int32, device=DEV)
+    rc = L.evogp_hip_breed_lists(pop, table_rows, gp_len, n_elite, n_surv, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                 a[3].data_ptr() if n_elite else None, a[4].data_ptr(), a[5].data_ptr(), int(mutate_below), d[0].data_ptr(),
+                                 d[1].data_ptr(), d[2].data_ptr(), v.data_ptr(), t.data_ptr(), s.data_ptr(), dec.data_ptr(), row_begin,
+                                 row_count, _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    out = _np3(v, t, s)
+    return out, dec.cpu().numpy()
+
+
 def batch_argmax_count(value, type_, size, X, labels, out_len):
     pop, gp_len = value.shape
     a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32), dev(labels, np.int32)]

@@ -23,15 +23,18 @@ def oracle():
     return Oracle("port")
 
 
-def _expected(oracle, forest, order, rnd, below, n_elite, n_surv, donors):
-    """What the reference's operators produce for these draws."""
+def _expected(oracle, forest, order, rnd, below, n_elite, n_surv, donors, parents=None, pop=None):
+    """What the reference's operators produce for these draws (genetic_programming.py:110-122: elites = forest[elite indices],
+    parents drawn from forest[survivor indices] — a list that may repeat trees)."""
     v, t, s = forest
-    pop, L = v.shape
+    pop = v.shape[0] if pop is None else pop
+    L = v.shape[1]
     n_new = pop - n_elite
     sizes = s[:, 0].astype(np.int64)
     r = rnd.astype(np.int64)
-    li = order[r[0] % n_surv]
-    ri = order[r[1] % n_surv]
+    parents = order if parents is None else parents
+    li = parents[r[0] % n_surv]
+    ri = parents[r[1] % n_surv]
     p = (r[2] % sizes[li]).astype(np.int32)
     q = (r[3] % sizes[ri]).astype(np.int32)
     child = [a.copy() for a in oracle.crossover(v, t, s, li.astype(np.int32), ri.astype(np.int32), p, q)]
@@ -82,6 +85,37 @@ def test_breed_default_bit_exact(g, oracle, pop, L, mlc, dmlc, funcs, rate, elit
     got, dec = g.breed_default(*forest, order, rnd, below, n_elite, n_surv, *got_d)
     assert np.array_equal(dec, want_dec), "breed: decisions differ"
     assert_forest_equal(got, want, "breed_default")
+
+
+@pytest.mark.parametrize("pop,L,n_elite,n_surv,rate", [
+    (3000, 64, 30, 1500, 0.2),      # a tournament's survivor list: half the population, many repeats
+    (2000, 32, 0, 2600, 0.5),       # no elites, more parents than trees (drawn with replacement)
+    (1500, 128, 400, 7, 1.0),       # more elites than parents
+    (600, 50, 5, 300, 0.3),         # the one-row-per-wave kernel
+])
+def test_breed_lists_bit_exact(g, oracle, pop, L, n_elite, n_surv, rate):
+    """evogp_hip_breed_lists — the breeding pass under ANY selection operator (BASELINE configs[2]: tournament selection):
+    separate elite and parent lists, the parent list with repeats as selection/tournament.py:59-133 returns it; against the
+    oracle's crossover / mutate composed as genetic_programming.py:110-122 composes them, whole population and in slices."""
+    rng = np.random.default_rng(pop * 7 + L)
+    forest = oracle.generate(pop, L, 5, 1, 0.5, 0.5, [3, 4], depth2leaf(5), roulette_uniform(ARITH), [-1, 0, 1, 0.5])
+    n_new = pop - n_elite
+    elites = rng.permutation(pop)[:n_elite].astype(np.int32)          # any order, no repeats
+    parents = rng.integers(0, pop // 3, n_surv).astype(np.int32)      # repeats
+    rnd = rng.integers(0, 2**31 - 1, (6, n_new)).astype(np.int32)
+    below = int(rate * (2**31 - 1))
+    dargs = (n_new, L, 5, 1, 0.5, 0.5, [7, 9], depth2leaf(3), roulette_uniform(ARITH), [-1, 0, 1])
+    donors = oracle.generate(*dargs)
+    want, want_dec = _expected(oracle, forest, elites, rnd, below, n_elite, n_surv, donors, parents=parents)
+    pad = [np.concatenate([np.zeros((n_elite, L), a.dtype), a]) for a in donors]    # donor row k belongs to next-generation row k
+    got, dec = g.breed_lists(*forest, elites, parents, rnd, below, *pad)
+    assert np.array_equal(dec[n_elite:], want_dec), "breed_lists: decisions differ"
+    assert_forest_equal(got, want, "breed_lists")
+    # three ragged slices concatenate to the same rows
+    cuts = [0, pop // 3 + 1, pop // 3 + 2, pop]
+    parts = [g.breed_lists(*forest, elites, parents, rnd, below, *[a[lo:hi] for a in pad], pop=pop, row_begin=lo, row_count=hi - lo)[0]
+             for lo, hi in zip(cuts[:-1], cuts[1:])]
+    assert_forest_equal(tuple(np.concatenate([p[k] for p in parts]) for k in range(3)), want, "breed_lists in slices")
 
 
 def test_genetic_programming_default_step_uses_the_fused_path_and_stays_valid(g):
@@ -189,62 +223,111 @@ def test_rollout_problem_graph_replay_matches_eager(g):
         print(f"rollout {name}: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per step at pop 20000 (500 steps, capture included)")
 
 
-def test_sharded_native_step_union_equals_single_device(g):
-    """SURVEY.md §8e on one GPU: the rows the ranks of a G-way sharded run would build (same gathered population, same
-    generator state) concatenate to the single-device next generation, bit for bit, for G = 1, 2, 3, 8."""
+@pytest.mark.parametrize("selection", ["default", "more_elites_than_parents", "tournament_replace", "tournament_noreplace"])
+def test_sharded_native_step_union_equals_single_device(g, selection):
+    """SURVEY.md §8e on one GPU: the rows the ranks of a G-way sharded run would build (same gathered fitness, same seed)
+    concatenate to the single-device next generation, bit for bit, for G = 1, 2, 3, 8 — under DefaultSelection and under the
+    TournamentSelection BASELINE configs[2] names (selection/tournament.py:59-133; its survivor list repeats trees)."""
     import torch
 
     import evogp_amd  # noqa: F401
     from evogp_amd.algorithm import DefaultSelection
-    from evogp_amd.parallel import ShardedGeneticProgramming
+    from evogp_amd.algorithm.selection import TournamentSelection
+    from evogp_amd.parallel import ShardedGeneticProgramming, _pack, _unpack, kept_rows, plan_exchange
     from evogp_amd.tree import Forest, GenerateDescriptor
 
+    make = {"default": lambda: DefaultSelection(0.3, elite_rate=0.01),
+            "more_elites_than_parents": lambda: DefaultSelection(0.02, elite_cnt=500),
+            "tournament_replace": lambda: TournamentSelection(3, best_probability=0.9, replace=True, survivor_rate=0.5, elite_rate=0.01),
+            "tournament_noreplace": lambda: TournamentSelection(5, best_probability=1, replace=False, survivor_rate=0.8, elite_cnt=7)}[selection]
     dev = torch.device("cuda", 0)
     desc = GenerateDescriptor(max_tree_len=64, input_len=5, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5,
                               const_samples=[-1.0, 0.0, 1.0])
     pop = 4800
     full = Forest.random_generate(pop, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
     fitness = torch.randn(pop, device=dev)
+    fitness[::13] = float("-inf")
+
+    def same(got, ref, what):
+        for a, b in zip(got, ref):
+            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
+                               b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), what
 
     def run(G):
         parts = []
         for r in range(G):
-            sg = ShardedGeneticProgramming(full[:pop // G], 0.2, desc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=5)
+            sg = ShardedGeneticProgramming(full[:pop // G], 0.2, desc.update(max_layer_cnt=3), make(), seed=5)
             parts.append(sg.next_slice_native(full, fitness, r * (pop // G), (r + 1) * (pop // G)))
         return [torch.cat([getattr(p, n) for p in parts]) for n in ("batch_node_value", "batch_node_type", "batch_subtree_size")]
 
     ref = run(1)
     assert int(ref[2][:, 0].min()) >= 1
+    sg = ShardedGeneticProgramming(full, 0.2, desc.update(max_layer_cnt=3), make(), seed=5)
+    elites, parents = sg.select(fitness)
+    n_elite, n_surv = sg.selection.counts(pop)
+    assert elites.numel() == n_elite and parents.numel() == n_surv
+    # the elites are the best trees, copied verbatim to the first rows
+    best = torch.topk(fitness, max(n_elite, 1)).indices[:n_elite]
+    assert set(elites.tolist()) == set(best.tolist())
+    assert torch.equal(ref[0][:n_elite].view(torch.int32), full.batch_node_value[elites.long()].view(torch.int32))
+    if selection.startswith("tournament"):
+        assert parents.unique().numel() < n_surv                               # repeats: winners of several tournaments
+        pf = fitness[parents.long()]
+        assert float(pf[torch.isfinite(pf)].mean()) > float(fitness[torch.isfinite(fitness)].mean()) + 0.3   # selection pressure
     for G in (2, 3, 8):
-        got = run(G)
-        for a, b in zip(got, ref):
-            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
-                               b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), f"G = {G}"
-    # the exchange of a sharded run gathers only the trees that can be parents or elites: the slices built from that
-    # compact table (ranking expressed in table rows) are the same rows again
-    from evogp_amd.parallel import _pack, _unpack, kept_rows, plan_exchange
-
+        same(run(G), ref, f"G = {G}")
+    # the exchange of a sharded run gathers only the trees the two lists name: the slices built from that compact table
+    # (lists expressed in table rows; exact row count or the sync-free bound) are the same rows again
     for G in (2, 8):
         n_local = pop // G
-        sel = DefaultSelection(0.3, elite_rate=0.01)
-        n_elite, n_surv = sel.counts(pop)
-        n_keep = max(n_elite, n_surv)
-        per_rank, cap, order = plan_exchange(fitness, n_elite, n_keep, G)
-        assert cap < n_local
-        rows = [kept_rows(per_rank[r], cap) for r in range(G)]
-        table = _unpack(torch.cat([_pack(full[r * n_local:(r + 1) * n_local], rows[r]) for r in range(G)]), 64, 5, 1)
-        parts = []
-        for r in range(G):
-            sg = ShardedGeneticProgramming(full[:n_local], 0.2, desc.update(max_layer_cnt=3), sel, seed=5)
-            parts.append(sg.slice_native(table, order, pop, r * n_local, (r + 1) * n_local))
-        got = [torch.cat([getattr(p, n) for p in parts]) for n in ("batch_node_value", "batch_node_type", "batch_subtree_size")]
-        for a, b in zip(got, ref):
-            assert torch.equal(a.view(torch.uint8) if a.dtype != torch.float32 else a.view(torch.int32),
-                               b.view(torch.uint8) if b.dtype != torch.float32 else b.view(torch.int32)), f"compact table, G = {G}"
+        for cap_mode in ("exact", "bound"):
+            sg = ShardedGeneticProgramming(full[:n_local], 0.2, desc.update(max_layer_cnt=3), make(), seed=5, cap=cap_mode)
+            elites, parents = sg.select(fitness)
+            cap = None if cap_mode == "exact" else sg._cap_bound(elites.numel(), parents.numel())
+            per_rank, cap, elite_rows, parent_rows = plan_exchange(elites, parents, pop, G, cap)
+            assert cap <= n_local and int(per_rank.sum(1).max()) <= cap
+            rows = [kept_rows(per_rank[r], cap) for r in range(G)]
+            table = _unpack(torch.cat([_pack(full[r * n_local:(r + 1) * n_local], rows[r]) for r in range(G)]), 64, 5, 1)
+            parts = [sg.slice_native(table, elite_rows, parent_rows, pop, r * n_local, (r + 1) * n_local) for r in range(G)]
+            got = [torch.cat([getattr(p, n) for p in parts]) for n in ("batch_node_value", "batch_node_type", "batch_subtree_size")]
+            same(got, ref, f"compact table, G = {G}, cap {cap_mode}")
     # and the torch composition of the same step is a valid population of the same shape (different random words)
-    sg = ShardedGeneticProgramming(full, 0.2, desc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=5)
+    sg = ShardedGeneticProgramming(full, 0.2, desc.update(max_layer_cnt=3), make(), seed=5)
     nxt = sg.next_slice_torch(full, fitness, 0, pop)
-    assert nxt.pop_size == pop
+    assert nxt.pop_size == pop and int(nxt.batch_subtree_size[:, 0].min()) >= 1
+
+
+def test_genetic_programming_step_with_tournament_selection_takes_the_fused_path(g):
+    """GeneticProgramming.step with TournamentSelection + DefaultCrossover + DefaultMutation runs selection -> one breeding pass
+    (evogp_hip_breed_lists) and improves the population; the elites are copied verbatim"""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, GeneticProgramming
+    from evogp_amd.algorithm.selection import TournamentSelection
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=4, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5,
+                              const_samples=[-1, 0, 1])
+    pop = 6000
+    forest = Forest.random_generate(pop, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
+    sel = TournamentSelection(4, best_probability=0.95, replace=False, survivor_rate=0.5, elite_rate=0.005)
+    algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, desc.update(max_layer_cnt=3)), sel)
+    assert algo._native_default_ok()
+    X = torch.rand(256, 4, device=dev) * 4 - 2
+    y = (X[:, 0] * X[:, 1] - X[:, 2]).unsqueeze(1)
+    best = []
+    for _ in range(8):
+        fit = -algo.forest.SR_fitness(X, y)
+        fit[torch.isnan(fit)] = -torch.inf
+        best.append(float(fit.max()))
+        top = str(algo.forest[int(torch.argmax(fit))])
+        new = algo.step(fit)
+        assert top in {str(new[i]) for i in range(sel.counts(pop)[0])}
+        sizes = new.batch_subtree_size[:, 0]
+        assert int(sizes.min()) >= 1 and int(sizes.max()) <= 64
+    assert best[-1] > best[0]
 
 
 def test_select_survivors_equals_the_sets_of_a_stable_sort(g):
@@ -268,6 +351,8 @@ def test_select_survivors_equals_the_sets_of_a_stable_sort(g):
         q[torch.rand(n, generator=gen) < 0.01] = float("inf")
         cases.append((q, (0, 1, n // 100, n // 3)))
         cases.append((torch.zeros(n), (0, n // 2)))               # all equal
+        z = torch.zeros(n); z[::2] = -0.0; z[::7] = float("nan")    # -0 = +0 (ties by index), NaN behind them
+        cases.append((z, (0, n // 3)))
         cases.append((-torch.arange(n, dtype=torch.float32) * 1e-3 - 1e-40, (1,)))   # descending incl. denormal steps near zero
     for x, elites in cases:
         n = x.shape[0]
@@ -276,15 +361,13 @@ def test_select_survivors_equals_the_sets_of_a_stable_sort(g):
         nan = torch.isnan(x)
         by_value = torch.sort(torch.where(nan, torch.full_like(x, float("-inf")), x), descending=True, stable=True).indices
         rank = by_value[torch.sort(nan[by_value].to(torch.int8), stable=True).indices]
-        if not nan.any():
-            assert torch.equal(select_order(x, 3 if n > 3 else 0, n).long().sort().values, torch.arange(n))   # (the CPU definition: a permutation)
+        assert torch.equal(select_order(x, 3 if n > 3 else 0, n).long().sort().values, torch.arange(n))   # (the CPU definition: a permutation)
         for n_elite in elites:
             for n_keep in sorted({max(n_elite, 1), max(n_elite, n * 3 // 10, 1), n}):
                 got = torch.ops.evogp_hip.select_survivors(xd, n_elite, n_keep).cpu()
                 want = torch.cat([torch.sort(rank[:n_elite]).values, torch.sort(rank[n_elite:n_keep]).values]).to(torch.int32)
                 assert torch.equal(got, want), (n, n_elite, n_keep, int((got != want).sum()))
-                if not nan.any():
-                    assert torch.equal(select_order(x, n_elite, n_keep), want)   # the torch definition used off the GPU agrees
+                assert torch.equal(select_order(x, n_elite, n_keep), want)   # the torch definition used off the GPU agrees, NaN and -0 included
 
 
 def test_native_random_words_equal_the_python_definition(g):

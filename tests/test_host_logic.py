@@ -159,3 +159,38 @@ def test_tree_views_and_printing():
     assert t.SR_fitness(torch.tensor([[0., 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1]]), torch.tensor([[0.], [1], [1], [0]])).item() == 0.5
     assert t.forward(torch.tensor([1.0, 0.0, 3.0])).tolist() == [4.0]
     assert t.to_forest().pop_size == 1
+
+
+# ---- TournamentSelection against the reference's own operator (tests/golden/make_tournament_golden.py) ---------------------
+_TGOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("case", ["t3_p1", "t7_p08_replace", "t4_p09_noreplace", "t5_p05_many_passes"])
+def test_tournament_selection_replays_the_reference(case):
+    """The reference's TournamentSelection (selection/tournament.py:59-133) was run with its draws logged; fed the same
+    contenders and the same uniform numbers, ours must name the same survivors (repeats and order included) and elites."""
+    import json
+
+    from evogp_amd.algorithm.selection import TournamentSelection
+
+    g = np.load(os.path.join(_TGOLD, f"tournament_{case}.npz"))
+    meta = json.loads(bytes(g["meta"]).decode())
+    n, kw = meta["pop"], meta["kwargs"]
+    sel = TournamentSelection(**kw)
+    n_elite, n_surv = sel.counts(n)
+    assert n_elite == len(g["elites"]) and n_surv == len(g["survivors"])
+    per_pass, passes = sel.selector.passes(n, n_surv)
+    assert g["contenders"].shape == (passes, per_pass * kw["tournament_size"])       # the reference's pass structure, :117-121
+    fitness = torch.from_numpy(g["fitness"])
+    contenders = torch.from_numpy(g["contenders"]).reshape(-1, kw["tournament_size"])[:n_surv]
+    survivors = sel.selector.apply(fitness, contenders, torch.from_numpy(g["u"]))
+    assert survivors.dtype == torch.int32 and survivors.tolist() == g["survivors"].tolist()
+    elites, _ = sel(type("P", (), {"pop_size": n})(), fitness)
+    assert elites.tolist() == g["elites"].tolist()
+    # the operator's own draws have the reference's shape: every pass is a set of disjoint tournaments when replace=False
+    c, u = sel.selector.draw(n, n_surv, "cpu")
+    assert c.shape == (n_surv, kw["tournament_size"]) and int(c.min()) >= 0 and int(c.max()) < n
+    if not kw["replace"]:
+        for k in range(passes):
+            block = c[k * per_pass:(k + 1) * per_pass].reshape(-1)
+            assert block.unique().numel() == block.numel()

@@ -20,6 +20,21 @@ def _free_port():
     return p
 
 
+def _selection(name):
+    from evogp_amd.algorithm.selection import DefaultSelection, TournamentSelection
+
+    return {
+        "default": lambda: DefaultSelection(survival_rate=0.3, elite_rate=0.01),
+        "default_more_elites_than_parents": lambda: DefaultSelection(survival_rate=0.05, elite_cnt=70),   # legal, order[:n_surv] was wrong
+        "tournament_replace": lambda: TournamentSelection(3, best_probability=0.9, replace=True, survivor_rate=0.5, elite_rate=0.01),
+        "tournament_noreplace": lambda: TournamentSelection(4, best_probability=1, replace=False, survivor_rate=0.7, elite_cnt=3),
+    }[name]()
+
+
+SELECTIONS = ["default", "default_more_elites_than_parents", "tournament_replace", "tournament_noreplace"]
+MODES = [("rows", "exact"), ("rows", "bound"), ("packed", "exact")]
+
+
 def _run(rank, world, port, outdir):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -35,28 +50,44 @@ def _run(rank, world, port, outdir):
                               const_samples=[-1, 0, 1])
     n_local = POP // world
     keys = torch.tensor([42, 0], dtype=torch.int64)
-    local = Forest.random_generate(n_local, desc, keys=keys, tree_index_offset=rank * n_local)
     X = torch.tensor([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=torch.float32)
     y = (X.sum(1) % 2)[:, None]
-    gp = ShardedGeneticProgramming(local, 0.2, desc.update(max_layer_cnt=3), seed=123)
-    for _ in range(GENS):
-        fit = -gp.forest.SR_fitness(X, y)
-        fit[torch.isnan(fit)] = -torch.inf
-        gp.step(fit)
-    f = gp.forest
-    np.savez(os.path.join(outdir, f"w{world}_r{rank}.npz"), v=f.batch_node_value.numpy(), t=f.batch_node_type.numpy(),
-             s=f.batch_subtree_size.numpy())
+    for sel in SELECTIONS:
+        for exchange, cap in (MODES if world > 1 else MODES[:1]):
+            local = Forest.random_generate(n_local, desc, keys=keys, tree_index_offset=rank * n_local)
+            gp = ShardedGeneticProgramming(local, 0.2, desc.update(max_layer_cnt=3), selection=_selection(sel), seed=123,
+                                           exchange=exchange, cap=cap)
+            sent = []
+            for _ in range(GENS):
+                fit = -gp.forest.SR_fitness(X, y)
+                fit[torch.isnan(fit)] = -torch.inf
+                gp.step(fit)
+                sent.append(gp.last_exchange.get("bytes_sent", 0))
+            f = gp.forest
+            np.savez(os.path.join(outdir, f"w{world}_r{rank}_{sel}_{exchange}_{cap}.npz"), v=f.batch_node_value.numpy(),
+                     t=f.batch_node_type.numpy(), s=f.batch_subtree_size.numpy(), sent=np.array(sent),
+                     collectives=np.array(gp.last_exchange.get("collectives", 0)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank(tmp_path):
-    out = str(tmp_path)
+@pytest.fixture(scope="module")
+def runs(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("sharded"))
     mp.spawn(_run, args=(1, _free_port(), out), nprocs=1, join=True)  # separate process: leaves this one's state alone
     mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
-    one = np.load(os.path.join(out, "w1_r0.npz"))
-    parts = [np.load(os.path.join(out, f"w2_r{r}.npz")) for r in range(2)]
+    return out
+
+
+@pytest.mark.parametrize("sel", SELECTIONS)
+@pytest.mark.parametrize("exchange,cap", MODES)
+def test_two_ranks_equal_one_rank(runs, sel, exchange, cap):
+    """world 2 == world 1 for every selection operator (BASELINE configs[2]: tournament selection over the gathered fitness)
+    and every form of the exchange (two collectives with an exact or a sync-free row count; one packed collective)"""
+    out = runs
+    one = np.load(os.path.join(out, f"w1_r0_{sel}_rows_exact.npz"))
+    parts = [np.load(os.path.join(out, f"w2_r{r}_{sel}_{exchange}_{cap}.npz")) for r in range(2)]
     for k in ("v", "t", "s"):
         both = np.concatenate([p[k] for p in parts])
         a = one[k].view(np.uint32) if k == "v" else one[k]
@@ -66,6 +97,38 @@ def test_two_ranks_equal_one_rank(tmp_path):
     from oracle.pyoracle import Oracle
     o = Oracle("port")
     assert all(o.validate_tree(one["t"][i], one["s"][i]) == 0 for i in range(POP))
+    # what the step sent: one collective of the whole shard + its fitness, or two with at most the bound's rows
+    n_local = POP // 2
+    sent = parts[0]["sent"]
+    if exchange == "packed":
+        assert int(parts[0]["collectives"]) == 1 and (sent == n_local * (4 + 8 * L)).all()
+    else:
+        assert int(parts[0]["collectives"]) == 2 and (sent <= n_local * 4 + n_local * 8 * L).all()
+        if cap == "exact":
+            bound = np.load(os.path.join(out, f"w2_r0_{sel}_rows_bound.npz"))["sent"]
+            assert (sent <= bound).all()
+
+
+def test_selection_that_reads_the_trees_is_refused():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops
+    cpu_ops.register()
+    from evogp_amd.algorithm.selection import BaseSelection
+    from evogp_amd.parallel import ShardedGeneticProgramming
+    from evogp_amd.tree import Forest
+
+    class BySize(BaseSelection):
+        def __call__(self, forest, fitness):
+            return torch.empty(0, dtype=torch.int32), torch.argsort(forest.batch_subtree_size[:, 0])[:10]
+
+    f = Forest.zero_generate(20, 8, 2, 1)
+    if f.batch_node_value.is_cuda:
+        pytest.skip("host-logic test")
+    with pytest.raises(TypeError, match="BaseSelection"):
+        ShardedGeneticProgramming(f, 0.1, None, selection=lambda forest, fit: None)
+    gp = ShardedGeneticProgramming(f, 0.1, None, selection=BySize())
+    with pytest.raises(TypeError, match="cannot run in a sharded step"):
+        gp.select(torch.zeros(20))
 
 
 def test_pack_unpack_roundtrip():
@@ -84,7 +147,7 @@ def test_pack_unpack_roundtrip():
 
 
 def _roundtrip(Forest, GenerateDescriptor, set_default_device, _pack, _unpack):
-    from evogp_amd.parallel import kept_rows, plan_exchange, select_order
+    from evogp_amd.parallel import default_lists, kept_rows, plan_exchange, select_order
 
     set_default_device("cpu")
     desc = GenerateDescriptor(max_tree_len=L, input_len=3, output_len=2, using_funcs=["+", "*", "sin"], max_layer_cnt=4,
@@ -99,8 +162,10 @@ def _roundtrip(Forest, GenerateDescriptor, set_default_device, _pack, _unpack):
     fit = torch.randn(60)
     fit[7] = fit[31]  # a tie: the stable sort prefers the lower index on every rank
     world, n_elite, n_keep = 3, 4, 17
-    per_rank, cap, order = plan_exchange(fit, n_elite, n_keep, world)   # the sets by selection, table rows by index arithmetic
+    elites, parents = default_lists(fit, n_elite, n_keep)
+    per_rank, cap, elite_rows, order = plan_exchange(elites, parents, 60, world)   # the sets by selection, table rows by index arithmetic
     assert per_rank.shape == (3, 20) and int(per_rank.sum()) == n_keep and cap == int(per_rank.sum(1).max())
+    assert torch.equal(elite_rows, order[:n_elite])
     rows = [kept_rows(per_rank[r], cap) for r in range(world)]
     sends = [_pack(f[r * 20:(r + 1) * 20], rows[r]) for r in range(world)]
     table = _unpack(torch.cat(sends), L, 3, 2)
