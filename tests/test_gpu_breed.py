@@ -316,7 +316,7 @@ def test_genetic_programming_step_with_tournament_selection_takes_the_fused_path
     algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, desc.update(max_layer_cnt=3)), sel)
     assert algo._native_default_ok()
     X = torch.rand(256, 4, device=dev) * 4 - 2
-    y = (X[:, 0] * X[:, 1] - X[:, 2]).unsqueeze(1)
+    y = (X[:, 0] * X[:, 1] - X[:, 2] / (X[:, 3] * X[:, 3] + 1.5) + 0.5 * X[:, 0]).unsqueeze(1)    # not in generation 0
     best = []
     for _ in range(8):
         fit = -algo.forest.SR_fitness(X, y)
