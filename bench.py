@@ -95,9 +95,9 @@ def source_sha():
 def cpu_baseline(forest, X, y, device, budget_s=6.0):
     """The CPU oracle on this host: (a) a bounded sample of the headline workload (first S trees of rank 0's shard x all
     1024 datapoints, S sized from a probe for ~budget_s seconds); (b) BASELINE configs[0] exactly, beside the GPU."""
-    from oracle.pyoracle import Oracle, depth2leaf, roulette_uniform
+    from oracle.pyoracle import Oracle, depth2leaf, have_reference, roulette_uniform
 
-    o = Oracle("port")
+    o = Oracle("port", native=True)     # compiled -march=native on this box where a compiler exists (else the x86-64-v3 build)
     n = min(forest.pop_size, 1_000_000)
     v = forest.batch_node_value[:n].cpu().numpy(); t = forest.batch_node_type[:n].cpu().numpy(); s = forest.batch_subtree_size[:n].cpu().numpy()
     # warm-up (thread pool, page faults), then whole passes over the sample until ~budget_s seconds of wall time are spent
@@ -114,11 +114,32 @@ def cpu_baseline(forest, X, y, device, budget_s=6.0):
         "unit": "tree-evals/s",
         "cores": int(o.threads_used),
         "kind": "port",
-        "sample": f"first {sample} trees of the rank-0 shard x {X.shape[0]} datapoints, {reps} passes of {dt:.2f} s, plain-C oracle (-O3 -march=x86-64-v3, "
+        "sample": f"first {sample} trees of the rank-0 shard x {X.shape[0]} datapoints, {reps} passes of {dt:.2f} s, plain-C oracle ({o.flags}, "
                   f"IEEE fp32, no FMA contraction), OpenMP over trees: {int(o.threads_used)} threads on a host with "
                   f"{os.cpu_count()} logical cpus ({len(os.sched_getaffinity(0))} usable by this process)",
         "node_evals_per_s": float(s[:sample, 0].astype(np.int64).sum()) * X.shape[0] / dt,
     }
+    # one core: the port, and the REFERENCE's own device code compiled for the host (oracle/_ref, serial harness) on the same
+    # trees -- anchors "port ~ reference speed" (VERDICT r02 #6).  ~1 s each.
+    one = {}
+    k = 2000
+    try:
+        o.sr_fitness(v[:64], t[:64], s[:64], X, y, True, 1)
+        t0 = time.perf_counter(); o.sr_fitness(v[:k], t[:k], s[:k], X, y, True, 1); d1 = time.perf_counter() - t0
+        one["port_1core"] = {"value": k * X.shape[0] / d1, "unit": "tree-evals/s", "cores": 1, "kind": "port", "sample": f"first {k} trees x {X.shape[0]} datapoints, one pass of {d1:.2f} s"}
+        if have_reference():
+            r = Oracle("reference")
+            r.sr_fitness(v[:64], t[:64], s[:64], X, y, True)
+            t0 = time.perf_counter(); fr = r.sr_fitness(v[:k], t[:k], s[:k], X, y, True); d2 = time.perf_counter() - t0
+            fp = o.sr_fitness(v[:k], t[:k], s[:k], X, y, True, 1)
+            same = bool(np.array_equal(np.where(np.isnan(fr), 0, fr).view(np.uint32), np.where(np.isnan(fp), 0, fp).view(np.uint32)))
+            one["reference_1core"] = {"value": k * X.shape[0] / d2, "unit": "tree-evals/s", "cores": 1, "kind": "reference, 1 core",
+                                      "sample": f"the same {k} trees; the reference's forward.cu compiled for the host (hipcc --offload-host-only -O2, oracle/build_ref.py), "
+                                                f"one pass of {d2:.2f} s; its harness emulates the 1024-thread blocks serially (every 'thread' copies the tree, forward.cu:284-287)",
+                                      "fitness_bits_equal_port": same}
+    except Exception as exc:
+        one["error"] = repr(exc)[:200]
+    out.update(one)
     # configs[0]: XOR-3d SymbolicRegression, pop 5000, max_tree_len 32, 8 datapoints (README.md:130-175), CPU-runnable
     pop1 = 5000
     xs = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.float32)

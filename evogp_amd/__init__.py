@@ -24,3 +24,25 @@ def get_sr_division() -> str:
     from . import _lib
 
     return ("ieee", "fast", "short")[_lib.lib.evogp_hip_get_sr_division()]
+
+
+def set_program_buffer_limit(nbytes: int) -> None:
+    """Cap of the engine-owned program-record buffer of ``tree_SR_fitness`` (include/evogp_hip.h: size law, default 16 GiB).
+    A call that would need more runs on the register interpreters (same results, slower); 0 disables the compiled path."""
+    from . import _lib
+
+    _lib.check(_lib.lib.evogp_hip_set_program_buffer_limit(int(nbytes)), "set_program_buffer_limit")
+
+
+def program_buffer_bytes() -> int:
+    """bytes of program records the engine holds on the current device (not visible to torch's allocator)"""
+    from . import _lib
+
+    return int(_lib.lib.evogp_hip_program_buffer_bytes())
+
+
+def release_workspaces() -> None:
+    """Wait for the current device and free the engine-owned program-record buffer; the next fitness call allocates again."""
+    from . import _lib
+
+    _lib.check(_lib.lib.evogp_hip_release_workspaces(), "release_workspaces")

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "evogp_hip_evaluate_prepared": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "evogp_hip_random_words": [C.c_longlong, C.c_longlong, _i, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp],
     "evogp_hip_select": [_u, _u, _u, _vp, _vp, _vp, _vp],
+    "evogp_hip_set_program_buffer_limit": [C.c_ulonglong],
+    "evogp_hip_release_workspaces": [],
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
     "evogp_hip_debug_set_stats": [_vp],
@@ -66,6 +68,8 @@ def _load() -> C.CDLL:
     lib.evogp_hip_evaluate_workspace_bytes.restype = C.c_size_t
     lib.evogp_hip_select_workspace_bytes.argtypes = []
     lib.evogp_hip_select_workspace_bytes.restype = C.c_size_t
+    lib.evogp_hip_program_buffer_bytes.argtypes = []
+    lib.evogp_hip_program_buffer_bytes.restype = C.c_ulonglong
     lib.evogp_hip_error_string.argtypes = [_i]
     lib.evogp_hip_error_string.restype = C.c_char_p
     got = lib.evogp_hip_abi_version()

@@ -183,6 +183,26 @@ class InsertMutation(BaseMutation):
         return self.apply(forest, mask, p, keys, u)
 
 
+_warned_roulette = False
+
+
+def _warn_unnormalised_roulette(d: GenerateDescriptor) -> None:
+    """The reference searches the per-arity roulettes with u in [0, 1) although a class's entries only sum to the class's share
+    of the function probabilities (single_point.py:70-90): every draw above that share writes the invalid function id 29 (it
+    evaluates as 0 and has no name).  That behaviour is the default here because it is the reference's; say so once."""
+    global _warned_roulette
+    if _warned_roulette:
+        return
+    totals = [float(r[-1]) for r in (d.roulette_ufuncs, d.roulette_bfuncs, d.roulette_tfuncs)]
+    if any(0.0 < t < 1.0 - 1e-6 for t in totals):
+        import warnings
+
+        _warned_roulette = True
+        warnings.warn("point mutation with the reference's unnormalised per-arity roulettes (class totals "
+                      f"{[round(t, 3) for t in totals]}): draws above a class total write the invalid function id 29, as upstream does "
+                      "(single_point.py:70-90); pass fix_roulette=True to scale the draw by the class total instead", stacklevel=3)
+
+
 def _roulette_pick(roulette: torch.Tensor, u: torch.Tensor, fix: bool, fallback: torch.Tensor) -> torch.Tensor:
     """function id for a uniform draw: the reference's searchsorted on the class roulette (single_point.py:70-84), or with
     `fix` the draw scaled by the class total (then never the invalid id 29; a class without functions keeps the old id)"""
@@ -229,6 +249,8 @@ class MultiPointMutation(BaseMutation):
         self.modify_output = modify_output
         self.per_node = per_node
         self.fix_roulette = fix_roulette
+        if not fix_roulette:
+            _warn_unnormalised_roulette(descriptor)
 
     def _node_draws(self, forest: Forest):
         dev = forest.batch_node_value.device

@@ -85,41 +85,43 @@ int xcc_regions(hipStream_t stream) {
     return r;
 }
 
-constexpr int kCounterRing = 4096;
+// Zeroed four-word counter slots.  Every stream has a ring of its own: a slot that comes round again is reused on the stream
+// that used it last, so stream order alone puts the memset behind the slot's previous kernel -- no device-wide wait, nothing
+// held across a wait, legal inside a stream capture (the ring of a capturing stream must exist already: it is allocated by
+// the first call outside a capture).
+constexpr int kCounterRing = 256;
 struct CounterRing {
+    hipStream_t stream = nullptr;
     unsigned *base = nullptr;
-    std::atomic<unsigned> next{0};
-    hipStream_t last_user[kCounterRing] = {};  // a slot coming round again on ANOTHER stream is not ordered behind its last use
-    bool used[kCounterRing] = {};
+    unsigned next = 0;
 };
-static CounterRing g_ring[64];
+static std::vector<CounterRing> g_ring[64];
 
 unsigned *acquire_counter(hipStream_t stream, hipError_t *err) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) dev = 0;
-    CounterRing &r = g_ring[dev];
-    if (!r.base) {
-        std::lock_guard<std::mutex> lock(g_mu);
-        if (!r.base) {
-            unsigned *ptr = nullptr;
-            hipError_t e = hipMalloc((void **)&ptr, kCounterRing * 4 * sizeof(unsigned));
-            if (e != hipSuccess) { *err = e; return nullptr; }
-            r.base = ptr;
-        }
-    }
-    const unsigned idx = r.next.fetch_add(1) % kCounterRing;
-    unsigned *slot = r.base + 4 * idx;
+    unsigned *slot = nullptr;
     {
-        // 4096 acquisitions later the slot's previous kernel has long finished -- unless thousands of launches are queued.
-        // Same stream: stream order covers it.  Another stream: wait for the device once (cannot happen inside a capture:
-        // captured calls take their counters from the call's scratch block).
         std::lock_guard<std::mutex> lock(g_mu);
-        if (r.used[idx] && r.last_user[idx] != stream) (void)hipDeviceSynchronize();
-        r.used[idx] = true;
-        r.last_user[idx] = stream;
+        CounterRing *r = nullptr;
+        for (auto &c : g_ring[dev]) if (c.stream == stream) r = &c;
+        if (!r) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+                (void)hipGetLastError();
+                *err = hipErrorStreamCaptureUnsupported;   // call once on this stream before capturing
+                return nullptr;
+            }
+            unsigned *ptr = nullptr;
+            const hipError_t e = hipMalloc((void **)&ptr, kCounterRing * 4 * sizeof(unsigned));
+            if (e != hipSuccess) { *err = e; return nullptr; }
+            g_ring[dev].push_back(CounterRing{stream, ptr, 0});
+            r = &g_ring[dev].back();
+        }
+        slot = r->base + 4 * (r->next++ % kCounterRing);
     }
-    hipError_t e = hipMemsetAsync(slot, 0, 4 * sizeof(unsigned), stream);
+    const hipError_t e = hipMemsetAsync(slot, 0, 4 * sizeof(unsigned), stream);
     if (e != hipSuccess) { *err = e; return nullptr; }
     *err = hipSuccess;
     return slot;

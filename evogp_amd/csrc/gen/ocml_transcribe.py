@@ -31,6 +31,16 @@ PROBES = {
     "cosh": ("coshf(a[i])", 1),
 }
 
+# the sequences are compiler output of a third-party library: its notice travels with them
+NOTICE = """THIRD-PARTY NOTICE.  The instruction sequences below are compiler output of AMD's ROCm-Device-Libs (the OCML math library:
+powf, sinhf, coshf and the sequences the transcendental handlers of gen_tc_asm.py were transcribed from), distributed under
+the University of Illinois/NCSA Open Source License.  The licence text that ships with ROCm
+(/opt/rocm/share/doc/rocm-device-libs/LICENSE.TXT) is reproduced in gen/ROCM_DEVICE_LIBS_LICENSE.TXT next to this file:
+
+    Copyright (c) 2014-2016, Advanced Micro Devices, Inc.  All rights reserved.
+    Developed by: AMD Research and AMD HSA Software Development, Advanced Micro Devices, Inc., www.amd.com
+"""
+
 DROP = re.compile(r"^(s_load_|global_load_|global_store_|s_waitcnt|s_endpgm)")
 REG = re.compile(r"\b([vs])\[(\d+):(\d+)\]|\b([vs])(\d+)\b")
 
@@ -104,7 +114,7 @@ def transcribe(name, expr, nargs):
 def main():
     ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()[0]
     out = ['"""GENERATED by gen/ocml_transcribe.py -- the device math library\'s instruction sequences with registers as',
-           f'placeholders ({ver}).  Do not edit; re-run the script to refresh."""', "BODIES = {"]
+           f'placeholders ({ver}).  Do not edit; re-run the script to refresh.', '', NOTICE + '"""', "BODIES = {"]
     for name, (expr, nargs) in PROBES.items():
         b = transcribe(name, expr, nargs)
         out.append(f"    {name!r}: {{")

@@ -210,6 +210,20 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
                                 const void *workspace, int with_fallback,
                                 const float *variables, float *results, evogp_stream_t stream);
 
+/* Engine-owned device memory (no counterpart in the reference, whose kernels keep a private copy of the tree per thread,
+ * forward.cu:284-287).  evogp_hip_sr_fitness compiles every tree into PROGRAM RECORDS that its interpreter kernel reads: one
+ * buffer per device, allocated with hipMalloc on first use, grown on demand (never while a HIP graph is being captured),
+ * reused by every later call on that device and invisible to the caller's allocator.  Size law:
+ *     bytes = ceil(pop_size * 256 / 4096) * 4096 * max(2, ceil((gp_len + 2) / 31))    (+ 1/8 slack when it grows)
+ * i.e. 512 MB for 1 M trees of gp_len <= 64, 8.7 GB for 1 M trees of gp_len 1024.
+ *   evogp_hip_set_program_buffer_limit  caps the buffer (default 16 GiB): a call that would need more runs on the register
+ *                                       interpreters instead (same results, 3-6x slower); 0 disables the compiled path.
+ *   evogp_hip_program_buffer_bytes      bytes currently held on the current device.
+ *   evogp_hip_release_workspaces        waits for the current device and frees the buffer; the next fitness call allocates again. */
+int evogp_hip_set_program_buffer_limit(unsigned long long bytes);
+unsigned long long evogp_hip_program_buffer_bytes(void);
+int evogp_hip_release_workspaces(void);
+
 /* Average duration in milliseconds of the most recent `evogp_hip_*` launch sequence that was
  * bracketed by evogp_hip_timer_begin/_end on `stream` (hipEvent pair recorded on that stream).
  * Used by bench.py to time the kernel on the stream it is launched on. */

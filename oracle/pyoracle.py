@@ -34,6 +34,33 @@ def build_port(force: bool = False) -> str:
     return PORT_SO
 
 
+def _cpu_tag() -> str:
+    """identifies the host CPU (model + ISA flags): a -march=native build is only valid on the machine that made it"""
+    import hashlib
+
+    try:
+        lines = [ln for ln in open("/proc/cpuinfo") if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        lines = []
+    return hashlib.sha1("".join(lines).encode()).hexdigest()[:10]
+
+
+def build_port_native() -> str | None:
+    """The port compiled -O3 -march=native ON THIS HOST (the CPU baseline runs native code of the box it is timed
+    on; the default library is -march=x86-64-v3 because it is built in the dev container and travels).  The file name carries
+    the CPU's tag, so a library made elsewhere is never loaded.  None when no compiler is available."""
+    so = os.path.join(HERE, f"libevogp_oracle_native_{_cpu_tag()}.so")
+    src = os.path.join(HERE, "evogp_oracle.c")
+    if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
+        return so
+    cmd = ["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-shared", "-o", so, src, "-lm"]
+    try:
+        subprocess.run(cmd, check=True, capture_output=True, timeout=120)
+    except Exception:
+        return None
+    return so
+
+
 def have_reference() -> bool:
     return os.path.exists(REF_SO)
 
@@ -44,11 +71,15 @@ def _p(a, dt):
 
 
 class Oracle:
-    def __init__(self, kind: str = "port"):
+    def __init__(self, kind: str = "port", native: bool = False):
         assert kind in ("port", "reference")
         self.kind = kind
+        self.flags = "-O3 -march=x86-64-v3"
         if kind == "port":
-            self.lib = C.CDLL(build_port())
+            so = build_port_native() if native else None
+            if so is not None:
+                self.flags = "-O3 -march=native"
+            self.lib = C.CDLL(so or build_port())
             self.pfx = "evogp_oracle_"
         else:
             if not have_reference():

@@ -68,6 +68,39 @@ def random_crossover_indices(rng, sizes, n, invalid_frac=0.02):
     return li, ri, ln, rn
 
 
+def middle_child_roots(type_, size):
+    """bool[pop][L]: positions that are the root of the MIDDLE operand of a ternary node.  Replacing a subtree exactly there is
+    undefined in the reference: its ancestor walk (mutation.cu:66-82) reads ``subtree_size_stack[midTreeIndex]``, but only positions
+    below the replaced node were copied to that stack (:30-35), so with midTreeIndex == old_node_idx the walk continues from
+    whatever the uninitialised local memory holds (on the host build: sometimes an endless loop).  The oracle and the engine
+    compute the evidently intended result; comparisons against the compiled reference avoid these positions."""
+    type_, size = np.asarray(type_), np.asarray(size).astype(np.int64)
+    pop, L = type_.shape
+    live = np.arange(L)[None, :] < size[:, :1]
+    tern = ((type_ & 0x7F) == 4) & live
+    mask = np.zeros((pop, L), bool)
+    t, i = np.nonzero(tern)
+    first = i + 1
+    ok = first < L
+    t, first = t[ok], first[ok]
+    mid = first + size[t, first]
+    ok = mid < L
+    mask[t[ok], mid[ok]] = True
+    return mask
+
+
+def avoid_middle_child_roots(type_, size, trees, positions):
+    """positions with the undefined ones (see middle_child_roots) moved to the node in front of them (its left sibling's last node)"""
+    positions = np.asarray(positions).copy()
+    bad = middle_child_roots(type_, size)
+    tr = np.clip(np.asarray(trees), 0, np.asarray(type_).shape[0] - 1)
+    inside = (positions >= 0) & (positions < np.asarray(type_).shape[1])
+    hit = np.zeros(positions.shape, bool)
+    hit[inside] = bad[tr[inside], positions[inside]]
+    positions[hit] -= 1
+    return positions
+
+
 # ---- per-entry tolerance for trees of library functions (device OCML vs host libm) -----------------------------------
 def the_oracle():
     from oracle.pyoracle import Oracle

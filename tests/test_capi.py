@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for sym in declared_symbols():
         assert hasattr(lib, sym), f"libevogp_hip.so does not export {sym}"
-    assert set(_lib.PROTOTYPES) | {"evogp_hip_error_string", "evogp_hip_evaluate_workspace_bytes", "evogp_hip_select_workspace_bytes"} == set(declared_symbols())
+    assert set(_lib.PROTOTYPES) | {"evogp_hip_error_string", "evogp_hip_evaluate_workspace_bytes", "evogp_hip_select_workspace_bytes",
+                                  "evogp_hip_program_buffer_bytes"} == set(declared_symbols())
     assert lib.evogp_hip_abi_version() == _lib.ABI_VERSION
 
 
@@ -51,6 +52,12 @@ def test_error_strings_and_argument_errors_without_gpu():
     assert _lib.lib.evogp_hip_batch_argmax_count(4, 8, 32, 3, 1, None, None, None, None, None, None, None) == -1   # one output: no arg-max
     assert _lib.lib.evogp_hip_batch_argmax_count(4, 8, 32, 3, 2, None, None, None, None, None, None, None) == -2
     assert _lib.lib.evogp_hip_evaluate_prepare(4, 32, 3, 1, None, None, None, None, 0, None) == -1               # prepared lists are for multi-output forests
+    # the breeding pass with separate elite / parent lists
+    assert _lib.lib.evogp_hip_breed_lists(10, 10, 0, 1, 3, *([None] * 6), 0, *([None] * 7), 0, 10, None) == -1       # gp_len 0
+    assert _lib.lib.evogp_hip_breed_lists(10, 10, 8, 1, 0, *([None] * 6), 0, *([None] * 7), 0, 10, None) == -1       # no parent
+    assert _lib.lib.evogp_hip_breed_lists(10, 10, 8, 1, 30, *([None] * 6), 0, *([None] * 7), 0, 10, None) == -2      # null pointers (more parents than trees is legal)
+    # the engine-owned program-record buffer: nothing held before the first fitness call; the cap is a plain setter
+    assert _lib.lib.evogp_hip_set_program_buffer_limit(1 << 34) == 0
 
 
 def test_ops_are_registered_with_reference_schemas():

@@ -164,3 +164,38 @@ def test_sr_installation_scenario(torch_mod):
     prob.execute_mode = "torch"
     b = prob.evaluate(forest)
     assert_close_classes(a.cpu().numpy(), b.cpu().numpy(), 1e-4, what="kernel vs torch mode")
+
+
+def test_program_record_buffer_is_capped_and_released():
+    import torch
+
+    """the engine-owned program-record buffer of tree_SR_fitness (include/evogp_hip.h): its size follows the documented law, a cap
+    sends the call to the register interpreters with the same results, release frees it and the next call allocates again"""
+    import evogp_amd
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=4, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5, const_samples=[-1, 0, 1])
+    pop = 30_000
+    f = Forest.random_generate(pop, desc, keys=torch.tensor([3, 4], dtype=torch.uint32, device=dev))
+    X = torch.rand(512, 4, device=dev) * 4 - 2
+    y = (X[:, 0] - X[:, 1] * X[:, 2]).unsqueeze(1)
+    evogp_amd.release_workspaces()
+    assert evogp_amd.program_buffer_bytes() == 0
+    a = f.SR_fitness(X, y)
+    law = (pop * 256 + 4095) // 4096 * 4096 * 2
+    held = evogp_amd.program_buffer_bytes()
+    assert law <= held <= law + law // 8 + 8 * 256, (held, law)
+    evogp_amd.release_workspaces()
+    assert evogp_amd.program_buffer_bytes() == 0
+    try:
+        evogp_amd.set_program_buffer_limit(1 << 20)        # far below the law: the compiled path is not eligible
+        b = f.SR_fitness(X, y)
+        assert evogp_amd.program_buffer_bytes() == 0
+    finally:
+        evogp_amd.set_program_buffer_limit(16 << 30)
+    c = f.SR_fitness(X, y)
+    assert evogp_amd.program_buffer_bytes() == held
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32))
+    ok = torch.isfinite(a)
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.allclose(a[ok], b[ok], rtol=1e-5, atol=0)
