@@ -507,17 +507,15 @@ def main():
             extras["vis_ipynb_config"] = {"error": repr(exc)[:300]}
 
         # BASELINE configs[3]: the classifier of example/uci_classifier.py at its shape -- pop 200 000 multi-output trees, output_len 10,
-        # max_tree_len 128; 64 features x 1797 rows (the size of sklearn's digits; the example's UCI table needs the network) -- fitness =
-        # fused arg-max count (compiled programs + END_CLS handler), then the default generation step
+        # max_tree_len 128 -- on sklearn's digits (64 features x 1797 rows, 10 classes: the offline data set classification.py:35-48
+        # loads; the example's UCI table needs the network); fitness = fused arg-max count (compiled programs + END_CLS handler,
+        # equal to torch's argmax(clip(softmax)) count), then the default generation step
         try:
             from evogp_amd.problem import Classification
 
             cdesc = GenerateDescriptor(max_tree_len=128, input_len=64, output_len=10, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6,
                                        const_samples=[-1, 0, 1])
-            cg = torch.Generator().manual_seed(5)
-            cX = (torch.rand(1797, 64, generator=cg) * 16).to(device)
-            cy = torch.randint(0, 10, (1797,), generator=cg).to(torch.float32).to(device)
-            cprob = Classification(cX, cy)
+            cprob = Classification(dataset="digits")
             cpop = 200_000
             calgo = GeneticProgramming(Forest.random_generate(cpop, cdesc, keys=torch.tensor([7, 0], dtype=torch.uint32, device=device)),
                                        DefaultCrossover(), DefaultMutation(0.2, cdesc.update(max_layer_cnt=3)), DefaultSelection(0.3, elite_rate=0.01))
@@ -533,8 +531,9 @@ def main():
                 calgo.step(cprob.evaluate(calgo.forest))
                 torch.cuda.synchronize(); cms.append((time.perf_counter() - g0) * 1000)
             extras["configs3"] = {
-                "workload": "BASELINE configs[3] shape: classifier trees, pop 200k, output_len 10, max_tree_len 128, 64 features x 1797 rows (synthetic), "
-                            "accuracy fitness + default operators",
+                "workload": "BASELINE configs[3]: classifier trees, pop 200k, output_len 10, max_tree_len 128, Classification(dataset='digits') = "
+                            f"sklearn load_digits, {cprob.datapoints.shape[1]} features x {cprob.datapoints.shape[0]} rows, accuracy fitness + default operators",
+                "best_accuracy_after_6_generations": float(cprob.evaluate(calgo.forest).max()),
                 "fitness_ms": fit_ms, "tree_evals_per_s": cpop * 1797 / (fit_ms / 1e3), "generation_ms": {"median": float(np.median(cms[1:])), "first": cms[0]}}
             del calgo, cprob
         except Exception as exc:

@@ -1346,10 +1346,14 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_branch {lab('end_acc')}")
 
     # end of a classifier program: per row the arg-max over the out_len accumulators as torch.argmax(clip(softmax(x))) sees it
-    # -- the FIRST maximum; index 0 when any output is NaN or the maximum is infinite (the soft-max row is then NaN or 0/1 only) --
-    # compared with the row's label; v6 counts the hits (as a float: exact below 2^24 rows).  aux = K * out_len is in T2, the
-    # labels (int32 bits) in the T bank.  Row registers: maximum M in P0, sum in P1 (a NaN sum <=> a NaN output, or both
-    # infinities -- which the infinite maximum already covers), arg-max in Q.
+    # -- the FIRST maximum; index 0 when any output is NaN or the maximum is infinite (the soft-max row is then NaN) -- compared
+    # with the row's label; v6 counts the hits (as a float: exact below 2^24 rows).  aux = K * out_len is in T2, the labels
+    # (int32 bits) in the T bank.  Row registers: maximum M in P0 (made NaN when the row holds a NaN: a NaN sum <=> a NaN output,
+    # or both infinities -- which the infinite maximum already covers), the sum, then the tie threshold M - 2^-22 in P1, and in Q
+    # two 16-bit minima: low half = first index whose output EQUALS M (the arg-max), high half = first index whose output is
+    # >= the threshold.  high < low: an output in front of the maximum is so close to it that torch's fp32 soft-max may round both
+    # to the same float and return the earlier index (interp.hpp kSoftmaxTieMargin) -- such a row is AMBIGUOUS, and a tree with an
+    # ambiguous row leaves through the run-time bail-out: sr_wide.hip's recount kernel evaluates it with torch's own arithmetic.
     Mx, Sm, Bx = P[0], P[1], Q
     a(f"{lab('endcls_body')}:")
     a(f"s_mov_b32 m0, {hex(MODE['SRC0'] << 12)}")     # output 0
@@ -1357,7 +1361,6 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"v_mov_b32 v{Mx + k}, v{S0 + k}")
     for k in range(K):
         a(f"v_mov_b32 v{Sm + k}, v{Mx + k}")
-        a(f"v_mov_b32 v{Bx + k}, 0")
     a("s_mov_b32 m0, 0")
     a(f"s_mov_b32 s{sX}, {K}")                         # K * output index
     a(f"s_cmp_lt_u32 s{sX}, s{T2}")
@@ -1370,30 +1373,46 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_add_u32 s{sX}, s{sX}, {K}")
     a(f"s_cmp_lt_u32 s{sX}, s{T2}")
     a(f"s_cbranch_scc1 {lab('endcls_max')}")
-    # the first output that equals the maximum: from the last output down to output 1, a later hit overwritten by an earlier one
+    a(f"{lab('endcls_first')}:")
+    a("s_mov_b32 m0, 0")
+    for k in range(K):
+        a(f"v_cmp_u_f32 vcc, v{Sm + k}, v{Sm + k}")
+        a("s_nop 1")
+        a(f"v_cndmask_b32 v{Mx + k}, v{Mx + k}, v8, vcc")          # v8 = NaN
+        a(f"v_add_f32 v{Sm + k}, 0xb4800000, v{Mx + k}")           # threshold: M - 2^-22
+        a(f"v_mov_b32 v{Bx + k}, -1")
+    # every output, from the last down to output 0: index minima under the two compares (source 0 is M0-relative inside this loop,
+    # so the running minima cannot be source 0 of anything, and an SGPR operand plus VCC would be two constant-bus operands: the
+    # compares write EXEC and the packed minimum takes its constant from an SGPR)
     a(f"s_sub_u32 s{sX}, s{T2}, {K}")
     a(f"{lab('endcls_arg')}:")
     a(f"s_add_u32 m0, s{sX}, {hex(MODE['SRC0'] << 12)}")
     a(f"s_lshr_b32 s{T1}, s{sX}, {K.bit_length() - 1}")   # output index = sX / K (K is a power of two)
+    a(f"s_lshl_b32 s{sA}, s{T1}, 16")
+    a(f"s_or_b32 s{sA}, s{sA}, 0xffff")                   # {index, 0xffff}: lowers the high half only
+    a(f"s_or_b32 s{T4}, s{T1}, 0xffff0000")               # {0xffff, index}: lowers the low half only
     for k in range(K):
-        # (source 0 is M0-relative inside this loop, so the running arg-max cannot be a select's source there, and an SGPR index
-        # plus VCC would be two constant-bus operands: the compare writes EXEC instead and the index is moved under it)
+        a(f"v_cmpx_ge_f32 exec, v{S0 + k}, v{Sm + k}")
+        a(f"v_pk_min_u16 v{Bx + k}, s{sA}, v{Bx + k}")
         a(f"v_cmpx_eq_f32 exec, v{S0 + k}, v{Mx + k}")
-        a(f"v_mov_b32 v{Bx + k}, s{T1}")
+        a(f"v_pk_min_u16 v{Bx + k}, s{T4}, v{Bx + k}")
         a("s_mov_b64 exec, -1")
     a(f"s_sub_u32 s{sX}, s{sX}, {K}")
     a(f"s_cmp_ge_i32 s{sX}, 0")
     a(f"s_cbranch_scc1 {lab('endcls_arg')}")
-    a(f"{lab('endcls_first')}:")
     a("s_mov_b32 m0, 0")
-    a(f"s_movk_i32 s{T1}, 0x204")                      # -inf | +inf
+    a(f"s_mov_b64 s[{sA}:{sA + 1}], 0")                   # (sA, sX: free from here on)
+    a(f"s_movk_i32 s{T1}, 0x207")                        # NaN | -inf | +inf
     for k in range(K):
+        a(f"v_lshrrev_b32 v9, 16, v{Bx + k}")
+        a(f"v_and_b32 v{Bx + k}, 0xffff, v{Bx + k}")
+        a(f"v_cmp_lt_u32 vcc, v9, v{Bx + k}")
+        a(f"s_or_b64 s[{sA}:{sA + 1}], s[{sA}:{sA + 1}], vcc")
         a(f"v_cmp_class_f32_e64 vcc, v{Mx + k}, s{T1}")
         a("s_nop 1")
         a(f"v_cndmask_b32_e64 v{Bx + k}, v{Bx + k}, 0, vcc")
-        a(f"v_cmp_u_f32 vcc, v{Sm + k}, v{Sm + k}")
-        a("s_nop 1")
-        a(f"v_cndmask_b32_e64 v{Bx + k}, v{Bx + k}, 0, vcc")
+    a(f"s_cmp_lg_u64 s[{sA}:{sA + 1}], 0")
+    a(f"s_cbranch_scc1 {lab('bail')}")
     # hits: rows of this tile that exist (flags bit 1 / bit 4 as in END) and whose arg-max is their label
     a(f"s_add_u32 s{T1}, s{sTILE}, 1")
     a(f"s_cmp_lt_u32 s{T1}, s15")

@@ -40,6 +40,66 @@ template <> struct VecOf<32> { using type = v32f; };
 
 constexpr int kMaxOutRegs = 16; // multi-output accumulators kept in registers
 
+// ---- the Classification problem's prediction rule (src/evogp/problem/classification.py:62-67) --------------------------------
+//     pred = torch.argmax(torch.clip(torch.softmax(outputs, dim), 1e-15, 1 - 1e-15))
+// The arg-max of the soft-max is the arg-max of the raw outputs EXCEPT where two outputs are so close that their fp32 soft-max
+// values round to the same float: exp(x_i - max) is 1 or 1 - 2^-24 only for max - x_i below ~1e-7, and a quotient by the same
+// sum can then equal that of the maximum; torch.argmax returns the FIRST of equal values, i.e. possibly an index in front of
+// the true maximum.  A row is AMBIGUOUS when an output in front of the first maximum lies within kSoftmaxTieMargin (2^-22, a
+// safe superset) below it; the fast kernels take the raw arg-max and send trees with an ambiguous row to the recount kernel,
+// which evaluates torch's arithmetic itself:
+//   * aten's softmax_warp_forward (the kernel a row of <= 1024 fp32 elements gets): max over the row; e_i = std::exp(x_i - max)
+//     (the device library's expf); the sum by an xor-butterfly over next_pow2(n) lanes holding one element each (lanes past
+//     the row hold exp(-inf) = 0) -- every lane computes the same pairwise tree, halving the width level by level; e_i / sum
+//     with the correctly rounded division;
+//   * clip to [1e-15f, 1.0f] (1 - 1e-15 rounds to 1 in fp32); arg-max = first index of the largest value.
+// A NaN output or an infinite maximum makes the whole soft-max row NaN (inf - inf), whose arg-max is index 0.
+constexpr float kSoftmaxTieMargin = 2.384185791015625e-07f;  // 2^-22
+
+__device__ inline int argmax_raw(const float *x, int n, bool *ambiguous) {
+    int best = 0;
+    float m = x[0];
+    bool poisoned = m != m;
+    for (int o = 1; o < n; ++o) {
+        const float v = x[o];
+        poisoned |= v != v;
+        if (v > m) { m = v; best = o; }
+    }
+    if (poisoned || __builtin_isinf(m)) { *ambiguous = false; return 0; }
+    bool amb = false;
+    const float thr = m - kSoftmaxTieMargin;
+    for (int o = 0; o < best; ++o) amb |= x[o] >= thr;   // (x[o] < m for every o in front of the first maximum)
+    *ambiguous = amb;
+    return best;
+}
+
+__device__ inline int argmax_as_torch(const float *x, int n) {
+    float m = x[0];
+    bool poisoned = m != m;
+    for (int o = 1; o < n; ++o) {
+        poisoned |= x[o] != x[o];
+        m = m < x[o] ? x[o] : m;
+    }
+    if (poisoned || __builtin_isinf(m)) return 0;
+    float e[kMaxOutRegs];
+    int width = 1;
+    while (width < n) width <<= 1;
+    for (int o = 0; o < kMaxOutRegs; ++o) e[o] = o < n ? expf(x[o] - m) : 0.0f;
+    float part[kMaxOutRegs];
+    for (int o = 0; o < kMaxOutRegs; ++o) part[o] = e[o];
+    for (int off = width >> 1; off >= 1; off >>= 1)
+        for (int o = 0; o < off; ++o) part[o] = part[o] + part[o + off];
+    const float sum = part[0];
+    int best = 0;
+    float top = -1.0f;
+    for (int o = 0; o < n; ++o) {
+        float s = e[o] / sum;
+        s = s < 1e-15f ? 1e-15f : (s > 1.0f ? 1.0f : s);
+        if (s > top) { top = s; best = o; }
+    }
+    return best;
+}
+
 // Handler ids produced by the pre-decoder.  The six ids every default SR function set uses come
 // first so the scalar dispatch reaches them in three compares.
 enum : uint32_t {

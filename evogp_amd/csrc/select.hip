@@ -252,14 +252,16 @@ extern "C" int evogp_hip_select(unsigned n, unsigned n_elite, unsigned n_keep, c
     if (!fitness || !order || !zeroed_workspace) return EVOGP_E_NULLPTR;
     SelectParams p{fitness, order, (unsigned *)zeroed_workspace, (int)n, (int)n_elite, (int)n_keep};
     // The grid barrier needs every workgroup resident at once: never launch more than the occupancy calculator says fit
-    // (CU masks and partitioned modes shrink the chip), and ask the runtime for a cooperative launch, which fails instead of
-    // hanging when they would not.  EVOGP_SELECT_COOP=0: plain launch of the same clamped grid.
+    // (register growth, partitioned modes).  EVOGP_SELECT_COOP=1 additionally asks the runtime for a cooperative launch, which
+    // fails instead of hanging when the grid would not be co-resident (a CU mask the occupancy query does not see) -- opt-in,
+    // because hipLaunchCooperativeKernel costs 22 us per call on this stack (100 k values: 54 instead of 32 us; 1 M: 86 instead of
+    // 62; profiles/r03b_10_select_time.log), two thirds of the kernel itself.
     static const int per_cu = [] {
         int b = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, select_kernel, kSelThreads, 0) != hipSuccess) b = 0;
         return b;
     }();
-    static const bool coop = [] { const char *e = getenv("EVOGP_SELECT_COOP"); return !(e && e[0] == '0'); }();
+    static const bool coop = [] { const char *e = getenv("EVOGP_SELECT_COOP"); return e && e[0] == '1'; }();
     if (per_cu < 1) return EVOGP_E_UNSUPPORTED;
     int blocks = device_info().num_cus;
     if (blocks > kSelMaxBlocks) blocks = kSelMaxBlocks;

@@ -43,7 +43,8 @@ struct WideParams {
 constexpr int kWideWaves = 8;
 struct __attribute__((packed, aligned(4))) Unaligned4 { float x, y, z, w; };  // 16-byte store at 4-byte alignment
 
-// MODE 1 follow-up: trees marked deep are counted with the scratch-stack interpreter, one wave per tree, lanes over rows
+// MODE 1 follow-up: trees marked deep -- and trees with a row whose arg-max hangs on the soft-max's rounding (interp.hpp) -- are
+// counted with the scratch-stack interpreter, one wave per tree, lanes over rows, with torch's own arithmetic for the arg-max
 __global__ __launch_bounds__(64) void wide_deep_count_kernel(WideParams p) {
     if (p.marks && p.marks[1] == 0u) return;
     const int lane = threadIdx.x;
@@ -58,15 +59,7 @@ __global__ __launch_bounds__(64) void wide_deep_count_kernel(WideParams p) {
         for (int d0 = 0; d0 < p.D; d0 += 64) {
             const int d = d0 + lane, dc = d < p.D ? d : p.D - 1;
             (void)run_general<true>(p.type + row, p.value + row, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, o16, stk);
-            int best = 0;
-            float m = o16[0];
-            bool poisoned = m != m;
-            for (int o = 1; o < p.out_len; ++o) {
-                const float x = o16[o];
-                poisoned |= x != x;
-                if (x > m) { m = x; best = o; }
-            }
-            if (poisoned || __builtin_isinf(m)) best = 0;
+            const int best = argmax_as_torch(o16, p.out_len);
             hits += (unsigned)__popcll(__ballot(d < p.D && best == p.labels[dc]));
         }
         if (lane == 0) p.counts[t] = hits;
@@ -181,8 +174,10 @@ __global__ __launch_bounds__(kWideWaves * 64) __attribute__((amdgpu_waves_per_eu
             }
             __builtin_amdgcn_wave_barrier();  // the block is rewritten for the wave's next tree
         } else {
-            // arg-max as torch.argmax(clip(softmax(x))) sees it
+            // arg-max as torch.argmax(clip(softmax(x))) sees it: the raw arg-max, except in rows where an output in front of the
+            // first maximum is within the soft-max's rounding of it -- a tree with such a row is recounted with torch's arithmetic
             unsigned hits = 0;
+            bool any_amb = false;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 int best = 0;
@@ -196,10 +191,19 @@ __global__ __launch_bounds__(kWideWaves * 64) __attribute__((amdgpu_waves_per_eu
                         if (x > m) { m = x; best = o; }
                     }
                 }
-                if (poisoned || __builtin_isinf(m)) best = 0;
+                const bool forced = poisoned || __builtin_isinf(m);
+                const float thr = m - kSoftmaxTieMargin;
+                bool amb = false;
+#pragma unroll
+                for (int o = 0; o < kMaxOutRegs; ++o)
+                    if (o < p.out_len) amb |= o < best && outs[k][o] >= thr;
+                any_amb |= amb && !forced && d0 + k < p.D;
+                if (forced) best = 0;
                 hits += (unsigned)__popcll(__ballot(d0 + k < p.D && best == label[k]));
             }
-            if (lane == 0 && hits) atomicAdd(p.counts + t, hits);
+            if (__ballot(any_amb) != 0ull) {   // (wave-uniform: the recount kernel overwrites whatever the groups add)
+                if (lane == 0) { atomicOr(p.counts + t, kDeepCountBit); if (p.marks) p.marks[1] = 1u; }
+            } else if (lane == 0 && hits) atomicAdd(p.counts + t, hits);
         }
     }
 }

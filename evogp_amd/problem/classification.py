@@ -63,12 +63,12 @@ class Classification(BaseProblem):
         if (self.multi_output and self.datapoints.is_cuda and 2 <= forest.output_len <= 16
                 and forest.input_len * 256 <= 150 * 1024 and os.environ.get("EVOGP_FUSED_ACCURACY", "1") != "0"
                 and self._int_labels() is not None):
-            # fused epilogue: only the per-tree count of correct rows leaves the kernel (csrc/sr_wide.hip).  The kernel compares
-            # the raw arg-max with an int32 label: only taken for integral labels (a label like 1.5 never equals a prediction
-            # in the reference's `pred == labels`, classification.py:62-75; a truncating cast would make it class 1).  One
-            # difference remains and is accepted: the reference takes argmax(clip(softmax(.))), which returns the FIRST of two
-            # outputs whose soft-max values round to the same float (outputs closer than ~6e-8 relative); the kernel
-            # returns the larger raw output.
+            # fused epilogue: only the per-tree count of correct rows leaves the kernel (csrc/sr_tc.hip END_CLS, csrc/sr_wide.hip).
+            # The kernel compares the arg-max with an int32 label: only taken for integral labels (a label like 1.5 never equals
+            # a prediction in the reference's `pred == labels`, classification.py:62-75; a truncating cast would make it class 1).
+            # The count EQUALS the reference's: argmax(clip(softmax(.))) is the raw arg-max except where an output in front of the
+            # maximum is within ~1e-7 of it (their fp32 soft-max values may round to the same float, and torch returns the first);
+            # trees with such a row are recounted with aten's soft-max arithmetic (csrc/interp.hpp argmax_as_torch).
             counts = torch.ops.evogp_hip.tree_batch_argmax_count(
                 forest.pop_size, D, forest.max_tree_len, forest.input_len, forest.output_len, *forest._tensors(),
                 self.datapoints.contiguous().to(torch.float32), self._int_labels())

@@ -215,7 +215,7 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
  * buffer per device, allocated with hipMalloc on first use, grown on demand (never while a HIP graph is being captured),
  * reused by every later call on that device and invisible to the caller's allocator.  Size law:
  *     bytes = ceil(pop_size * 256 / 4096) * 4096 * max(2, ceil((gp_len + 2) / 31))    (+ 1/8 slack when it grows)
- * i.e. 512 MB for 1 M trees of gp_len <= 64, 8.7 GB for 1 M trees of gp_len 1024.
+ * i.e. 768 MB for 1 M trees of gp_len 64 (three arrays of records; two up to gp_len 60), 8.7 GB for 1 M trees of gp_len 1024.
  *   evogp_hip_set_program_buffer_limit  caps the buffer (default 16 GiB): a call that would need more runs on the register
  *                                       interpreters instead (same results, 3-6x slower); 0 disables the compiled path.
  *   evogp_hip_program_buffer_bytes      bytes currently held on the current device.

@@ -261,7 +261,9 @@ static inline void jitter_begin(long tree) { t_jitter_state = g_jitter_seed ^ ((
 static inline float jit(float r) {
     if (g_jitter_ulps == 0 || !isfinite(r) || r == 0.0f) return r;
     t_jitter_state = t_jitter_state * 1664525u + 1013904223u;
-    const int k = (int)((t_jitter_state >> 8) % (uint32_t)(2 * g_jitter_ulps + 1)) - g_jitter_ulps;
+    int k = (int)((t_jitter_state >> 8) % (uint32_t)(2 * g_jitter_ulps + 1)) - g_jitter_ulps;
+    if (g_jitter_seed == 0xFFFFFFFFu) k = g_jitter_ulps;   /* systematic probes: every result +J ulps / -J ulps (a tree whose */
+    if (g_jitter_seed == 0xFFFFFFFEu) k = -g_jitter_ulps;  /* value hangs on ONE library call is otherwise a lottery)         */
     uint32_t b = float_to_bits(r);
     const uint32_t mag = (b & 0x7FFFFFFFu) + (uint32_t)k; /* sign-magnitude: +k ulps away from zero */
     if (mag == 0u || mag >= 0x7F800000u) return r;

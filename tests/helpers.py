@@ -118,8 +118,10 @@ def sensitivity(oracle, fn, base_rtol=1e-5, ulps=3, seeds=4):
     spread = np.zeros(want.shape, dtype=np.float64)
     unstable = np.zeros(want.shape, bool)
     try:
-        for seed in range(seeds):
-            oracle.set_jitter(ulps, 1000 + seed)
+        # random signs per call, plus the two systematic probes (every library result +ulps / -ulps): an entry that hangs on ONE
+        # call (a single huge row under pow) would otherwise depend on the luck of four draws
+        for seed in [1000 + i for i in range(seeds)] + [0xFFFFFFFF, 0xFFFFFFFE]:
+            oracle.set_jitter(ulps, seed)
             j = fn()
             with np.errstate(all="ignore"):
                 spread = np.maximum(spread, np.nan_to_num(np.abs(j.astype(np.float64) - want), nan=0.0, posinf=0.0))
@@ -152,3 +154,19 @@ def assert_within_sensitivity(got, want, tol, unstable, name, max_unstable=0.1, 
 
 def per_tree_tolerance(oracle, forest, X, y, base_rtol=1e-5, ulps=3, seeds=4, use_mse=True):
     return sensitivity(oracle, lambda: oracle.sr_fitness(*forest, X, y, use_mse), base_rtol, ulps, seeds)
+
+
+# ---- the Classification problem's prediction rule, computed by torch ON THE DEVICE (the reference runs it there) ------------------
+def torch_rule_counts(outs_np, labels, block=256):
+    """counts[t] = #rows whose torch.argmax(torch.clip(torch.softmax(outs[t]), 1e-15, 1 - 1e-15)) equals the label
+    (src/evogp/problem/classification.py:62-67), with torch's own kernels on cuda:0 — the definition the fused count must meet
+    with EQUALITY (near-ties between soft-max probabilities included)."""
+    import torch
+
+    lab = torch.from_numpy(np.asarray(labels).astype(np.int64)).cuda()
+    out = []
+    for i in range(0, outs_np.shape[0], block):
+        o = torch.from_numpy(np.ascontiguousarray(outs_np[i:i + block])).cuda()
+        pred = torch.argmax(torch.clip(torch.softmax(o, dim=2), 1e-15, 1 - 1e-15), dim=2)
+        out.append((pred == lab[None, :]).sum(1).cpu())
+    return torch.cat(out).numpy()
