@@ -293,17 +293,33 @@ def main():
         clock_hz = float(getattr(props, "clock_rate", 2_400_000)) * 1e3
         cus = props.multi_processor_count
         peak = cus * 4 * clock_hz / 4.0                           # 4 SIMDs per CU, one 64-lane VALU instruction per 4 clocks each
+        peak_spec = cus * 4 * clock_hz / 2.0                      # MI355X_MICROARCH.md: a SIMD issues a VALU instruction over 2 cycles (157.3 TFLOP/s fp32 vector / 128)
         kernel_s = stage_ms["interpreter"] / 1e3
         top = sorted(((int(w), names[i]) for i, w in enumerate(words) if w), reverse=True)[:8]
+        # the SQ counters of the committed PMC run (same sources): how busy the pipe really is
+        pipe_busy = clk_per_inst = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if pj.get("source_sha") == source_sha() and pj.get("pop_per_launch") == pop:
+                c = pj["kernels"]["sr_tc_kernel"]["per_launch"]
+                pipe_busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cus * 4) / (kernel_s * clock_hz)
+                clk_per_inst = c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"]
+        except Exception:
+            pass
         valu = {
             "frac": wave_insts / kernel_s / peak if kernel_s > 0 else None,
-            "valu_insts_per_launch": wave_insts, "peak_insts_per_s": peak, "cus": cus, "clock_hz": clock_hz,
+            "frac_of_spec": wave_insts / kernel_s / peak_spec if kernel_s > 0 else None,
+            "valu_pipe_busy": pipe_busy, "clocks_per_valu_inst": clk_per_inst,
+            "valu_per_row_per_word": wave_insts / (float(words.sum()) * tiles * info["K"]) if words.sum() else None,
+            "valu_insts_per_launch": wave_insts, "peak_insts_per_s": peak, "peak_insts_per_s_spec": peak_spec, "cus": cus, "clock_hz": clock_hz,
             "program_words": int(words.sum()), "words_per_tree": float(words.sum()) / pop, "passes_per_tree": tiles,
             "top_handlers": [f"{n}:{w}" for w, n in top],
             "what": "sum over program words of the handler's VALU instruction count (evogp_amd/lib/tc_handlers.json, from the generator) "
-                    "x datapoint tiles, / interpreter launch time, / (CUs x 4 SIMDs x clock / 4): the share of the one-instruction-per-4-clocks "
-                    "VALU issue rate the interpreter's arithmetic uses; transcendental and 3-source instructions take longer than 4 clocks, "
-                    "so the pipe is busier than this fraction says",
+                    "x datapoint tiles, / interpreter launch time.  frac: against one instruction per 4 clocks and SIMD (the rate the VOP3 / 3-source / "
+                    "SGPR-source class runs at: scripts/ubench/valu_rates.hip measures 4.1 clocks); frac_of_spec: against the chip's issue rate, one per 2 "
+                    "clocks (157.3 TFLOP/s fp32 vector).  valu_pipe_busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / kernel clocks and clocks_per_valu_inst = "
+                    "SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU from the PMC run of the same sources (profiles/pmc_latest.json; null when it is of other "
+                    "sources): the pipe is nearly full of slow-class instructions, so the lever is their number and class, not latency",
         }
     except Exception as exc:
         valu = {"frac": None, "error": repr(exc)[:300]}
@@ -318,13 +334,14 @@ def main():
         kernel_s = stage_ms["interpreter"] / 1e3 if stage_ms["calls"] else call_ms / 1e3
         alg_bytes = 6.0 * total_nodes + 2.0 * pop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * pop  # SURVEY.md §8d, this rank's launch
         achieved = alg_bytes / kernel_s / 1e9
-        traffic, traffic_note = None, "no PMC record for this build"
+        traffic, traffic_call, traffic_note = None, None, "no PMC record for this build"
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 if pj.get("source_sha") == source_sha() and pj.get("pop_per_launch") == pop:
                     traffic = pj.get("sr_tc_kernel_hbm_bytes_per_launch")
+                    traffic_call = pj.get("call_hbm_bytes")
                     traffic_note = f"FETCH_SIZE + WRITE_SIZE of the interpreter kernel, rocprofv3 --pmc, measured on this source ({pj.get('source_sha')}): {pj.get('files')}"
                 else:
                     traffic_note = (f"profiles/pmc_latest.json was measured on source {pj.get('source_sha')} / {pj.get('pop_per_launch')} trees per launch, "
@@ -354,7 +371,7 @@ def main():
             "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_note": traffic_note,
+                "traffic": traffic, "traffic_call": traffic_call, "traffic_note": traffic_note,
                 "kernel": "sr_tc_kernel<8,false,2> (threaded-code interpreter, short division), rank 0's launch; algorithmic bytes = SURVEY.md §8d "
                           "(6 B per live node + size + dataset + fitness) x the trees of the launch",
                 "kernel_ms": kernel_s * 1e3, "algorithmic_bytes": alg_bytes,
@@ -456,6 +473,25 @@ def main():
                     "selection names; packed: ONE all-gather of {fitness|value|type|size} per tree, then selection) + breeding pass for the local "
                     "rows, max over ranks, barriers on both sides; DefaultMutation(0.2); last_exchange.bytes_sent = bytes this rank contributes"}
 
+        # What strong scaling can give at best: the fitness pass on the shards N = 8, 4, 2 ranks would own, timed on THIS GPU.  The
+        # first SCALE record can be checked against it (a rank cannot be faster than its shard alone).
+        if world == 1 and P >= 8:
+            sm_trees, sm_ms = [], []
+            for nshard in (8, 4, 2, 1):
+                n_s = P // nshard
+                fs = forest if nshard == 1 else Forest(forest.input_len, forest.output_len, forest.batch_node_value[:n_s], forest.batch_node_type[:n_s],
+                                                       forest.batch_subtree_size[:n_s])
+                for _ in range(3):
+                    fs.SR_fitness(Xd, yd, True, "auto")
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(20):
+                    fs.SR_fitness(Xd, yd, True, "auto")
+                torch.cuda.synchronize()
+                sm_trees.append(n_s); sm_ms.append((time.perf_counter() - t0) / 20 * 1e3)
+            extras["shard_model"] = {"trees": sm_trees, "ms": sm_ms, "efficiency_vs_linear": [sm_ms[-1] * t / P / m for t, m in zip(sm_trees, sm_ms)],
+                                     "what": "tree_SR_fitness on the first P/8, P/4, P/2, P trees of the headline population on one GPU: the per-rank time "
+                                             "an N-rank strong-scaling run cannot beat; efficiency = (time of P trees x share) / time of the shard"}
+
         # BASELINE configs[1]: 100k trees per GPU (weak), same protocol
         pop1 = args.pop_per_gpu
         forest1, _, _, _, _ = sr_inputs(rank * pop1, pop1, device)
@@ -479,6 +515,43 @@ def main():
             "generation_ms": {"median": float(np.median(gen_ms[1:])), "first": gen_ms[0],
                               "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
         }
+
+    if not args.headline_only:
+        # BASELINE configs[4] (example/brax_task.py:19-32 shape: policy trees pop 50 000, 17 observations, 6 actions, max_tree_len 256,
+        # 1000 steps per generation) across the ranks: every rank rolls out its own 50 000 / N trees (HIP-graph replay of one step: the
+        # prepared forward pass + the environment's kernels; no collective inside the episode), then the sharded generation step.  Brax
+        # is not in this image: the environment is the batched linear system of evogp_amd/problem/rollout.py (per-tree episodes
+        # keyed by the global tree index).
+        try:
+            from evogp_amd.problem import RolloutProblem
+            from evogp_amd.problem.rollout import LinearTrackingEnv
+
+            c5_pop, c5_steps = 50_000, 1000
+            n5 = c5_pop // world
+            pdesc = GenerateDescriptor(max_tree_len=256, input_len=17, output_len=6, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6,
+                                       const_samples=torch.linspace(-1, 1, 100).tolist())
+            pf = Forest.random_generate(n5, pdesc, keys=torch.tensor([7, 0], dtype=torch.uint32, device=device), tree_index_offset=rank * n5)
+            prob5 = RolloutProblem(LinearTrackingEnv(device=device, randomize=0.1), c5_steps, use_graph=True)
+            sg5 = ShardedGeneticProgramming(pf, 0.2, pdesc.update(max_layer_cnt=3), DefaultSelection(0.3, elite_rate=0.01), seed=99)
+            roll_ms, gen5_ms = [], []
+            for _ in range(3):
+                barrier(); g0 = time.perf_counter()
+                fit5 = prob5.evaluate(sg5.forest, tree_index_offset=rank * n5)
+                barrier(); g1 = time.perf_counter()
+                sg5.step(fit5)
+                barrier(); g2 = time.perf_counter()
+                roll_ms.append(max_over_ranks((g1 - g0) * 1e3)); gen5_ms.append(max_over_ranks((g2 - g0) * 1e3))
+            extras["c5_rollout"] = {
+                "workload": f"BASELINE configs[4] shape: policy trees pop {c5_pop} over {world} rank(s) ({n5} per rank), 17 observations, 6 actions, "
+                            f"max_tree_len 256, {c5_steps} steps per generation; batched linear stand-in environment (no Brax in this image)",
+                "rollout_ms": float(np.median(roll_ms[1:])), "us_per_step": float(np.median(roll_ms[1:])) * 1e3 / c5_steps,
+                "policy_steps_per_s": c5_pop * c5_steps / (float(np.median(roll_ms[1:])) / 1e3),
+                "generation_ms": float(np.median(gen5_ms[1:])), "first_rollout_ms": roll_ms[0],
+                "what": "rollout = prepare the forest's operation lists + capture one step + 1000 graph replays (max over ranks); generation = "
+                        "rollout + sharded step (fitness all-gather, selection, row exchange, breeding)"}
+            del sg5, prob5, pf
+        except Exception as exc:
+            extras["c5_rollout"] = {"error": repr(exc)[:300]}
 
     if not args.headline_only and rank == 0:
         # the reference's only published timing: test/vis.ipynb:12-45,171,181 -- XOR-3d, pop 100 000, max_tree_len 128, 8 datapoints,

@@ -31,6 +31,8 @@ PROTOTYPES = {
     "evogp_hip_breed_default_rows": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_breed_default_table": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_breed_lists": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "evogp_hip_breed_lists_compiled": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "evogp_hip_sr_fitness_stamped": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_ulonglong, _vp],
     "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_batch_argmax_count": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_evaluate_prepare": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_size_t, _vp],

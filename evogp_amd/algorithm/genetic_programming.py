@@ -117,6 +117,7 @@ class GeneticProgramming:
         donors = torch.ops.evogp_hip.tree_generate_masked(
             n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
             d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, rnd[4], below)
-        nv, nt, ns = torch.ops.evogp_hip.breed_rows(pop, L, value, ntype, size, elites, parents, rnd, below, *donors, 0, pop)
-        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns)
+        # (the pass also compiles the rows it builds for the next tree_SR_fitness call where the engine can: csrc/sr_tc.hip)
+        nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_compiled(pop, L, value, ntype, size, elites, parents, rnd, below, *donors, 0, pop)
+        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns).set_compiled_records(stamp)
         return self.forest

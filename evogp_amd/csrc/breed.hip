@@ -21,26 +21,12 @@
 // rows), one full output row.
 #include "evogp_defs.hpp"
 #include "launch.hpp"
-#include "replace_row.hpp"
+#include "breed_group.hpp"
 #include <cstdint>
 #include <cstdlib>
 
 namespace evogp {
 
-struct BreedParams {
-    const float *v; const int16_t *t; const int16_t *s;    // current generation [pop][gp_len]
-    const int *order;                                        // [n_elite] rows copied unchanged (the elites)
-    const int *parents;                                      // [n_surv] rows the parents are drawn from (repeats allowed)
-    const int *rnd;                                          // [6][n_new] raw words in [0, 2^31 - 1)
-    const float *dv; const int16_t *dt; const int16_t *ds;  // donors [n_new][gp_len] (rows of mutating offspring only)
-    float *ov; int16_t *ot; int16_t *os;                    // next generation [pop][gp_len]
-    int *decisions;                                          // optional [n_new][6]: left, right, p, q, mutated, mutate position
-    int pop, gp_len, n_elite, n_surv, n_new;
-    int table_rows;  // rows of v/t/s: the whole population, or only the trees `order` can name (a sharded run's survivor table)
-    unsigned mutate_below;
-    int row_begin, row_count;  // rows [row_begin, row_begin + row_count) of the next generation are built; output and donor
-                               // arrays hold exactly these rows (donor row k belongs to next-generation row row_begin + k)
-};
 
 // A workgroup (4 waves) takes 64 consecutive output rows in two phases.  DECIDE: lane l of wave 0 owns row n0 + l and
 // chases the dependent loads of its decisions (random words -> order[] -> tree sizes -> subtree sizes -> donor size):
@@ -145,116 +131,11 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
     }
 }
 
-// ---- four rows per wave -------------------------------------------------------------------------------------------------
-// Same two phases, but BUILD works in groups of 16 lanes (replace_row.hpp): the workgroup's 16 groups build 16 rows at a
-// time, so a chunk of 64 rows is four steps of dependent memory round trips instead of sixteen.  A mutated child is staged
-// in the group's own LDS row (8 bytes per node) between the two replacements.
 __global__ __launch_bounds__(kRepBlock) void breed_group_kernel(BreedParams a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char breed_lds[];
-    constexpr int kGroups = kRepBlock / kGroupLanes;
-    const int w = uni((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const int g = threadIdx.x / kGroupLanes;           // group in the workgroup
-    const int gl = threadIdx.x & (kGroupLanes - 1);
-    unsigned char *mine = breed_lds + (size_t)g * a.gp_len * 8;
-    float *cv = (float *)mine;
-    int16_t *ct = (int16_t *)(mine + (size_t)a.gp_len * 4);
-    int16_t *cs = ct + a.gp_len;
     __shared__ int dec_s[10][64];
-    const int nchunks = (a.row_count + 63) >> 6;
-    const int row_end = a.row_begin + a.row_count;
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const int n0 = a.row_begin + (c << 6);
-        // ---- DECIDE (wave 0), as in breed_kernel ----
-        const int n = n0 + lane;
-        int li = 0, ri = 0, S = 0, p = 0, q = 0, m = 0, o = 0, dm = 0;
-        unsigned r5 = 0;
-        bool fallback = true, mutating = false;
-        if (w == 0 && n < row_end) {
-            if (n < a.n_elite) {
-                li = a.order[n];
-                li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
-                ri = li;
-                S = (int)a.s[(size_t)li * a.gp_len];
-                S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
-            } else {
-                const int i = n - a.n_elite;
-                const unsigned r0 = (unsigned)a.rnd[i], r1 = (unsigned)a.rnd[a.n_new + i], r2 = (unsigned)a.rnd[2 * a.n_new + i],
-                               r3 = (unsigned)a.rnd[3 * a.n_new + i], r4 = (unsigned)a.rnd[4 * a.n_new + i];
-                r5 = (unsigned)a.rnd[5 * a.n_new + i];
-                li = a.parents[r0 % (unsigned)a.n_surv];
-                ri = a.parents[r1 % (unsigned)a.n_surv];
-                li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
-                ri = ri < 0 ? 0 : (ri >= a.table_rows ? a.table_rows - 1 : ri);
-                const int16_t *ls = a.s + (size_t)li * a.gp_len, *rs = a.s + (size_t)ri * a.gp_len;
-                S = (int)ls[0];
-                int RS = (int)rs[0];
-                S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
-                RS = RS < 0 ? 0 : (RS > a.gp_len ? a.gp_len : RS);
-                p = S > 0 ? (int)(r2 % (unsigned)S) : 0;
-                q = RS > 0 ? (int)(r3 % (unsigned)RS) : 0;
-                fallback = S <= 0 || RS <= 0;
-                if (!fallback) {
-                    m = (int)rs[q];
-                    o = (int)ls[p];
-                    fallback = m < 1 || q + m > a.gp_len || S + (m - o) > a.gp_len;  // mutation.cu:279-289
-                }
-                mutating = r4 < a.mutate_below;
-                if (mutating) dm = (int)a.ds[(size_t)(n - a.row_begin) * a.gp_len];
-            }
-        }
-        if (w == 0) {
-            dec_s[0][lane] = li; dec_s[1][lane] = ri; dec_s[2][lane] = S; dec_s[3][lane] = p; dec_s[4][lane] = q;
-            dec_s[5][lane] = m; dec_s[6][lane] = o; dec_s[7][lane] = dm; dec_s[8][lane] = (int)r5;
-            dec_s[9][lane] = (fallback ? 1 : 0) | (mutating ? 2 : 0);
-        }
-        __syncthreads();
-        // ---- BUILD: 16 rows per step ----
-        const int rows = row_end - n0 < 64 ? row_end - n0 : 64;
-        for (int l0 = 0; l0 < rows; l0 += kGroups) {
-            const int l = l0 + g;
-            const bool active = l < rows;
-            const int lc = active ? l : 0;
-            const int nn = n0 + lc;
-            const size_t off = (size_t)(nn - a.row_begin) * a.gp_len;
-            const int li_ = dec_s[0][lc], ri_ = dec_s[1][lc], S_ = dec_s[2][lc], p_ = dec_s[3][lc], q_ = dec_s[4][lc],
-                      m_ = dec_s[5][lc], o_ = dec_s[6][lc], flags = dec_s[9][lc];
-            const size_t lo = (size_t)li_ * a.gp_len, ro = (size_t)ri_ * a.gp_len;
-            const bool fb = (flags & 1) != 0, mu = active && (flags & 2) != 0;
-            // the child of the crossover goes straight to its row, or to the group's LDS row when it mutates next
-            float *tv = mu ? cv : a.ov + off;
-            int16_t *tt = mu ? ct : a.ot + off, *ts = mu ? cs : a.os + off;
-            build_row_group(a.v + lo, a.t + lo, a.s + lo, a.v + ro, a.t + ro, a.s + ro, S_, p_, q_, m_, o_, fb, active,
-                            a.gp_len, tv, tt, ts);
-            int pm = -1;
-            if (__any(mu)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (mu) {
-                    int CS = (int)cs[0];
-                    CS = CS < 0 ? 0 : (CS > a.gp_len ? a.gp_len : CS);
-                    const unsigned r5_ = (unsigned)dec_s[8][lc];
-                    pm = CS > 0 ? (int)((r5_ % (unsigned)kMaxStack) % (unsigned)CS) : 0;  // mutation/default.py:59-66
-                    const int dm_ = dec_s[7][lc];
-                    bool mfall = CS <= 0 || dm_ < 1 || dm_ > a.gp_len;                   // mutation.cu:150-160 (+ donor sanity)
-                    int co = 0;
-                    if (!mfall) {
-                        co = (int)cs[pm];
-                        mfall = CS + (dm_ - co) > a.gp_len;                              // :170-180
-                    }
-                    build_row_group(cv, ct, cs, a.dv + off, a.dt + off, a.ds + off, CS, pm, 0, dm_, co, mfall, true, a.gp_len,
-                                    a.ov + off, a.ot + off, a.os + off);
-                }
-                __builtin_amdgcn_wave_barrier();  // the staging rows are rewritten in the next step
-            }
-            if (a.decisions && active && gl == 0 && nn >= a.n_elite) {
-                int *d = a.decisions + (size_t)(nn - a.row_begin) * 6;
-                d[0] = li_; d[1] = ri_; d[2] = p_; d[3] = q_; d[4] = mu ? 1 : 0; d[5] = pm;
-            }
-        }
-        __syncthreads();  // the next chunk's decisions overwrite dec_s
-    }
+    NoBreedHook hook;
+    breed_group_body(a, breed_lds, dec_s, hook);
 }
 
 } // namespace evogp
@@ -302,7 +183,19 @@ extern "C" int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, i
                                      const int *rnd, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
                                      const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
                                      int *decisions, int row_begin, int row_count, evogp_stream_t stream_) {
+    return evogp_hip_breed_lists_compiled(pop_size, table_rows, gp_len, n_elite, n_surv, value, type, size, elite_rows, parent_rows, rnd,
+                                          mutate_below, donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions,
+                                          row_begin, row_count, nullptr, stream_);
+}
+
+extern "C" int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
+                                              const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
+                                              const int *rnd, unsigned mutate_below, const float *donor_value,
+                                              const int16_t *donor_type, const int16_t *donor_size, float *value_res,
+                                              int16_t *type_res, int16_t *size_res, int *decisions, int row_begin, int row_count,
+                                              unsigned long long *records_stamp, evogp_stream_t stream_) {
     const int *order = elite_rows;
+    if (records_stamp) *records_stamp = 0ull;
     // n_surv may exceed pop_size: a selection that draws with replacement may name more parents than there are trees
     if (pop_size <= 0 || table_rows <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0)
         return EVOGP_E_BADARG;
@@ -321,6 +214,11 @@ extern "C" int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, i
     const size_t lds_groups = (size_t)(kRepBlock / kGroupLanes) * gp_len * 8;
     if (groups_on && gp_len % 4 == 0 && lds_groups <= 48 * 1024 && (uintptr_t)value_res % 16 == 0 && (uintptr_t)type_res % 8 == 0 &&
         (uintptr_t)size_res % 8 == 0) {
+        if (records_stamp) {   // the same pass, compiling its rows for the next fitness call where that is possible (sr_tc.hip)
+            const hipError_t ce = launch_breed_compiled(a, (unsigned)blocks, lds_groups, (hipStream_t)stream_, records_stamp);
+            if (ce != hipSuccess) return (int)ce;
+            if (*records_stamp != 0ull) return EVOGP_OK;
+        }
         hipLaunchKernelGGL(breed_group_kernel, dim3((unsigned)blocks), dim3(kRepBlock), lds_groups, (hipStream_t)stream_, a);
         return (int)hipGetLastError();
     }

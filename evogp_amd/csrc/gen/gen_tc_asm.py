@@ -1349,7 +1349,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     # -- the FIRST maximum; index 0 when any output is NaN or the maximum is infinite (the soft-max row is then NaN) -- compared
     # with the row's label; v6 counts the hits (as a float: exact below 2^24 rows).  aux = K * out_len is in T2, the labels
     # (int32 bits) in the T bank.  Row registers: maximum M in P0 (made NaN when the row holds a NaN: a NaN sum <=> a NaN output,
-    # or both infinities -- which the infinite maximum already covers), the sum, then the tie threshold M - 2^-22 in P1, and in Q
+    # or both infinities -- which the infinite maximum already covers), the sum, then the tie threshold M - 1.25 * 2^-23 in P1, and in Q
     # two 16-bit minima: low half = first index whose output EQUALS M (the arg-max), high half = first index whose output is
     # >= the threshold.  high < low: an output in front of the maximum is so close to it that torch's fp32 soft-max may round both
     # to the same float and return the earlier index (interp.hpp kSoftmaxTieMargin) -- such a row is AMBIGUOUS, and a tree with an
@@ -1379,7 +1379,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"v_cmp_u_f32 vcc, v{Sm + k}, v{Sm + k}")
         a("s_nop 1")
         a(f"v_cndmask_b32 v{Mx + k}, v{Mx + k}, v8, vcc")          # v8 = NaN
-        a(f"v_add_f32 v{Sm + k}, 0xb4800000, v{Mx + k}")           # threshold: M - 2^-22
+        a(f"v_add_f32 v{Sm + k}, 0xb4200000, v{Mx + k}")           # threshold: M - 1.25 * 2^-23 (interp.hpp kSoftmaxTieMargin)
         a(f"v_mov_b32 v{Bx + k}, -1")
     # every output, from the last down to output 0: index minima under the two compares (source 0 is M0-relative inside this loop,
     # so the running minima cannot be source 0 of anything, and an SGPR operand plus VCC would be two constant-bus operands: the

@@ -45,8 +45,9 @@ constexpr int kMaxOutRegs = 16; // multi-output accumulators kept in registers
 // The arg-max of the soft-max is the arg-max of the raw outputs EXCEPT where two outputs are so close that their fp32 soft-max
 // values round to the same float: exp(x_i - max) is 1 or 1 - 2^-24 only for max - x_i below ~1e-7, and a quotient by the same
 // sum can then equal that of the maximum; torch.argmax returns the FIRST of equal values, i.e. possibly an index in front of
-// the true maximum.  A row is AMBIGUOUS when an output in front of the first maximum lies within kSoftmaxTieMargin (2^-22, a
-// safe superset) below it; the fast kernels take the raw arg-max and send trees with an ambiguous row to the recount kernel,
+// the true maximum.  A row is AMBIGUOUS when an output in front of the first maximum lies within kSoftmaxTieMargin below it (1.25 x 2^-23:
+// for d = max - x_i above it the true exp(-d) lies below 1 - 2^-23, so a faithfully rounded exp returns at most 1 - 2^-23, whose
+// quotient by the sum differs from that of 1 by at least one unit in the last place: the two cannot round to the same float); the fast kernels take the raw arg-max and send trees with an ambiguous row to the recount kernel,
 // which evaluates torch's arithmetic itself:
 //   * aten's softmax_warp_forward (the kernel a row of <= 1024 fp32 elements gets): max over the row; e_i = std::exp(x_i - max)
 //     (the device library's expf); the sum by an xor-butterfly over next_pow2(n) lanes holding one element each (lanes past
@@ -54,7 +55,7 @@ constexpr int kMaxOutRegs = 16; // multi-output accumulators kept in registers
 //     with the correctly rounded division;
 //   * clip to [1e-15f, 1.0f] (1 - 1e-15 rounds to 1 in fp32); arg-max = first index of the largest value.
 // A NaN output or an infinite maximum makes the whole soft-max row NaN (inf - inf), whose arg-max is index 0.
-constexpr float kSoftmaxTieMargin = 2.384185791015625e-07f;  // 2^-22
+constexpr float kSoftmaxTieMargin = 1.4901161193847656e-07f;  // 1.25 * 2^-23 = 0x34200000
 
 __device__ inline int argmax_raw(const float *x, int n, bool *ambiguous) {
     int best = 0;

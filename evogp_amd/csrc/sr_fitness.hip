@@ -532,6 +532,15 @@ extern "C" int evogp_hip_sr_fitness(unsigned pop_size, unsigned data_points, uns
                                     unsigned out_len, int use_mse, const float *value, const int16_t *type,
                                     const int16_t *size, const float *variables, const float *labels,
                                     float *fitnesses, unsigned kernel_type, evogp_stream_t stream_) {
+    return evogp_hip_sr_fitness_stamped(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels,
+                                        fitnesses, kernel_type, 0ull, stream_);
+}
+
+extern "C" int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len,
+                                            unsigned out_len, int use_mse, const float *value, const int16_t *type,
+                                            const int16_t *size, const float *variables, const float *labels,
+                                            float *fitnesses, unsigned kernel_type, unsigned long long records_stamp,
+                                            evogp_stream_t stream_) {
     // argument contract of torch_wrapper.cu:250-254
     if (pop_size == 0 || data_points == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len == 0)
         return EVOGP_E_BADARG;
@@ -542,6 +551,7 @@ extern "C" int evogp_hip_sr_fitness(unsigned pop_size, unsigned data_points, uns
     p.value = value; p.type = type; p.size = size; p.X = variables; p.y = labels; p.fitness = fitnesses;
     p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len;
     p.out_len = (int)out_len; p.use_mse = use_mse ? 1 : 0;
+    p.stamp = records_stamp;
     return run_population<false>(p, (hipStream_t)stream_);
 }
 

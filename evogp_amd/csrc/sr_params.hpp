@@ -32,6 +32,7 @@ struct SrParams {
     unsigned *zero_next; // four words the first kernel of the chain zeroes for the next call on this stream (or nullptr)
     int mark_chunks;     // the threaded code ran the population in this many chunks: chunk c's flags are marks[c * kCallScratchChunkWords + i]
     hipEvent_t prof_mid; // profiling (evogp_hip_debug_profile): recorded between the compiler and the interpreter launch, or nullptr
+    unsigned long long stamp; // != 0: the caller believes the program records of the breeding pass with this stamp belong to this population
     unsigned *marks; // [0] != 0: some tree carries kSentinelHeavy, [1] != 0: some tree carries kSentinelDeep,
                      // [2]: how many of the mark_sample sampled trees were marked heavy (may be nullptr)
 };

@@ -231,7 +231,7 @@ static hipError_t launch_wide_k(WideParams p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.ngroups * p.workers)), dim3(kWideWaves * 64), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || MODE != 1) return e;
-    long blocks = (long)dev.num_cus * 4;
+    long blocks = (long)dev.num_cus * 16;   // one wave per marked tree at a time: as many waves as the chip holds
     if (blocks > p.pop) blocks = p.pop;
     hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
@@ -305,7 +305,7 @@ extern "C" int evogp_hip_batch_argmax_count(unsigned pop_size, unsigned data_poi
         bool handled = false;
         if ((e = run_argmax_count_threaded(s, labels, counts, p.marks, stream, &handled)) != hipSuccess) return (int)e;
         if (handled) {
-            long blocks = (long)device_info().num_cus * 4;
+            long blocks = (long)device_info().num_cus * 16;
             if (blocks > p.pop) blocks = p.pop;
             hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, p);
             return (int)hipGetLastError();

@@ -164,9 +164,9 @@ Tensor tree_evaluate(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t 
     return results;
 }
 
-Tensor tree_SR_fitness(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
+Tensor sr_fitness_impl(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
                        const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
-                       int64_t kernel_type) {
+                       int64_t kernel_type, int64_t records_stamp) {
     check_sizes(pop_size, gp_len);
     TORCH_CHECK(var_len > 0, "var_len must be larger than 0, but got ", var_len);
     TORCH_CHECK(out_len > 0, "out_len must be larger than 0, but got ", out_len);
@@ -178,12 +178,26 @@ Tensor tree_SR_fitness(int64_t pop_size, int64_t data_points, int64_t gp_len, in
     check_tensor(labels, {data_points, out_len}, "labels", dev, at::kFloat);
     c10::DeviceGuard guard(dev);
     Tensor fitness = at::empty({pop_size}, value.options());
-    const int rc = evogp_hip_sr_fitness((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len,
-                                        use_mse ? 1 : 0, value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(),
-                                        variables.data_ptr<float>(), labels.data_ptr<float>(), fitness.data_ptr<float>(),
-                                        (unsigned)kernel_type, current_stream(dev));
+    const int rc = evogp_hip_sr_fitness_stamped((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len,
+                                                use_mse ? 1 : 0, value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(),
+                                                variables.data_ptr<float>(), labels.data_ptr<float>(), fitness.data_ptr<float>(),
+                                                (unsigned)kernel_type, (unsigned long long)records_stamp, current_stream(dev));
     check_rc(rc, "tree_SR_fitness");
     return fitness;
+}
+
+Tensor tree_SR_fitness(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
+                       const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
+                       int64_t kernel_type) {
+    return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type, 0);
+}
+
+// tree_SR_fitness for a forest the breeding pass compiled ahead (breed_rows_compiled returned `records_stamp` for exactly these rows)
+Tensor tree_SR_fitness_stamped(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
+                               const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
+                               int64_t kernel_type, int64_t records_stamp) {
+    return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type,
+                           records_stamp);
 }
 
 // ---- extra ops (no counterpart in the reference) ------------------------------------------------------------------------
@@ -370,9 +384,9 @@ Tensor3 breed_default_rows(int64_t pop_size, int64_t gp_len, int64_t n_elite, in
 
 // The same rows for ANY selection operator: the elites and the parents are two lists of table rows (parents may repeat, as
 // the survivor indices of a tournament selection do); n_elite / n_surv are the lists' lengths.
-Tensor3 breed_rows(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
-                   const Tensor &parent_rows, const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value, const Tensor &donor_type,
-                   const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
+Tensor3 breed_rows_impl(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
+                        const Tensor &parent_rows, const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value, const Tensor &donor_type,
+                        const Tensor &donor_size, int64_t row_begin, int64_t row_count, unsigned long long *records_stamp) {
     check_sizes(pop_size, gp_len);
     TORCH_CHECK(row_begin >= 0 && row_count > 0 && row_begin + row_count <= pop_size, "row range out of the population");
     TORCH_CHECK(mutate_below >= 0 && mutate_below < (1LL << 32), "mutate_below must fit in 32 bits");
@@ -394,14 +408,35 @@ Tensor3 breed_rows(int64_t pop_size, int64_t gp_len, const Tensor &value, const 
     const int64_t skip = drows == row_count - head ? head : 0;
     c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(row_count, gp_len, dev);
-    const int rc = evogp_hip_breed_lists(
+    const int rc = evogp_hip_breed_lists_compiled(
         (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),
         size.data_ptr<int16_t>(), n_elite > 0 ? elite_rows.data_ptr<int>() : nullptr, parent_rows.data_ptr<int>(), rnd.data_ptr<int>(),
         (unsigned)mutate_below, donor_value.data_ptr<float>() - skip * gp_len, donor_type.data_ptr<int16_t>() - skip * gp_len,
         donor_size.data_ptr<int16_t>() - skip * gp_len, std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
-        std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, current_stream(dev));
+        std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, records_stamp, current_stream(dev));
     check_rc(rc, "breed_rows");
     return out;
+}
+
+Tensor3 breed_rows(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
+                   const Tensor &parent_rows, const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value, const Tensor &donor_type,
+                   const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
+    return breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, rnd, mutate_below, donor_value, donor_type, donor_size,
+                           row_begin, row_count, nullptr);
+}
+
+// breed_rows that also compiles the rows it builds into the program records of the next tree_SR_fitness call where the engine
+// can (include/evogp_hip.h evogp_hip_breed_lists_compiled); the int is the records' stamp (0: not compiled) for
+// tree_SR_fitness_stamped
+std::tuple<Tensor, Tensor, Tensor, int64_t> breed_rows_compiled(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type,
+                                                                const Tensor &size, const Tensor &elite_rows, const Tensor &parent_rows,
+                                                                const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value,
+                                                                const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin,
+                                                                int64_t row_count) {
+    unsigned long long stamp = 0;
+    Tensor3 out = breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, rnd, mutate_below, donor_value, donor_type,
+                                  donor_size, row_begin, row_count, &stamp);
+    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), (int64_t)stamp};
 }
 
 }  // namespace
@@ -449,6 +484,11 @@ TORCH_LIBRARY(evogp_hip, m) {
     m.def("breed_rows(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows, Tensor parent_rows,"
           " Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin, int row_count)"
           " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
+    m.def("breed_rows_compiled(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows,"
+          " Tensor parent_rows, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin,"
+          " int row_count) -> (Tensor value, Tensor node_type, Tensor subtree_size, int records_stamp)");
+    m.def("tree_SR_fitness_stamped(int pop_size, int data_points, int gp_len, int var_len, int out_len, bool use_mse, Tensor value,"
+          " Tensor node_type, Tensor subtree_size, Tensor variables, Tensor labels, int kernel_type, int records_stamp) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(evogp_hip, CompositeExplicitAutograd, m) { m.impl("random_words", &random_words); }  // no tensor argument to dispatch on
@@ -463,5 +503,7 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("breed_default", &breed_default);
     m.impl("breed_default_rows", &breed_default_rows);
     m.impl("breed_rows", &breed_rows);
+    m.impl("breed_rows_compiled", &breed_rows_compiled);
+    m.impl("tree_SR_fitness_stamped", &tree_SR_fitness_stamped);
     m.impl("select_survivors", &select_survivors);
 }

@@ -28,7 +28,12 @@ class LinearTrackingEnv:
     """A deterministic linear system the policy has to regulate to the origin: x' = A x + B a, reward = -|x|^2 - c|a|^2,
     done when |x|_inf > limit.  obs = x.  Sized like halfcheetah by default (17 observations, 6 actions)."""
 
-    def __init__(self, obs_dim: int = 17, act_dim: int = 6, seed: int = 0, limit: float = 50.0, device=None):
+    def __init__(self, obs_dim: int = 17, act_dim: int = 6, seed: int = 0, limit: float = 50.0, device=None, randomize: float = 0.0):
+        """``randomize`` > 0: every tree starts from its own perturbed state, a counter-based function of (seed, GLOBAL tree
+        index) — the rank of a sharded run that owns trees [offset, offset + n) resets with ``reset(n, offset)`` and gets exactly
+        the episodes those trees have in a single-process run (the reference's simulators are reset per environment the same
+        way, brax_problem.py:60-66)."""
+        self.randomize, self.seed = float(randomize), int(seed)
         g = torch.Generator().manual_seed(seed)
         a = torch.randn(obs_dim, obs_dim, generator=g) * (0.6 / obs_dim**0.5)
         self.A = (torch.eye(obs_dim) * 0.97 + a).to(device)
@@ -36,8 +41,14 @@ class LinearTrackingEnv:
         self.x0 = torch.randn(obs_dim, generator=g).to(device)
         self.obs_dim, self.act_dim, self.limit, self.device = obs_dim, act_dim, limit, device
 
-    def reset(self, n: int) -> Tensor:
-        return self.x0[None, :].repeat(n, 1)   # every tree faces the same episode: fitness depends on the tree only
+    def reset(self, n: int, offset: int = 0) -> Tensor:
+        x = self.x0[None, :].repeat(n, 1)      # randomize == 0: every tree faces the same episode, fitness depends on the tree only
+        if self.randomize > 0:
+            from ..parallel import random_words   # word k of tree i = hash(seed, 0, k, i): the same on every rank and for every world size
+
+            w = random_words(self.seed, 0, self.obs_dim, offset, offset + n, x.device)          # (obs_dim, n) in [0, 2^31 - 1)
+            x = x + self.randomize * (w.t().to(torch.float32) / float(2**30) - 1.0)
+        return x
 
     def observe(self, state: Tensor) -> Tensor:
         return state
@@ -93,9 +104,12 @@ class RolloutProblem(BaseProblem):
         nxt = torch.where(done[:, None], state, torch.nan_to_num(nxt))
         return nxt, total, done
 
-    def evaluate(self, forest: Forest) -> Tensor:
+    def evaluate(self, forest: Forest, tree_index_offset: int = 0) -> Tensor:
+        """``tree_index_offset``: global index of the forest's first tree when it is a rank's shard of a larger population
+        (evogp_amd/parallel.py): environments that reset per tree are then reset for exactly those trees.  No collective inside
+        the episode: every rank rolls out its own trees; the fitness values meet in ShardedGeneticProgramming.step."""
         n = forest.pop_size
-        state = self.env.reset(n)
+        state = self.env.reset(n, tree_index_offset) if tree_index_offset else self.env.reset(n)
         dev = state.device
         total = torch.zeros(n, device=dev)
         done = torch.zeros(n, dtype=torch.bool, device=dev)

@@ -157,6 +157,29 @@ int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, int n_elite,
                           const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
                           int *decisions, int row_begin, int row_count, evogp_stream_t stream);
 
+/* Program records written AHEAD of the fitness call (no counterpart in the reference).  evogp_hip_sr_fitness spends a fifth of
+ * its time compiling the trees into the program records its interpreter reads; the breeding pass has the rows it builds in
+ * the cache and its vector unit idle.  evogp_hip_breed_lists_compiled is evogp_hip_breed_lists that also compiles rows
+ * [row_begin, row_begin + row_count) — record k = row row_begin + k — for the dataset geometry of the device's most recent
+ * single-output evogp_hip_sr_fitness call, and returns a STAMP naming those records (0: not possible now — no such call yet,
+ * gp_len > 64, the record buffer too small — then it is exactly evogp_hip_breed_lists).  evogp_hip_sr_fitness_stamped is
+ * evogp_hip_sr_fitness for a caller that presents the stamp it got for EXACTLY the rows it now passes (same row_count trees,
+ * unmodified since): if the engine's records still carry that stamp, the population size matches and the dataset geometry is
+ * the one they were compiled for, the compiler launch is skipped; in every other case (stamp 0, another forest evaluated in
+ * between, another dataset shape, another division mode ...) the call compiles as usual.  Results are identical either way.
+ * The caller vouches only for "these are the rows that pass built, unmodified" (evogp_amd/tree/forest.py checks the tensors'
+ * data pointers and version counters). */
+int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
+                                   const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
+                                   const int *rnd, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                                   const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
+                                   int *decisions, int row_begin, int row_count, unsigned long long *records_stamp,
+                                   evogp_stream_t stream);
+int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                 int use_mse, const float *value, const int16_t *type, const int16_t *size,
+                                 const float *variables, const float *labels, float *fitnesses, unsigned kernel_type,
+                                 unsigned long long records_stamp, evogp_stream_t stream);
+
 /* Counter-based random words for the breeding pass of a sharded run (no counterpart in the reference, which draws with
  * torch's generator): out[k][i] for k < rows, i in [lo, hi) = hash(seed, generation, k, i) mapped to [0, 2^31 - 1), the value
  * evogp_amd/parallel.py random_words computes on any device; out: i32[rows][n_cols], only columns [lo, hi) are written.  Every

@@ -33,3 +33,21 @@ for pop in [int(a) for a in sys.argv[1:]] or [125_000, 1_000_000]:
     print(f"pop {pop}: generate(full) {timed(lambda: Forest.random_generate(pop, desc, keys=keys)):.1f} us | select {timed(lambda: torch.ops.evogp_hip.select_survivors(fit, n_elite, n_surv)):.1f}"
           f" | randint {timed(lambda: torch.randint(0, 2**31 - 1, (6, n_new), dtype=torch.int32, device=dev)):.1f} | donors (20 % live, depth 3) {timed(gen):.1f}"
           f" | breed {timed(lambda: torch.ops.evogp_hip.breed_default(pop, 64, n_elite, n_surv, value, ntype, size, order, rnd, below, *donors, False)):.1f}")
+    # the breeding pass that also compiles its rows (needs the geometry of a fitness call), and what the next fitness call then costs
+    import numpy as np
+    rng = np.random.default_rng(1234)
+    Xn = rng.uniform(-5, 5, (1024, 10)).astype(np.float32)
+    X = torch.from_numpy(Xn).to(dev); y = torch.from_numpy((Xn[:, 0] * Xn[:, 1] + Xn[:, 2] * Xn[:, 3] - Xn[:, 4] + 0.5 * Xn[:, 5] ** 2)[:, None].copy()).to(dev)
+    f.SR_fitness(X, y)
+    elites, parents = order[:n_elite], order[:n_surv]
+    bc = lambda: torch.ops.evogp_hip.breed_rows_compiled(pop, 64, value, ntype, size, elites, parents, rnd, below, *donors, 0, pop)
+    t_bc = timed(bc)
+    nv, nt, ns, stamp = bc()
+    child = Forest(f.input_len, f.output_len, nv, nt, ns)
+    t_plain = timed(lambda: child.SR_fitness(X, y))
+    def ahead():
+        v2, t2, s2, st = bc()
+        return Forest(f.input_len, f.output_len, v2, t2, s2).set_compiled_records(st).SR_fitness(X, y)
+    t_pair = timed(ahead)
+    print(f"           breed + compile {t_bc:.1f} us (stamp {stamp}) | fitness of the children, compiled in the call {t_plain:.1f} us | breed + compile + fitness {t_pair:.1f} us"
+          f" (separately: {timed(lambda: torch.ops.evogp_hip.breed_rows(pop, 64, value, ntype, size, elites, parents, rnd, below, *donors, 0, pop)) + t_plain:.1f})")

@@ -66,6 +66,13 @@ def main():
         out["sr_tc_kernel_hbm_bytes_per_launch"] = 2 * f + w
         out["correction"] = ("counter values are KB (x 1024); FETCH_SIZE doubled (gfx950 tallies 128-byte requests of 16 B/lane coalesced reads at 64 B; "
                              f"calibration on this kernel: records = pop x 256 B = {pop * 256} B, raw FETCH_SIZE = {f:.0f} B); WRITE_SIZE as reported")
+    if comp and "FETCH_SIZE" in t.get(comp, {}) and "WRITE_SIZE" in t[comp] and "sr_tc_kernel_hbm_bytes_per_launch" in out:
+        # the whole fitness call: + the program compiler (its reads are 2- and 4-byte node loads: FETCH_SIZE as reported) -- it reads
+        # the forest and writes the records the interpreter then reads
+        cf, cw = t[comp]["FETCH_SIZE"][1] * 1024, t[comp]["WRITE_SIZE"][1] * 1024
+        out["tc_compile_kernel_fetch_bytes_raw"] = cf
+        out["tc_compile_kernel_write_bytes_raw"] = cw
+        out["call_hbm_bytes"] = out["sr_tc_kernel_hbm_bytes_per_launch"] + cf + cw
     if interp and "SQ_WAVE_CYCLES" in t[interp]:
         c = {k: v[1] * inst for k, v in t[interp].items()}
         wc = c["SQ_WAVE_CYCLES"]

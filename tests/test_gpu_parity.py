@@ -416,7 +416,7 @@ def test_batch_argmax_count_on_near_ties_equals_torch(g, oracle, rng, out_len, D
     outs = oracle.batch_evaluate(*f, X, out_len)
     want = torch_rule_counts(outs, labels)
     raw = (np.argmax(outs, axis=2) == labels[None, :]).sum(1)
-    assert (raw != want).mean() > 0.05, "the forest does not exercise the near-tie rule"
+    assert (raw != want).mean() > 0.01, "the forest does not exercise the near-tie rule"
     got = g.batch_argmax_count(*f, X, labels, out_len)
     assert np.array_equal(got, want), (np.abs(got - want).max(), (got != want).mean(), np.flatnonzero(got != want)[:5])
 

@@ -67,6 +67,24 @@ def _run(rank, world, port, outdir):
             np.savez(os.path.join(outdir, f"w{world}_r{rank}_{sel}_{exchange}_{cap}.npz"), v=f.batch_node_value.numpy(),
                      t=f.batch_node_type.numpy(), s=f.batch_subtree_size.numpy(), sent=np.array(sent),
                      collectives=np.array(gp.last_exchange.get("collectives", 0)))
+    # BASELINE configs[4] shape in small: policy trees with several outputs, fitness = a rollout of every rank's
+    # own trees (no collective inside the episode), per-tree episodes keyed by the GLOBAL tree index
+    from evogp_amd.problem import RolloutProblem
+    from evogp_amd.problem.rollout import LinearTrackingEnv
+
+    pdesc = GenerateDescriptor(max_tree_len=L, input_len=4, output_len=2, using_funcs=["+", "-", "*", "/"], max_layer_cnt=4,
+                               const_samples=[-1, 0, 1, 0.5])
+    local = Forest.random_generate(n_local, pdesc, keys=keys, tree_index_offset=rank * n_local)
+    prob = RolloutProblem(LinearTrackingEnv(obs_dim=4, act_dim=2, seed=3, randomize=0.5), 12, use_graph=False)
+    gp = ShardedGeneticProgramming(local, 0.2, pdesc.update(max_layer_cnt=3), selection=_selection("default"), seed=77, exchange="packed")
+    fits = []
+    for _ in range(2):
+        fit = prob.evaluate(gp.forest, tree_index_offset=rank * n_local)
+        fits.append(fit.numpy().copy())
+        gp.step(fit)
+    f = gp.forest
+    np.savez(os.path.join(outdir, f"w{world}_r{rank}_rollout.npz"), v=f.batch_node_value.numpy(), t=f.batch_node_type.numpy(),
+             s=f.batch_subtree_size.numpy(), fit=np.stack(fits))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -107,6 +125,18 @@ def test_two_ranks_equal_one_rank(runs, sel, exchange, cap):
         if cap == "exact":
             bound = np.load(os.path.join(out, f"w2_r0_{sel}_rows_bound.npz"))["sent"]
             assert (sent <= bound).all()
+
+
+def test_sharded_rollout_two_ranks_equal_one_rank(runs):
+    """C5 across ranks: every rank rolls out its own policy trees (per-tree episodes keyed by the global tree index), the fitness
+    values meet in the sharded step; world 2 == world 1 in the fitness of every generation and in the final population"""
+    one = np.load(os.path.join(runs, "w1_r0_rollout.npz"))
+    parts = [np.load(os.path.join(runs, f"w2_r{r}_rollout.npz")) for r in range(2)]
+    assert np.array_equal(one["fit"].view(np.uint32), np.concatenate([p["fit"] for p in parts], axis=1).view(np.uint32))
+    assert len(np.unique(one["fit"][0])) > POP // 4, "the episodes do not depend on the tree"
+    for k in ("v", "t", "s"):
+        both = np.concatenate([p[k] for p in parts])
+        assert np.array_equal(one[k].view(np.uint32) if k == "v" else one[k], both.view(np.uint32) if k == "v" else both), k
 
 
 def test_selection_that_reads_the_trees_is_refused():
