@@ -21,6 +21,8 @@
 // Trees whose operand stack exceeds the register stack are marked (MODE 0: sentinel in results[t][0][0], redone by
 // sr_general_kernel; MODE 1: counted by a scratch-stack fallback inside this kernel's slow path below).
 #include "interp.hpp"
+#include <cstdio>
+#include <vector>
 #include "launch.hpp"
 #include "sr_params.hpp"
 #include <cstdlib>
@@ -44,26 +46,52 @@ constexpr int kWideWaves = 8;
 struct __attribute__((packed, aligned(4))) Unaligned4 { float x, y, z, w; };  // 16-byte store at 4-byte alignment
 
 // MODE 1 follow-up: trees marked deep -- and trees with a row whose arg-max hangs on the soft-max's rounding (interp.hpp) -- are
-// counted with the scratch-stack interpreter, one wave per tree, lanes over rows, with torch's own arithmetic for the arg-max
+// counted with the scratch-stack interpreter and torch's own arithmetic for the arg-max.  A wave takes ONE block of 64 rows of a
+// marked tree (blockIdx.y = row block): the first version gave a wave the whole tree, and a handful of marked trees (44 of
+// 200 000 on the digits data) then cost the fitness pass the serial walk of one wave through all 29 row blocks, 0.6-1.4 ms.
+// Three launches, all leaving at once when nothing is marked: clear (a marked tree's count word becomes the bare mark -- the
+// tile-group kernel's other row groups may have added their hits to it), count (atomic adds under the mark), unmark.
+__global__ void wide_deep_clear_kernel(WideParams p, int unmark) {
+    if (p.marks && p.marks[1] == 0u) return;
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= p.pop) return;
+    const unsigned c = p.counts[t];
+    if (c & kDeepCountBit) p.counts[t] = unmark ? (c & ~kDeepCountBit) : kDeepCountBit;
+}
+
 __global__ __launch_bounds__(64) void wide_deep_count_kernel(WideParams p) {
     if (p.marks && p.marks[1] == 0u) return;
     const int lane = threadIdx.x;
     float stk[kMaxStack + 2];
     float o16[kMaxOutRegs];
-    for (int t = blockIdx.x; t < p.pop; t += gridDim.x) {
-        if ((uni(p.counts[t]) & kDeepCountBit) == 0u) continue;
-        const size_t row = (size_t)t * p.gp_len;
-        int len = uni((int)p.size[row]);
-        len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
-        unsigned hits = 0;
-        for (int d0 = 0; d0 < p.D; d0 += 64) {
-            const int d = d0 + lane, dc = d < p.D ? d : p.D - 1;
+    const int d = (int)blockIdx.y * 64 + lane, dc = d < p.D ? d : p.D - 1;
+    for (int t0 = blockIdx.x * 64; t0 < p.pop; t0 += gridDim.x * 64) {
+        // 64 count words at a time: which of these trees are marked
+        const int tl = t0 + lane;
+        unsigned long long marked = __ballot(tl < p.pop && (p.counts[tl] & kDeepCountBit) != 0u);
+        while (marked) {
+            const int t = t0 + __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const size_t row = (size_t)t * p.gp_len;
+            int len = uni((int)p.size[row]);
+            len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
             (void)run_general<true>(p.type + row, p.value + row, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, o16, stk);
             const int best = argmax_as_torch(o16, p.out_len);
-            hits += (unsigned)__popcll(__ballot(d < p.D && best == p.labels[dc]));
+            const unsigned hits = (unsigned)__popcll(__ballot(d < p.D && best == p.labels[dc]));
+            if (lane == 0 && hits) atomicAdd(p.counts + t, hits);
         }
-        if (lane == 0) p.counts[t] = hits;
     }
+}
+
+// the three launches behind a fused count (threaded code: the count words of marked trees are bare marks already)
+static hipError_t launch_deep_recount(const WideParams &p, bool words_are_bare_marks, hipStream_t stream) {
+    const unsigned tb = (unsigned)((p.pop + 255) / 256);
+    if (!words_are_bare_marks) hipLaunchKernelGGL(wide_deep_clear_kernel, dim3(tb), dim3(256), 0, stream, p, 0);
+    long blocks = ((long)p.pop + 63) / 64;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks, (unsigned)((p.D + 63) / 64)), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(wide_deep_clear_kernel, dim3(tb), dim3(256), 0, stream, p, 1);
+    return hipGetLastError();
 }
 
 template <bool MO, int MODE, int K, int DEPTH>
@@ -231,10 +259,7 @@ static hipError_t launch_wide_k(WideParams p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.ngroups * p.workers)), dim3(kWideWaves * 64), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || MODE != 1) return e;
-    long blocks = (long)dev.num_cus * 16;   // one wave per marked tree at a time: as many waves as the chip holds
-    if (blocks > p.pop) blocks = p.pop;
-    hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, p);
-    return hipGetLastError();
+    return launch_deep_recount(p, false, stream);
 }
 
 // rows per lane: as many as the variables leave LDS for (two workgroups per CU when possible); EVOGP_WIDE_K overrides
@@ -305,10 +330,16 @@ extern "C" int evogp_hip_batch_argmax_count(unsigned pop_size, unsigned data_poi
         bool handled = false;
         if ((e = run_argmax_count_threaded(s, labels, counts, p.marks, stream, &handled)) != hipSuccess) return (int)e;
         if (handled) {
-            long blocks = (long)device_info().num_cus * 16;
-            if (blocks > p.pop) blocks = p.pop;
-            hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, p);
-            return (int)hipGetLastError();
+            static const bool dbg = getenv("EVOGP_DEBUG_CLS") != nullptr;   // how many trees go to the recount kernel (diagnostics)
+            if (dbg) {
+                std::vector<unsigned> h(pop_size);
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(h.data(), counts, (size_t)pop_size * sizeof(unsigned), hipMemcpyDeviceToHost);
+                size_t marked = 0;
+                for (unsigned c : h) marked += (c & kDeepCountBit) ? 1 : 0;
+                fprintf(stderr, "[evogp] batch_argmax_count: %zu of %u trees marked for the recount kernel\n", marked, pop_size);
+            }
+            return (int)launch_deep_recount(p, true, stream);
         }
     }
     if ((e = hipMemsetAsync(counts, 0, (size_t)pop_size * sizeof(unsigned), stream)) != hipSuccess) return (int)e;

@@ -168,7 +168,11 @@ int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, int n_elite,
  * the one they were compiled for, the compiler launch is skipped; in every other case (stamp 0, another forest evaluated in
  * between, another dataset shape, another division mode ...) the call compiles as usual.  Results are identical either way.
  * The caller vouches only for "these are the rows that pass built, unmodified" (evogp_amd/tree/forest.py checks the tensors'
- * data pointers and version counters). */
+ * data pointers and version counters).
+ * evogp_hip_set_breed_compile: 0 = off (DEFAULT: _compiled then is evogp_hip_breed_lists and returns stamp 0), 1 = one fused
+ * kernel, 2 = two-stream pipeline for >= 200 k rows.  Measured on MI355X the compiler's work costs the same time wherever it
+ * runs (csrc/sr_tc.hip launch_breed_compiled has the numbers), so nothing is gained yet; environment: EVOGP_BREED_COMPILE. */
+int evogp_hip_set_breed_compile(int mode);
 int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
                                    const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
                                    const int *rnd, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,

@@ -387,8 +387,21 @@ def test_native_random_words_equal_the_python_definition(g):
     assert abs(float(random_words(5, 5, 6, 0, 200_000, "cpu").float().mean()) / 2**31 - 0.5) < 0.005
 
 
+@pytest.fixture(params=[1, 2], ids=["fused", "pipe"])
+def compile_ahead(request, monkeypatch):
+    """the breeding pass compiles ahead (off by default: it does not pay yet, csrc/sr_tc.hip launch_breed_compiled); mode 2 pipelines
+    from 200 k rows on -- lowered here"""
+    import evogp_amd
+    from evogp_amd import _lib
+
+    monkeypatch.setenv("EVOGP_BREED_COMPILE_PIPE_MIN", "1000")     # read once per process, at the first mode-2 launch
+    _lib.check(_lib.lib.evogp_hip_set_breed_compile(request.param), "set_breed_compile")
+    yield request.param
+    _lib.check(_lib.lib.evogp_hip_set_breed_compile(0), "set_breed_compile")
+
+
 @pytest.mark.parametrize("funcs,D", [(["+", "-", "*", "/"], 1024), (["+", "-", "*", "/", "sin", "neg", "pow", "max"], 300), (["+", "*", "/"], 40)])
-def test_breeding_pass_compiles_ahead_and_stale_stamps_recompile(g, funcs, D):
+def test_breeding_pass_compiles_ahead_and_stale_stamps_recompile(g, compile_ahead, funcs, D):
     """the breeding pass compiles the rows it builds into the program records of the next tree_SR_fitness call
     (csrc/sr_tc.hip breed_compile_group_kernel); a forest that presents the records' stamp skips the compiler launch.  The
     fitness words must be those of an ordinary call, bit for bit — for compiled programs, for trees the compiler leaves to the
