@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
 
 __global__ __launch_bounds__(kRepBlock) void breed_group_kernel(BreedParams a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char breed_lds[];
-    __shared__ int dec_s[10][64];
+    __shared__ int dec_s[kBreedUnit][10][64];
     NoBreedHook hook;
     breed_group_body(a, breed_lds, dec_s, hook);
 }
@@ -205,12 +205,22 @@ extern "C" int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int 
     if (mutate_below != 0 && n_new > 0 && (!donor_value || !donor_type || !donor_size)) return EVOGP_E_NULLPTR;
     if (row_begin < 0 || row_count <= 0 || row_begin + row_count > pop_size) return EVOGP_E_BADARG;
     BreedParams a{value, type, size, order, parent_rows, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
-                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, table_rows, mutate_below, row_begin, row_count};
+                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, table_rows, mutate_below, row_begin, row_count, 1};
     const DeviceInfo &dev = device_info();
     long blocks = ((long)row_count + 63) / 64;  // one workgroup per 64 rows
     const long cap = (long)dev.num_cus * 8 * 4;
     if (blocks > cap) blocks = cap;
     static const bool groups_on = [] { const char *e = getenv("EVOGP_REPLACE_GROUPS"); return !(e && e[0] == '0'); }();
+    // EVOGP_BREED_UNIT=4: every wave decides a chunk and the workgroup builds the four (breed_group.hpp).  Measured SLOWER: 1 M rows
+    // 379 against 343 us, 500 k 203 against 152 (profiles/r03k_breed_unit.log) -- a chunk takes ~45 us under load, not the ~20 us
+    // of its idle round trips: the pass is bound by the memory system's rate of scattered 128- / 256-byte row reads (2.6 TB/s),
+    // not by the decision chain, and fewer, longer work units only balance worse.  Kept as a switch, default one chunk at a time.
+    static const int env_unit = [] { const char *e = getenv("EVOGP_BREED_UNIT"); return e ? atoi(e) : 0; }();
+    a.chunks_per_unit = env_unit == 4 ? 4 : 1;
+    if (a.chunks_per_unit > 1) {
+        const long units = (((long)row_count + 63) / 64 + kBreedUnit - 1) / kBreedUnit;
+        if (blocks > units) blocks = units;
+    }
     const size_t lds_groups = (size_t)(kRepBlock / kGroupLanes) * gp_len * 8;
     if (groups_on && gp_len % 4 == 0 && lds_groups <= 48 * 1024 && (uintptr_t)value_res % 16 == 0 && (uintptr_t)type_res % 8 == 0 &&
         (uintptr_t)size_res % 8 == 0) {

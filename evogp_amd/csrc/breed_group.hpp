@@ -21,7 +21,11 @@ struct BreedParams {
     unsigned mutate_below;
     int row_begin, row_count;  // rows [row_begin, row_begin + row_count) of the next generation are built; output and donor
                                // arrays hold exactly these rows (donor row k belongs to next-generation row row_begin + k)
+    int chunks_per_unit;       // 1: a workgroup decides and builds one chunk of 64 rows at a time; 4: every wave decides a chunk,
+                               // then the workgroup builds the four (large launches: the decision chains run four abreast)
 };
+
+constexpr int kBreedUnit = kRepBlock / 64;   // chunks a workgroup can decide at once: one per wave
 
 // sr_tc.hip: the same pass as a kernel that also compiles the rows it builds into the program records of the next fitness call
 // (*stamp != 0: launched, the stamp names the records; *stamp == 0: not possible now, nothing was launched)
@@ -35,8 +39,12 @@ struct NoBreedHook {
 // Same two phases, but BUILD works in groups of 16 lanes (replace_row.hpp): the workgroup's 16 groups build 16 rows at a
 // time, so a chunk of 64 rows is four steps of dependent memory round trips instead of sixteen.  A mutated child is staged
 // in the group's own LDS row (8 bytes per node) between the two replacements.
+// DECIDE is a chain of four dependent loads during which three of the four waves wait -- a third of a chunk's life.  In
+// launches with many chunks per workgroup (chunks_per_unit = 4) every wave decides a chunk of its own, so four chains run
+// abreast, and the workgroup then builds the four chunks; small launches keep one chunk per workgroup at a time (there are
+// not enough chunks to fill the chip otherwise).  `all_dec`: kBreedUnit tables of [10][64] decisions.
 template <class Hook>
-__device__ inline void breed_group_body(const BreedParams &a, unsigned char *breed_lds, int (*dec_s)[64], Hook &hook) {
+__device__ inline void breed_group_body(const BreedParams &a, unsigned char *breed_lds, int (*all_dec)[10][64], Hook &hook) {
     constexpr int kGroups = kRepBlock / kGroupLanes;
     const int w = uni((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -48,14 +56,20 @@ __device__ inline void breed_group_body(const BreedParams &a, unsigned char *bre
     int16_t *cs = ct + a.gp_len;
     const int nchunks = (a.row_count + 63) >> 6;
     const int row_end = a.row_begin + a.row_count;
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int cpu = uni(a.chunks_per_unit > 1 ? kBreedUnit : 1);
+    const int nunits = (nchunks + cpu - 1) / cpu;
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+      {
+        // ---- DECIDE: wave w decides chunk u * cpu + w (one chunk per unit: wave 0 alone), as in breed_kernel ----
+        const int c = u * cpu + w;
+        const bool decider = w < cpu && c < nchunks;
+        int (*dec_s)[64] = all_dec[w < cpu ? w : 0];
         const int n0 = a.row_begin + (c << 6);
-        // ---- DECIDE (wave 0), as in breed_kernel ----
         const int n = n0 + lane;
         int li = 0, ri = 0, S = 0, p = 0, q = 0, m = 0, o = 0, dm = 0;
         unsigned r5 = 0;
         bool fallback = true, mutating = false;
-        if (w == 0 && n < row_end) {
+        if (decider && n < row_end) {
             if (n < a.n_elite) {
                 li = a.order[n];
                 li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
@@ -88,12 +102,18 @@ __device__ inline void breed_group_body(const BreedParams &a, unsigned char *bre
                 if (mutating) dm = (int)a.ds[(size_t)(n - a.row_begin) * a.gp_len];
             }
         }
-        if (w == 0) {
+        if (decider) {
             dec_s[0][lane] = li; dec_s[1][lane] = ri; dec_s[2][lane] = S; dec_s[3][lane] = p; dec_s[4][lane] = q;
             dec_s[5][lane] = m; dec_s[6][lane] = o; dec_s[7][lane] = dm; dec_s[8][lane] = (int)r5;
             dec_s[9][lane] = (fallback ? 1 : 0) | (mutating ? 2 : 0);
         }
+      }
         __syncthreads();
+      for (int cc = 0; cc < cpu; ++cc) {
+        const int c = u * cpu + cc;
+        if (c >= nchunks) break;
+        int (*dec_s)[64] = all_dec[cc];
+        const int n0 = a.row_begin + (c << 6);
         // ---- BUILD: 16 rows per step ----
         const int rows = row_end - n0 < 64 ? row_end - n0 : 64;
         for (int l0 = 0; l0 < rows; l0 += kGroups) {
@@ -138,8 +158,14 @@ __device__ inline void breed_group_body(const BreedParams &a, unsigned char *bre
                 d[0] = li_; d[1] = ri_; d[2] = p_; d[3] = q_; d[4] = mu ? 1 : 0; d[5] = pm;
             }
         }
-        __syncthreads();  // the next chunk's decisions overwrite dec_s; every row of the chunk is written
-        hook.chunk_done(a, n0, rows);
+      }
+        __syncthreads();  // the next unit's decisions overwrite the tables; every row of the unit's chunks is written
+      for (int cc = 0; cc < cpu; ++cc) {
+        const int c = u * cpu + cc;
+        if (c >= nchunks) break;
+        const int n0 = a.row_begin + (c << 6);
+        hook.chunk_done(a, n0, row_end - n0 < 64 ? row_end - n0 : 64);
+      }
     }
 }
 

@@ -289,6 +289,14 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
     const int lane = threadIdx.x & 63;
     // only_marked 1: behind the register kernels, the trees they marked too deep; 2: behind the threaded code alone (more
     // variables than the register kernels take), every tree it left marked
+    // 3: the ONLY follow-up behind the threaded code when the launch hints skipped the general compiler and / or the FULL register
+    // build: every tree that still carries a sentinel (too deep, heavy / run-time bail-out, left for the general compiler); it also
+    // reports the call's marks for the hints of later calls
+    if (only_marked == 3 && p.marks) {
+        const bool heavy = marks_pending(p, 0), general = marks_pending(p, 4);
+        if (p.hint_words && blockIdx.x == 0 && lane == 0) { p.hint_words[0] = heavy ? 1u : 0u; p.hint_words[1] = general ? 1u : 0u; }
+        if (!heavy && !general && uni((int)p.marks[1]) == 0) return;
+    }
     if (only_marked == 1 && p.marks && uni((int)p.marks[1]) == 0) return;  // no tree needs the general path
     if (only_marked == 2 && p.marks && !marks_pending(p, 0) && uni((int)p.marks[1]) == 0) return;
     float stk[kMaxStack + 2];
@@ -347,7 +355,8 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
         bool hit = false;
         if (t < c1) {
             const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
-            hit = f2bits(*mark) == kSentinelDeep || (only_marked == 2 && f2bits(*mark) == kSentinelHeavy);
+            const uint32_t w = f2bits(*mark);
+            hit = w == kSentinelDeep || (only_marked >= 2 && w == kSentinelHeavy) || (only_marked == 3 && w == kSentinelGeneral);
         }
         unsigned long long m = __ballot(hit);
         while (m) {
@@ -419,6 +428,7 @@ static std::mutex g_chain_mu;  // one for both instantiations of run_population:
 template <bool STORE>
 static int run_population(const SrParams &p_in, hipStream_t stream) {
     SrParams p = p_in;
+    p.hint_general = 1; p.hint_heavy = 1; p.hint_words = nullptr;   // launch everything unless the hints below say otherwise
     // The scratch block handed out below was zeroed by the previous call's first kernel ON THE SAME STREAM; two host
     // threads feeding one stream must therefore not interleave their acquire + launch sequences.
     std::lock_guard<std::mutex> chain_lock(g_chain_mu);
@@ -469,6 +479,10 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         std::lock_guard<std::mutex> pl(g_prof_mu);
         g_prof.push_back(prof);
     };
+    if (!STORE && asm_depth == 3 && !mo && !profiling) {   // (per-stage profiling keeps the full launch sequence)
+        const TcHints h = tc_hints();
+        p.hint_general = h.general ? 1 : 0; p.hint_heavy = h.heavy ? 1 : 0; p.hint_words = h.device_words;
+    }
     if (!STORE && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
         p.stats = g_stats;
@@ -480,6 +494,8 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     if (tc_done && mo) {  // multi-output trees the threaded code left marked: FULL register build, then the general kernel
         if (p.D >= 128) e = p.var_len <= 16 ? launch_fast<2, 16, 16, true, 8, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<2, 16, 32, true, 8, STORE, false>(p, 1, stream, p.marks + 3);
         else e = p.var_len <= 16 ? launch_fast<1, 32, 16, true, 16, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<1, 32, 32, true, 16, STORE, false>(p, 1, stream, p.marks + 3);
+    } else if (tc_done && !p.hint_heavy) {
+        e = hipSuccess;   // no heavy marks for a while: whatever this call marks is taken by the scratch-stack kernel below (mode 3)
     } else if (tc_done) {
         if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
         else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
@@ -499,7 +515,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         e = p.var_len <= 16 ? launch_pair<1, 32, 16, true, 16, STORE>(p, stream) : launch_pair<1, 32, 32, true, 16, STORE>(p, stream);
     }
     if (e != hipSuccess) return (int)e;
-    e = launch_general<STORE>(p, 1, stream);
+    e = launch_general<STORE>(p, tc_done && !mo && p.hint_words ? 3 : 1, stream);
     prof_done(tc_done);
     return (int)e;
 }
@@ -513,6 +529,7 @@ hipError_t run_argmax_count_threaded(const SrParams &p_in, const int *labels, un
     static const int asm_depth = env_int("EVOGP_SR_ASM", EVOGP_SR_DEFAULT_ASM);
     if (asm_depth != 3) return hipSuccess;
     SrParams p = p_in;
+    p.hint_general = 1; p.hint_heavy = 1; p.hint_words = nullptr;
     std::lock_guard<std::mutex> chain_lock(g_chain_mu);   // (the call-scratch chain of run_population)
     hipError_t e;
     p.marks = acquire_call_scratch(stream, &p.zero_next, &e);

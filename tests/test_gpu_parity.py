@@ -636,3 +636,14 @@ def test_sr_fitness_sqrt_exp_log_inv_handlers_match_the_register_kernels(g, orac
     assert_close_classes(got, ref, 1e-4, what=f"sqrt/exp/log/inv vs batch_evaluate, D={D}")
     want, tol, unst = per_tree_tolerance(oracle, (v, t, s), X, y)
     assert_within_sensitivity(got, want, tol, unst, "sqrt/exp/log/inv vs oracle", max_unstable=0.15, min_tight=0.2)
+
+
+def test_sr_fitness_launch_hints_never_change_results():
+    """The launch hints (csrc/sr_tc.hip tc_hints; opt-in, EVOGP_TC_HINTS=1): tests/tools/hints_check.py in a process of its own"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "hints_check.py")], cwd=root, capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, EVOGP_TC_HINTS="1"))
+    assert r.returncode == 0 and "hints ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
