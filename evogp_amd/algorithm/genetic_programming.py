@@ -102,7 +102,13 @@ class GeneticProgramming:
         if type(self.selection) is DefaultSelection:
             elites, parents = default_lists(fitness.to(torch.float32), *self.selection.counts(pop))
         else:
-            elites, parents = self.selection(f, fitness)
+            lists = None
+            counter_based = getattr(self.selection, "counter_based", None)
+            if counter_based is not None and os.environ.get("EVOGP_NATIVE_TOURNAMENT", "1") != "0":
+                # (TournamentSelection with its default arguments: two launches; the words are keyed by torch's seed and a step counter)
+                self._steps = getattr(self, "_steps", 0) + 1
+                lists = counter_based(fitness, torch.initial_seed() & 0x7FFFFFFFFFFF, self._steps)
+            elites, parents = lists if lists is not None else self.selection(f, fitness)
             elites, parents = elites.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous()
         n_elite = elites.numel()
         n_new = pop - n_elite

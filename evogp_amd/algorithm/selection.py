@@ -208,3 +208,29 @@ class TournamentSelection(_SelectorSelection):
                  elite_cnt: Optional[int] = None):
         super().__init__(TournamentSelector(tournament_size, best_probability, replace), survivor_rate, elite_rate,
                          survivor_cnt, elite_cnt)
+
+    def counter_based(self, fitness: torch.Tensor, seed: int, generation: int):
+        """The operator with its contenders taken from the counter-based words of evogp_amd/parallel.py (contender k of tournament
+        i = word(seed, generation, 16 + k, i) % n) instead of torch's generator: every rank of a sharded run names the same
+        contenders without sharing generator state, and on a GPU the whole selection is two launches (csrc/select.hip
+        tournament_kernel + the radix select for the elites).  Same distribution as ``__call__`` (tournament.py:59-133).  Only for
+        the reference's default arguments — contenders with replacement, the best one wins; None otherwise (the caller then runs
+        ``__call__`` under a seeded generator)."""
+        sel = self.selector
+        if not sel.replace or sel.best_p < 1:
+            return None
+        from ..parallel import _select_key, default_lists, random_words
+
+        n = fitness.shape[0]
+        n_elite, n_surv = self.counts(n)
+        if n_surv < 1:
+            return None
+        fit = fitness.to(torch.float32).contiguous()
+        if fit.is_cuda:
+            parents = torch.ops.evogp_hip.tournament_select(fit, n_surv, sel.t_size, seed, generation)
+        else:
+            c = random_words(seed, generation, sel.t_size, 0, n_surv, fit.device, first_row=16).to(torch.int64) % n     # (t, n_surv)
+            best = _select_key(fit)[c].argmax(dim=0, keepdim=True)                                                        # first of equal keys
+            parents = c.gather(0, best).squeeze(0).to(torch.int32)
+        elites = default_lists(fit, n_elite, max(n_elite, 1))[0] if n_elite > 0 else torch.empty(0, dtype=torch.int32, device=fit.device)
+        return elites.contiguous(), parents.contiguous()

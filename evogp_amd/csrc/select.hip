@@ -240,9 +240,46 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
     }
 }
 
+// ---- tournaments (selection/tournament.py:59-133 with its defaults: contenders drawn with replacement, the best one wins) --------
+// winners[i] = the best of t_size contenders of tournament i; contender k of tournament i is tree
+//     word(seed, generation, 16 + k, i) % n        (word: the counter-based hash of breed.hip / parallel.random_words)
+// so every rank of a sharded run -- and the torch formulation for tensors that are not on a GPU -- names the same contenders.
+// "Best" is the order of select_key (NaN worst, -0 = +0); of equal contenders the first drawn wins, as torch.argmax does.
+// One lane per tournament: t_size dependent-free gathers from a vector that lives in L2 (4 MB at 1 M trees).
+__host__ __device__ inline unsigned long long tmix64(unsigned long long x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void tournament_kernel(const float *fitness, unsigned n, unsigned n_tournaments, unsigned t_size,
+                                                         unsigned long long base, int *winners) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tournaments) return;
+    uint32_t best_key = 0u;
+    unsigned best = 0u;
+    for (unsigned k = 0; k < t_size; ++k) {
+        const unsigned long long x = tmix64(base + ((unsigned long long)(16u + k) << 40) + (unsigned long long)i);
+        const unsigned c = (unsigned)((((x >> 33) & 0x7FFFFFFFull) % 0x7FFFFFFFull) % n);
+        const uint32_t key = select_key(fitness[c]);
+        if (k == 0u || key > best_key) { best_key = key; best = c; }
+    }
+    winners[i] = (int)best;
+}
+
 } // namespace evogp
 
 using namespace evogp;
+
+extern "C" int evogp_hip_tournament_select(unsigned n, unsigned n_tournaments, unsigned t_size, long long seed, long long generation,
+                                           const float *fitness, int *winners, evogp_stream_t stream_) {
+    if (n == 0 || n_tournaments == 0 || t_size == 0 || t_size > (1u << 20)) return EVOGP_E_BADARG;
+    if (!fitness || !winners) return EVOGP_E_NULLPTR;
+    const unsigned long long base = tmix64((unsigned long long)(seed * 1000003ll + generation));
+    hipLaunchKernelGGL(tournament_kernel, dim3((n_tournaments + 255) / 256), dim3(256), 0, (hipStream_t)stream_, fitness, n, n_tournaments, t_size,
+                       base, winners);
+    return (int)hipGetLastError();
+}
 
 extern "C" size_t evogp_hip_select_workspace_bytes(void) { return (size_t)kSelWords * sizeof(unsigned); }
 

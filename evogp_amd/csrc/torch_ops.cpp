@@ -314,6 +314,19 @@ Tensor select_survivors(const Tensor &fitness, int64_t n_elite, int64_t n_keep) 
     return order;
 }
 
+// int32[n_tournaments]: the winner of every tournament of t_size counter-based contenders (select.hip)
+Tensor tournament_select(const Tensor &fitness, int64_t n_tournaments, int64_t t_size, int64_t seed, int64_t generation) {
+    TORCH_CHECK(fitness.is_cuda() && fitness.is_contiguous() && fitness.scalar_type() == at::kFloat && fitness.dim() == 1,
+                "fitness must be a contiguous float32 CUDA vector");
+    TORCH_CHECK(fitness.size(0) > 0 && n_tournaments > 0 && t_size > 0, "need a population, tournaments and contenders");
+    const c10::Device dev = fitness.device();
+    c10::DeviceGuard guard(dev);
+    Tensor winners = at::empty({n_tournaments}, at::TensorOptions().dtype(at::kInt).device(dev));
+    check_rc(evogp_hip_tournament_select((unsigned)fitness.size(0), (unsigned)n_tournaments, (unsigned)t_size, seed, generation,
+                                         fitness.data_ptr<float>(), winners.data_ptr<int>(), current_stream(dev)), "tournament_select");
+    return winners;
+}
+
 void check_order(const Tensor &order, int64_t need, const c10::Device &dev) {
     TORCH_CHECK(order.is_cuda() && order.is_contiguous() && order.scalar_type() == at::kInt && order.dim() == 1 && order.size(0) >= need &&
                     order.device() == dev,
@@ -475,6 +488,7 @@ TORCH_LIBRARY(evogp_hip, m) {
           " Tensor workspace, bool with_fallback, Tensor variables) -> Tensor results");
     m.def("random_words(int seed, int generation, int rows, int n_cols, int lo, int hi, Device device) -> Tensor");
     m.def("select_survivors(Tensor fitness, int n_elite, int n_keep) -> Tensor");
+    m.def("tournament_select(Tensor fitness, int n_tournaments, int t_size, int seed, int generation) -> Tensor");
     m.def("breed_default(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor order, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size,"
           " bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)");
@@ -506,4 +520,5 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("breed_rows_compiled", &breed_rows_compiled);
     m.impl("tree_SR_fitness_stamped", &tree_SR_fitness_stamped);
     m.impl("select_survivors", &select_survivors);
+    m.impl("tournament_select", &tournament_select);
 }

@@ -134,10 +134,11 @@ def _mix64(x: torch.Tensor) -> torch.Tensor:
     return x ^ ((x >> 31) & 0x1FFFFFFFF)
 
 
-def random_words(seed: int, generation: int, rows: int, lo: int, hi: int, device) -> torch.Tensor:
-    """int32[rows][hi - lo]: word k of offspring i in [lo, hi), uniform in [0, 2^31 - 1) like torch.randint(0, 2^31 - 1)"""
+def random_words(seed: int, generation: int, rows: int, lo: int, hi: int, device, first_row: int = 0) -> torch.Tensor:
+    """int32[rows][hi - lo]: word k (first_row <= k < first_row + rows) of offspring i in [lo, hi), uniform in [0, 2^31 - 1) like
+    torch.randint(0, 2^31 - 1)"""
     i = torch.arange(lo, hi, dtype=torch.int64, device=device)[None, :]
-    k = torch.arange(rows, dtype=torch.int64, device=device)[:, None]
+    k = torch.arange(first_row, first_row + rows, dtype=torch.int64, device=device)[:, None]
     base = _mix64(torch.tensor([seed * 1000003 + generation], dtype=torch.int64, device=device))
     x = _mix64(base + (k << 40) + i)
     return (((x >> 33) & 0x7FFFFFFF) % (2**31 - 1)).to(torch.int32)
@@ -214,6 +215,13 @@ class ShardedGeneticProgramming:
             assert n_surv >= 1, "the selection leaves no parent (crossover/default.py:40 draws from an empty range)"
             return default_lists(fit_all, n_elite, n_surv)
         dev = fit_all.device
+        counter_based = getattr(self.selection, "counter_based", None)
+        if counter_based is not None and os.environ.get("EVOGP_NATIVE_TOURNAMENT", "1") != "0":
+            # operators that can draw from the counter-based words (TournamentSelection with its default arguments): one launch on a
+            # GPU, the same numbers from torch ops elsewhere, no generator state
+            lists = counter_based(fit_all, self.seed, self.generation)
+            if lists is not None:
+                return lists
         with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else [], enabled=True):
             torch.manual_seed(int(_mix64(torch.tensor([self.seed * 1000003 + self.generation], dtype=torch.int64))[0]) & 0x7FFFFFFFFFFF)
             try:

@@ -200,6 +200,15 @@ size_t evogp_hip_select_workspace_bytes(void);
 int evogp_hip_select(unsigned n, unsigned n_elite, unsigned n_keep, const float *fitness, int *order, void *zeroed_workspace,
                      evogp_stream_t stream);
 
+/* Tournament selection in one launch (no counterpart in the reference's ABI; src/evogp/algorithm/selection/tournament.py:59-133 with its
+ * default arguments, which is also the setting of example/uci_sr.py:73-75: contenders drawn WITH replacement, the best contender
+ * wins): winners[i] = the tree of highest fitness among t_size contenders, contender k of tournament i being tree
+ * hash(seed, generation, 16 + k, i) % n -- the counter-based words of evogp_hip_random_words, so every rank of a sharded run names
+ * the same contenders (evogp_amd/parallel.py random_words gives the same numbers on any device).  NaN is the worst fitness; of
+ * equal contenders the first drawn wins (torch.argmax).  winners: i32[n_tournaments]. */
+int evogp_hip_tournament_select(unsigned n, unsigned n_tournaments, unsigned t_size, long long seed, long long generation,
+                                const float *fitness, int *winners, evogp_stream_t stream);
+
 /* Non-replicating batch evaluation (replaces the repeat_interleave + tree_evaluate
  * composition of src/evogp/tree/forest.py:143-176): results[t][d][:] = tree_t(variables[d][:]),
  * variables: f32[D][var_len], results: f32[pop][D][out_len]. */

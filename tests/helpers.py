@@ -128,6 +128,11 @@ def sensitivity(oracle, fn, base_rtol=1e-5, ulps=3, seeds=4):
             unstable |= (np.isnan(j) != np.isnan(want)) | (np.isinf(j) != np.isinf(want))
     finally:
         oracle.set_jitter(0)
+    # an entry that a 3-ulp nudge of its library calls moves by more than 1 % carries no digits (condition number beyond 3e4:
+    # tan next to a pole, a / (sin - sin)): the perturbation is no longer in the linear regime "twice the spread" assumes, a
+    # fourth ulp can cross the pole.  Such entries are compared by class only, like those whose class itself flips
+    with np.errstate(all="ignore"):
+        unstable |= spread > 0.01 * np.abs(want.astype(np.float64))
     return want, base_rtol * np.abs(want.astype(np.float64)) + 2.0 * spread, unstable
 
 

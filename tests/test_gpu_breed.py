@@ -223,7 +223,7 @@ def test_rollout_problem_graph_replay_matches_eager(g):
         print(f"rollout {name}: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per step at pop 20000 (500 steps, capture included)")
 
 
-@pytest.mark.parametrize("selection", ["default", "more_elites_than_parents", "tournament_replace", "tournament_noreplace"])
+@pytest.mark.parametrize("selection", ["default", "more_elites_than_parents", "tournament_replace", "tournament_noreplace", "tournament_default_args"])
 def test_sharded_native_step_union_equals_single_device(g, selection):
     """SURVEY.md §8e on one GPU: the rows the ranks of a G-way sharded run would build (same gathered fitness, same seed)
     concatenate to the single-device next generation, bit for bit, for G = 1, 2, 3, 8 — under DefaultSelection and under the
@@ -237,6 +237,7 @@ def test_sharded_native_step_union_equals_single_device(g, selection):
     from evogp_amd.tree import Forest, GenerateDescriptor
 
     make = {"default": lambda: DefaultSelection(0.3, elite_rate=0.01),
+            "tournament_default_args": lambda: TournamentSelection(20, survivor_rate=0.5, elite_rate=0.1),
             "more_elites_than_parents": lambda: DefaultSelection(0.02, elite_cnt=500),
             "tournament_replace": lambda: TournamentSelection(3, best_probability=0.9, replace=True, survivor_rate=0.5, elite_rate=0.01),
             "tournament_noreplace": lambda: TournamentSelection(5, best_probability=1, replace=False, survivor_rate=0.8, elite_cnt=7)}[selection]
@@ -368,6 +369,33 @@ def test_select_survivors_equals_the_sets_of_a_stable_sort(g):
                 want = torch.cat([torch.sort(rank[:n_elite]).values, torch.sort(rank[n_elite:n_keep]).values]).to(torch.int32)
                 assert torch.equal(got, want), (n, n_elite, n_keep, int((got != want).sum()))
                 assert torch.equal(select_order(x, n_elite, n_keep), want)   # the torch definition used off the GPU agrees, NaN and -0 included
+
+
+def test_tournament_kernel_equals_the_torch_formulation(g):
+    """csrc/select.hip tournament_kernel (TournamentSelection with the reference's default arguments: contenders with replacement
+    from the counter-based words, the best one wins) against the same selection written in torch ops on the CPU: the same winners,
+    ties to the first contender drawn, NaN never preferred; and the elites are the best trees"""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm.selection import TournamentSelection
+
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(3)
+    for n, t, seed, generation in ((1000, 3, 0, 0), (100_000, 20, 1234, 7), (1_000_003, 5, 2**40 + 1, 99), (17, 50, 5, 5)):
+        fit = torch.round(torch.randn(n, generator=gen) * 4) / 4                  # many ties
+        fit[torch.rand(n, generator=gen) < 0.05] = float("nan")
+        fit[torch.rand(n, generator=gen) < 0.02] = float("-inf")
+        sel = TournamentSelection(t, survivor_rate=0.5, elite_rate=0.01)
+        e_cpu, p_cpu = sel.counter_based(fit, seed, generation)
+        e_gpu, p_gpu = sel.counter_based(fit.to(dev), seed, generation)
+        assert torch.equal(p_gpu.cpu(), p_cpu), (n, t, int((p_gpu.cpu() != p_cpu).sum()))
+        assert torch.equal(e_gpu.cpu(), e_cpu)
+        assert p_cpu.numel() == n // 2 and int(p_cpu.min()) >= 0 and int(p_cpu.max()) < n
+        won = fit[p_cpu.long()]
+        assert float(torch.nan_to_num(won, nan=-1e9, neginf=-1e9).mean()) > float(torch.nan_to_num(fit, nan=-1e9, neginf=-1e9).mean())
+    assert TournamentSelection(4, best_probability=0.9).counter_based(fit, 0, 0) is None          # not the default arguments:
+    assert TournamentSelection(4, replace=False).counter_based(fit, 0, 0) is None                 # the operator's own torch program
 
 
 def test_native_random_words_equal_the_python_definition(g):

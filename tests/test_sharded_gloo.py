@@ -28,10 +28,12 @@ def _selection(name):
         "default_more_elites_than_parents": lambda: DefaultSelection(survival_rate=0.05, elite_cnt=70),   # legal, order[:n_surv] was wrong
         "tournament_replace": lambda: TournamentSelection(3, best_probability=0.9, replace=True, survivor_rate=0.5, elite_rate=0.01),
         "tournament_noreplace": lambda: TournamentSelection(4, best_probability=1, replace=False, survivor_rate=0.7, elite_cnt=3),
+        # the reference's default arguments (example/uci_sr.py:73-75): contenders from the counter-based words, no generator state
+        "tournament_default_args": lambda: TournamentSelection(tournament_size=20, survivor_rate=0.5, elite_rate=0.1),
     }[name]()
 
 
-SELECTIONS = ["default", "default_more_elites_than_parents", "tournament_replace", "tournament_noreplace"]
+SELECTIONS = ["default", "default_more_elites_than_parents", "tournament_replace", "tournament_noreplace", "tournament_default_args"]
 MODES = [("rows", "exact"), ("rows", "bound"), ("packed", "exact")]
 
 
