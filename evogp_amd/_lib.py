@@ -32,6 +32,8 @@ PROTOTYPES = {
     "evogp_hip_breed_default_table": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_breed_lists": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_breed_lists_compiled": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "evogp_hip_generate_masked_hashed": [_u, _u, _u, _u, _u, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_longlong, C.c_longlong, _u, _vp],
+    "evogp_hip_breed_lists_hashed": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, C.c_longlong, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "evogp_hip_sr_fitness_stamped": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_ulonglong, _vp],
     "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_batch_argmax_count": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

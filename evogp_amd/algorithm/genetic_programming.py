@@ -105,25 +105,29 @@ class GeneticProgramming:
             lists = None
             counter_based = getattr(self.selection, "counter_based", None)
             if counter_based is not None and os.environ.get("EVOGP_NATIVE_TOURNAMENT", "1") != "0":
-                # (TournamentSelection with its default arguments: two launches; the words are keyed by torch's seed and a step counter)
-                self._steps = getattr(self, "_steps", 0) + 1
-                lists = counter_based(fitness, torch.initial_seed() & 0x7FFFFFFFFFFF, self._steps)
+                # (TournamentSelection with its default arguments: two launches; contenders from the counter-based words of this step)
+                if not hasattr(self, "_word_seed"):
+                    self._word_seed = int(torch.randint(0, 2**40, (1,)).item())
+                lists = counter_based(fitness, self._word_seed, getattr(self, "_steps", 0) + 1)
             elites, parents = lists if lists is not None else self.selection(f, fitness)
             elites, parents = elites.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous()
         n_elite = elites.numel()
         n_new = pop - n_elite
-        # one draw: six 31-bit words per offspring, and two more as the keys of the donor trees' streams (the reference draws
-        # the keys below 10^6, tree/forest.py:51-57; they only seed a hash, and a launch of their own costs 4-5 us)
-        words = torch.randint(0, 2**31 - 1, (6 * n_new + 2,), dtype=torch.int32, device=dev)
-        rnd = words[:6 * n_new].view(6, n_new)
-        keys = words[6 * n_new:].view(torch.uint32)
+        # no draw at all: the donor kernel and the breeding pass compute the six words of offspring i (and the two generation keys) as
+        # hash(seed, step, word, i) themselves (csrc/evogp_defs.hpp counter_word).  The seed is drawn ONCE per object from torch's
+        # CPU generator (reproducible under torch.manual_seed, independent between objects, no device sync); the reference draws
+        # seven tensors per generation (crossover/default.py:40-58, mutation/default.py:43-66, tree/forest.py:51-57)
+        if not hasattr(self, "_word_seed"):
+            self._word_seed = int(torch.randint(0, 2**40, (1,)).item())
+        self._steps = getattr(self, "_steps", 0) + 1
         below = int(min(max(self.mutation.mutation_rate, 0.0), 1.0) * (2**31 - 1))
         d = self.mutation.descriptor
         value, ntype, size = f._tensors()
-        donors = torch.ops.evogp_hip.tree_generate_masked(
-            n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
-            d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, rnd[4], below)
-        # (the pass also compiles the rows it builds for the next tree_SR_fitness call where the engine can: csrc/sr_tc.hip)
-        nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_compiled(pop, L, value, ntype, size, elites, parents, rnd, below, *donors, 0, pop)
+        donors = torch.ops.evogp_hip.tree_generate_masked_hashed(
+            n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob,
+            d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, self._word_seed, self._steps, below)
+        # (the pass also compiles the rows it builds for the next tree_SR_fitness call when that experiment is on: csrc/sr_tc.hip)
+        nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elites, parents, self._word_seed, self._steps,
+                                                                  below, *donors, 0, pop)
         self.forest = Forest(f.input_len, f.output_len, nv, nt, ns).set_compiled_records(stamp)
         return self.forest

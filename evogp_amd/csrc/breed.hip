@@ -60,9 +60,16 @@ __global__ __launch_bounds__(kRepBlock) void breed_kernel(BreedParams a) {
                 S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
             } else {
                 const int i = n - a.n_elite;
-                const unsigned r0 = (unsigned)a.rnd[i], r1 = (unsigned)a.rnd[a.n_new + i], r2 = (unsigned)a.rnd[2 * a.n_new + i],
-                               r3 = (unsigned)a.rnd[3 * a.n_new + i], r4 = (unsigned)a.rnd[4 * a.n_new + i];
-                r5 = (unsigned)a.rnd[5 * a.n_new + i];
+                unsigned r0, r1, r2, r3, r4;
+                if (a.hashed) {
+                    r0 = counter_word(a.hash_base, 0u, (unsigned long long)i); r1 = counter_word(a.hash_base, 1u, (unsigned long long)i);
+                    r2 = counter_word(a.hash_base, 2u, (unsigned long long)i); r3 = counter_word(a.hash_base, 3u, (unsigned long long)i);
+                    r4 = counter_word(a.hash_base, 4u, (unsigned long long)i); r5 = counter_word(a.hash_base, 5u, (unsigned long long)i);
+                } else {
+                    r0 = (unsigned)a.rnd[i]; r1 = (unsigned)a.rnd[a.n_new + i]; r2 = (unsigned)a.rnd[2 * a.n_new + i];
+                    r3 = (unsigned)a.rnd[3 * a.n_new + i]; r4 = (unsigned)a.rnd[4 * a.n_new + i];
+                    r5 = (unsigned)a.rnd[5 * a.n_new + i];
+                }
                 li = a.parents[r0 % (unsigned)a.n_surv];
                 ri = a.parents[r1 % (unsigned)a.n_surv];
                 li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);
@@ -188,12 +195,38 @@ extern "C" int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, i
                                           row_begin, row_count, nullptr, stream_);
 }
 
+static int breed_impl(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value, const int16_t *type,
+                      const int16_t *size, const int *elite_rows, const int *parent_rows, const int *rnd, int hashed,
+                      unsigned long long hash_base, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                      const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res, int *decisions, int row_begin,
+                      int row_count, unsigned long long *records_stamp, evogp_stream_t stream_);
+
 extern "C" int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
                                               const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
                                               const int *rnd, unsigned mutate_below, const float *donor_value,
                                               const int16_t *donor_type, const int16_t *donor_size, float *value_res,
                                               int16_t *type_res, int16_t *size_res, int *decisions, int row_begin, int row_count,
                                               unsigned long long *records_stamp, evogp_stream_t stream_) {
+    return breed_impl(pop_size, table_rows, gp_len, n_elite, n_surv, value, type, size, elite_rows, parent_rows, rnd, 0, 0ull, mutate_below,
+                      donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions, row_begin, row_count, records_stamp, stream_);
+}
+
+extern "C" int evogp_hip_breed_lists_hashed(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
+                                            const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
+                                            long long seed, long long generation, unsigned mutate_below, const float *donor_value,
+                                            const int16_t *donor_type, const int16_t *donor_size, float *value_res, int16_t *type_res,
+                                            int16_t *size_res, int *decisions, int row_begin, int row_count,
+                                            unsigned long long *records_stamp, evogp_stream_t stream_) {
+    return breed_impl(pop_size, table_rows, gp_len, n_elite, n_surv, value, type, size, elite_rows, parent_rows, nullptr, 1,
+                      counter_base(seed, generation), mutate_below, donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions,
+                      row_begin, row_count, records_stamp, stream_);
+}
+
+static int breed_impl(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value, const int16_t *type,
+                      const int16_t *size, const int *elite_rows, const int *parent_rows, const int *rnd, int hashed,
+                      unsigned long long hash_base, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                      const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res, int *decisions, int row_begin,
+                      int row_count, unsigned long long *records_stamp, evogp_stream_t stream_) {
     const int *order = elite_rows;
     if (records_stamp) *records_stamp = 0ull;
     // n_surv may exceed pop_size: a selection that draws with replacement may name more parents than there are trees
@@ -201,11 +234,11 @@ extern "C" int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int 
         return EVOGP_E_BADARG;
     if (!value || !type || !size || !parent_rows || (n_elite > 0 && !order) || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
     const int n_new = pop_size - n_elite;
-    if (n_new > 0 && !rnd) return EVOGP_E_NULLPTR;
+    if (n_new > 0 && !rnd && !hashed) return EVOGP_E_NULLPTR;
     if (mutate_below != 0 && n_new > 0 && (!donor_value || !donor_type || !donor_size)) return EVOGP_E_NULLPTR;
     if (row_begin < 0 || row_count <= 0 || row_begin + row_count > pop_size) return EVOGP_E_BADARG;
     BreedParams a{value, type, size, order, parent_rows, rnd, donor_value, donor_type, donor_size, value_res, type_res, size_res,
-                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, table_rows, mutate_below, row_begin, row_count, 1};
+                  decisions, pop_size, gp_len, n_elite, n_surv, n_new, table_rows, mutate_below, row_begin, row_count, hashed, hash_base, 1};
     const DeviceInfo &dev = device_info();
     long blocks = ((long)row_count + 63) / 64;  // one workgroup per 64 rows
     const long cap = (long)dev.num_cus * 8 * 4;
@@ -242,18 +275,11 @@ extern "C" int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int 
 // evogp_amd/parallel.py random_words (which serves the CPU paths and the tests).  A rank of a sharded run fills exactly the
 // columns of its own offspring; every rank computes the same word for the same offspring whatever the world size.
 namespace evogp {
-__host__ __device__ inline unsigned long long mix64(unsigned long long x) {
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
 __global__ void random_words_kernel(unsigned long long base, int rows, long long n_cols, long long lo, long long hi, int *out) {
     const long long n = hi - lo;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n * rows; e += (long long)gridDim.x * blockDim.x) {
         const long long k = e / n, i = lo + (e - k * n);
-        const unsigned long long x = mix64(base + ((unsigned long long)k << 40) + (unsigned long long)i);
-        out[k * n_cols + i] = (int)(((x >> 33) & 0x7FFFFFFFull) % 0x7FFFFFFFull);
+        out[k * n_cols + i] = (int)counter_word(base, (unsigned)k, (unsigned long long)i);
     }
 }
 }  // namespace evogp
@@ -263,7 +289,7 @@ extern "C" int evogp_hip_random_words(long long seed, long long generation, int 
     if (rows <= 0 || n_cols <= 0 || lo < 0 || hi > n_cols || lo > hi) return EVOGP_E_BADARG;
     if (!out) return EVOGP_E_NULLPTR;
     if (hi == lo) return EVOGP_OK;
-    const unsigned long long base = evogp::mix64((unsigned long long)(seed * 1000003ll + generation));
+    const unsigned long long base = evogp::counter_base(seed, generation);
     const long long n = (hi - lo) * rows;
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -21,6 +21,8 @@ struct BreedParams {
     unsigned mutate_below;
     int row_begin, row_count;  // rows [row_begin, row_begin + row_count) of the next generation are built; output and donor
                                // arrays hold exactly these rows (donor row k belongs to next-generation row row_begin + k)
+    int hashed;                // != 0: no rnd array: word k of offspring i is counter_word(hash_base, k, i) (evogp_defs.hpp)
+    unsigned long long hash_base;
     int chunks_per_unit;       // 1: a workgroup decides and builds one chunk of 64 rows at a time; 4: every wave decides a chunk,
                                // then the workgroup builds the four (large launches: the decision chains run four abreast)
 };
@@ -78,9 +80,16 @@ __device__ inline void breed_group_body(const BreedParams &a, unsigned char *bre
                 S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
             } else {
                 const int i = n - a.n_elite;
-                const unsigned r0 = (unsigned)a.rnd[i], r1 = (unsigned)a.rnd[a.n_new + i], r2 = (unsigned)a.rnd[2 * a.n_new + i],
-                               r3 = (unsigned)a.rnd[3 * a.n_new + i], r4 = (unsigned)a.rnd[4 * a.n_new + i];
-                r5 = (unsigned)a.rnd[5 * a.n_new + i];
+                unsigned r0, r1, r2, r3, r4;
+                if (a.hashed) {
+                    r0 = counter_word(a.hash_base, 0u, (unsigned long long)i); r1 = counter_word(a.hash_base, 1u, (unsigned long long)i);
+                    r2 = counter_word(a.hash_base, 2u, (unsigned long long)i); r3 = counter_word(a.hash_base, 3u, (unsigned long long)i);
+                    r4 = counter_word(a.hash_base, 4u, (unsigned long long)i); r5 = counter_word(a.hash_base, 5u, (unsigned long long)i);
+                } else {
+                    r0 = (unsigned)a.rnd[i]; r1 = (unsigned)a.rnd[a.n_new + i]; r2 = (unsigned)a.rnd[2 * a.n_new + i];
+                    r3 = (unsigned)a.rnd[3 * a.n_new + i]; r4 = (unsigned)a.rnd[4 * a.n_new + i];
+                    r5 = (unsigned)a.rnd[5 * a.n_new + i];
+                }
                 li = a.parents[r0 % (unsigned)a.n_surv];
                 ri = a.parents[r1 % (unsigned)a.n_surv];
                 li = li < 0 ? 0 : (li >= a.table_rows ? a.table_rows - 1 : li);

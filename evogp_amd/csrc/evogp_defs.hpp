@@ -62,6 +62,23 @@ struct Taus88 {
     __host__ __device__ inline float uniform() { return (float)next() * 2.3283064365386963e-10f; }
 };
 
+// ---- counter-based random words (no counterpart in the reference, which draws with torch's generator) -----------------------------
+// word k of item i of generation g under `seed` = the splitmix64 finaliser of (mix(seed * 1000003 + g) + (k << 40) + i), reduced to
+// [0, 2^31 - 1) like torch.randint(0, 2^31 - 1): evogp_amd/parallel.py random_words is the same arithmetic in torch ops.  Rows in
+// use: 0-5 the six words of offspring i (breed.hip), 7 the two generation keys (i = 0, 1), 16 + k contender k of tournament i.
+__host__ __device__ inline unsigned long long mix64(unsigned long long x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline unsigned long long counter_base(long long seed, long long generation) {
+    return mix64((unsigned long long)(seed * 1000003ll + generation));
+}
+__host__ __device__ inline unsigned counter_word(unsigned long long base, unsigned k, unsigned long long i) {
+    const unsigned long long x = mix64(base + ((unsigned long long)k << 40) + i);
+    return (unsigned)(((x >> 33) & 0x7FFFFFFFull) % 0x7FFFFFFFull);
+}
+
 __device__ inline float bits2f(uint32_t u) { return __uint_as_float(u); }
 __device__ inline uint32_t f2bits(float f) { return __float_as_uint(f); }
 

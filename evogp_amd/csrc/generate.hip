@@ -40,7 +40,18 @@ struct GenParams {
     unsigned index_offset;
     const int *active_word;    // optional: tree n is generated only when (unsigned)active_word[n] < active_below
     unsigned active_below;
+    int hashed;                // != 0: no keys / active_word arrays -- the two keys are word (7, 0 / 1) % 10^6 and tree n is generated
+    unsigned long long hash_base;  // when word (4, n + index_offset) < active_below, of the counter-based words of (seed, generation)
 };
+
+__device__ inline bool gen_active(const GenParams &p, unsigned n) {
+    if (p.hashed) return counter_word(p.hash_base, 4u, (unsigned long long)n + p.index_offset) < p.active_below;
+    return p.active_word == nullptr || (unsigned)p.active_word[n] < p.active_below;
+}
+__device__ inline uint32_t gen_seed(const GenParams &p, unsigned n) {
+    if (p.hashed) return seed_hash(n + p.index_offset, counter_word(p.hash_base, 7u, 0ull) % 1000000u, counter_word(p.hash_base, 7u, 1ull) % 1000000u);
+    return seed_hash(n + p.index_offset, p.keys[0], p.keys[1]);
+}
 
 template <bool MO>
 __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
@@ -49,7 +60,7 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
     __shared__ float leaf_s[kMaxFullDepth + 1];
     const int tid = threadIdx.x;
     const unsigned n = blockIdx.x * kGenBlock + tid;
-    const bool active = n < p.pop && (p.active_word == nullptr || (unsigned)p.active_word[n] < p.active_below);
+    const bool active = n < p.pop && gen_active(p, n);
     if (tid < kMaxFullDepth) leaf_s[tid] = p.leaf_probs[tid];
     if (tid == kMaxFullDepth) leaf_s[tid] = 1.0f; // depths past the table are leaves
     __syncthreads();
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
     const size_t row = (size_t)n * p.gp_len;
     unsigned cnt = 0;
     if (active) {
-        Taus88 rng(seed_hash(n + p.index_offset, p.keys[0], p.keys[1]));
+        Taus88 rng(gen_seed(p, n));
         int top = 1, deepest_open = -1;
         frame_s[0][tid] = 1u; // {childs = 1, depth = 0}
         while (top > 0 && cnt < (unsigned)kMaxStack) {
@@ -178,13 +189,13 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
     for (unsigned g = 0; g < (unsigned)kGenMaxGather; ++g) {
         const unsigned idx = (blockIdx.x * gather + g) * kWave + lane;
         word[g] = 0u;
-        if (g < gather && idx < p.pop && p.active_word != nullptr) word[g] = (unsigned)p.active_word[idx];
+        if (g < gather && idx < p.pop && p.active_word != nullptr && !p.hashed) word[g] = (unsigned)p.active_word[idx];
     }
 #pragma unroll
     for (unsigned g = 0; g < (unsigned)kGenMaxGather; ++g) {
         if (g >= gather) break;
         const unsigned idx = (blockIdx.x * gather + g) * kWave + lane;
-        const bool a = idx < p.pop && (p.active_word == nullptr || word[g] < p.active_below);
+        const bool a = idx < p.pop && (p.hashed ? gen_active(p, idx) : (p.active_word == nullptr || word[g] < p.active_below));
         const unsigned long long m = __ballot(a);
         if (a) rows_s[n_rows + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = idx;
         n_rows += (unsigned)__popcll(m);
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         }
     };
 
-    Taus88 rng(seed_hash(n + p.index_offset, p.keys[0], p.keys[1]));
+    Taus88 rng(gen_seed(p, n));
     int top = 1, deepest_open = -1;
     unsigned cnt = 0, it = 0;
     frame_s[lane] = 1u;  // {childs = 1, depth = 0}
@@ -371,19 +382,43 @@ extern "C" int evogp_hip_generate(unsigned pop_size, unsigned gp_len, unsigned v
                                      tree_index_offset, nullptr, 0u, stream_);
 }
 
+static int generate_impl(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len, unsigned const_samples_len, float out_prob,
+                         float const_prob, const unsigned *keys, const float *depth2leaf_probs, const float *roulette_funcs,
+                         const float *const_samples, float *value_res, int16_t *type_res, int16_t *size_res, unsigned tree_index_offset,
+                         const int *active_word, unsigned active_below, int hashed, unsigned long long hash_base, evogp_stream_t stream_);
+
 extern "C" int evogp_hip_generate_masked(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
                                          unsigned const_samples_len, float out_prob, float const_prob, const unsigned *keys,
                                          const float *depth2leaf_probs, const float *roulette_funcs,
                                          const float *const_samples, float *value_res, int16_t *type_res, int16_t *size_res,
                                          unsigned tree_index_offset, const int *active_word, unsigned active_below,
                                          evogp_stream_t stream_) {
+    if (!keys) return EVOGP_E_NULLPTR;
+    return generate_impl(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys, depth2leaf_probs, roulette_funcs,
+                         const_samples, value_res, type_res, size_res, tree_index_offset, active_word, active_below, 0, 0ull, stream_);
+}
+
+extern "C" int evogp_hip_generate_masked_hashed(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                                unsigned const_samples_len, float out_prob, float const_prob,
+                                                const float *depth2leaf_probs, const float *roulette_funcs, const float *const_samples,
+                                                float *value_res, int16_t *type_res, int16_t *size_res, unsigned tree_index_offset,
+                                                long long seed, long long generation, unsigned active_below, evogp_stream_t stream_) {
+    return generate_impl(pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, nullptr, depth2leaf_probs, roulette_funcs,
+                         const_samples, value_res, type_res, size_res, tree_index_offset, nullptr, active_below, 1, counter_base(seed, generation),
+                         stream_);
+}
+
+static int generate_impl(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len, unsigned const_samples_len, float out_prob,
+                         float const_prob, const unsigned *keys, const float *depth2leaf_probs, const float *roulette_funcs,
+                         const float *const_samples, float *value_res, int16_t *type_res, int16_t *size_res, unsigned tree_index_offset,
+                         const int *active_word, unsigned active_below, int hashed, unsigned long long hash_base, evogp_stream_t stream_) {
     if (pop_size == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len == 0 || const_samples_len == 0)
         return EVOGP_E_BADARG;
     if (!(out_prob >= 0.0f && out_prob <= 1.0f) || !(const_prob >= 0.0f && const_prob <= 1.0f)) return EVOGP_E_BADARG;
-    if (!keys || !depth2leaf_probs || !roulette_funcs || !const_samples || !value_res || !type_res || !size_res)
+    if ((!keys && !hashed) || !depth2leaf_probs || !roulette_funcs || !const_samples || !value_res || !type_res || !size_res)
         return EVOGP_E_NULLPTR;
     GenParams p{pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys, depth2leaf_probs,
-                roulette_funcs, const_samples, value_res, type_res, size_res, tree_index_offset, active_word, active_below};
+                roulette_funcs, const_samples, value_res, type_res, size_res, tree_index_offset, active_word, active_below, hashed, hash_base};
     hipStream_t stream = (hipStream_t)stream_;
     static const bool staged_ok = [] { const char *e = getenv("EVOGP_GEN_STAGED"); return !(e && e[0] == '0'); }();
     if (staged_ok && gp_len <= (unsigned)kStagedMaxLen) {
@@ -391,7 +426,7 @@ extern "C" int evogp_hip_generate_masked(unsigned pop_size, unsigned gp_len, uns
         // binomial keeps all but ~2 % of the workgroups at one pass of the serial loop); EVOGP_GEN_GATHER=1 switches it off
         static const int env_gather = [] { const char *e = getenv("EVOGP_GEN_GATHER"); return e ? atoi(e) : 0; }();
         unsigned gather = 1;
-        if (active_word) {
+        if (active_word || hashed) {
             const double share = (double)active_below / 2147483648.0;
             gather = share > 0.0 ? (unsigned)(0.8 / share) : (unsigned)kGenMaxGather;
             // ... but only as far as the gathered grid still fills the chip: a launch whose workgroups are all resident at once

@@ -246,12 +246,6 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
 // so every rank of a sharded run -- and the torch formulation for tensors that are not on a GPU -- names the same contenders.
 // "Best" is the order of select_key (NaN worst, -0 = +0); of equal contenders the first drawn wins, as torch.argmax does.
 // One lane per tournament: t_size dependent-free gathers from a vector that lives in L2 (4 MB at 1 M trees).
-__host__ __device__ inline unsigned long long tmix64(unsigned long long x) {
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
 __global__ __launch_bounds__(256) void tournament_kernel(const float *fitness, unsigned n, unsigned n_tournaments, unsigned t_size,
                                                          unsigned long long base, int *winners) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,8 +253,7 @@ __global__ __launch_bounds__(256) void tournament_kernel(const float *fitness, u
     uint32_t best_key = 0u;
     unsigned best = 0u;
     for (unsigned k = 0; k < t_size; ++k) {
-        const unsigned long long x = tmix64(base + ((unsigned long long)(16u + k) << 40) + (unsigned long long)i);
-        const unsigned c = (unsigned)((((x >> 33) & 0x7FFFFFFFull) % 0x7FFFFFFFull) % n);
+        const unsigned c = counter_word(base, 16u + k, (unsigned long long)i) % n;
         const uint32_t key = select_key(fitness[c]);
         if (k == 0u || key > best_key) { best_key = key; best = c; }
     }
@@ -275,7 +268,7 @@ extern "C" int evogp_hip_tournament_select(unsigned n, unsigned n_tournaments, u
                                            const float *fitness, int *winners, evogp_stream_t stream_) {
     if (n == 0 || n_tournaments == 0 || t_size == 0 || t_size > (1u << 20)) return EVOGP_E_BADARG;
     if (!fitness || !winners) return EVOGP_E_NULLPTR;
-    const unsigned long long base = tmix64((unsigned long long)(seed * 1000003ll + generation));
+    const unsigned long long base = counter_base(seed, generation);
     hipLaunchKernelGGL(tournament_kernel, dim3((n_tournaments + 255) / 256), dim3(256), 0, (hipStream_t)stream_, fitness, n, n_tournaments, t_size,
                        base, winners);
     return (int)hipGetLastError();

@@ -99,6 +99,31 @@ Tensor3 generate_impl(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t
     return out;
 }
 
+// rows of trees whose counter-based word (4, n + tree_index_offset) of (seed, generation) is not below active_below are left
+// uninitialised; no keys / active_word tensors (include/evogp_hip.h evogp_hip_generate_masked_hashed)
+Tensor3 tree_generate_masked_hashed(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t out_len, int64_t const_samples_len, double out_prob,
+                                    double const_prob, const Tensor &depth2leaf_probs, const Tensor &roulette_funcs, const Tensor &const_samples,
+                                    int64_t tree_index_offset, int64_t seed, int64_t generation, int64_t active_below) {
+    check_sizes(pop_size, gp_len);
+    TORCH_CHECK(var_len > 0 && out_len > 0 && const_samples_len > 0, "var_len, out_len and const_samples_len must be larger than 0");
+    TORCH_CHECK(out_prob >= 0 && out_prob <= 1 && const_prob >= 0 && const_prob <= 1, "out_prob / const_prob must be in range [0, 1]");
+    TORCH_CHECK(tree_index_offset >= 0 && tree_index_offset < (1LL << 32) && active_below >= 0 && active_below < (1LL << 32),
+                "tree_index_offset / active_below must fit in 32 bits");
+    const c10::Device dev = depth2leaf_probs.device();
+    check_tensor(depth2leaf_probs, {EVOGP_MAX_FULL_DEPTH}, "depth2leaf_probs", dev, at::kFloat);
+    check_tensor(roulette_funcs, {EVOGP_NUM_FUNCS}, "roulette_funcs", dev, at::kFloat);
+    check_tensor(const_samples, {const_samples_len}, "const_samples", dev, at::kFloat);
+    c10::DeviceGuard guard(dev);
+    Tensor3 out = empty_forest(pop_size, gp_len, dev);
+    const int rc = evogp_hip_generate_masked_hashed(
+        (unsigned)pop_size, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len, (unsigned)const_samples_len, (float)out_prob, (float)const_prob,
+        depth2leaf_probs.data_ptr<float>(), roulette_funcs.data_ptr<float>(), const_samples.data_ptr<float>(), std::get<0>(out).data_ptr<float>(),
+        std::get<1>(out).data_ptr<int16_t>(), std::get<2>(out).data_ptr<int16_t>(), (unsigned)tree_index_offset, seed, generation,
+        (unsigned)active_below, current_stream(dev));
+    check_rc(rc, "tree_generate_masked_hashed");
+    return out;
+}
+
 // ---- the reference's five ops -------------------------------------------------------------------------------------------
 Tensor3 tree_generate(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t out_len, int64_t const_samples_len, double out_prob,
                       double const_prob, const Tensor &keys, const Tensor &depth2leaf_probs, const Tensor &roulette_funcs,
@@ -398,8 +423,9 @@ Tensor3 breed_default_rows(int64_t pop_size, int64_t gp_len, int64_t n_elite, in
 // The same rows for ANY selection operator: the elites and the parents are two lists of table rows (parents may repeat, as
 // the survivor indices of a tournament selection do); n_elite / n_surv are the lists' lengths.
 Tensor3 breed_rows_impl(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
-                        const Tensor &parent_rows, const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value, const Tensor &donor_type,
-                        const Tensor &donor_size, int64_t row_begin, int64_t row_count, unsigned long long *records_stamp) {
+                        const Tensor &parent_rows, const Tensor *rnd_or_null, int64_t seed, int64_t generation, int64_t mutate_below,
+                        const Tensor &donor_value, const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin, int64_t row_count,
+                        unsigned long long *records_stamp) {
     check_sizes(pop_size, gp_len);
     TORCH_CHECK(row_begin >= 0 && row_count > 0 && row_begin + row_count <= pop_size, "row range out of the population");
     TORCH_CHECK(mutate_below >= 0 && mutate_below < (1LL << 32), "mutate_below must fit in 32 bits");
@@ -412,7 +438,7 @@ Tensor3 breed_rows_impl(int64_t pop_size, int64_t gp_len, const Tensor &value, c
     TORCH_CHECK(n_elite <= pop_size && n_surv > 0, "need n_elite <= pop_size and at least one parent, got ", n_elite, ", ", n_surv);
     check_order(parent_rows, n_surv, dev);
     if (n_elite > 0) check_order(elite_rows, n_elite, dev);
-    check_tensor(rnd, {6, pop_size - n_elite}, "rnd", dev, at::kInt);
+    if (rnd_or_null) check_tensor(*rnd_or_null, {6, pop_size - n_elite}, "rnd", dev, at::kInt);
     const int64_t head = std::max<int64_t>(0, std::min(row_begin + row_count, n_elite) - row_begin);
     const int64_t drows = donor_value.dim() == 2 ? donor_value.size(0) : -1;
     TORCH_CHECK(drows == row_count || drows == row_count - head, "donor arrays must have ", row_count, " or ", row_count - head,
@@ -421,12 +447,19 @@ Tensor3 breed_rows_impl(int64_t pop_size, int64_t gp_len, const Tensor &value, c
     const int64_t skip = drows == row_count - head ? head : 0;
     c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(row_count, gp_len, dev);
-    const int rc = evogp_hip_breed_lists_compiled(
-        (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),
-        size.data_ptr<int16_t>(), n_elite > 0 ? elite_rows.data_ptr<int>() : nullptr, parent_rows.data_ptr<int>(), rnd.data_ptr<int>(),
-        (unsigned)mutate_below, donor_value.data_ptr<float>() - skip * gp_len, donor_type.data_ptr<int16_t>() - skip * gp_len,
-        donor_size.data_ptr<int16_t>() - skip * gp_len, std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
-        std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, records_stamp, current_stream(dev));
+    const int rc = rnd_or_null
+        ? evogp_hip_breed_lists_compiled(
+              (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),
+              size.data_ptr<int16_t>(), n_elite > 0 ? elite_rows.data_ptr<int>() : nullptr, parent_rows.data_ptr<int>(), rnd_or_null->data_ptr<int>(),
+              (unsigned)mutate_below, donor_value.data_ptr<float>() - skip * gp_len, donor_type.data_ptr<int16_t>() - skip * gp_len,
+              donor_size.data_ptr<int16_t>() - skip * gp_len, std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
+              std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, records_stamp, current_stream(dev))
+        : evogp_hip_breed_lists_hashed(
+              (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),
+              size.data_ptr<int16_t>(), n_elite > 0 ? elite_rows.data_ptr<int>() : nullptr, parent_rows.data_ptr<int>(), seed, generation,
+              (unsigned)mutate_below, donor_value.data_ptr<float>() - skip * gp_len, donor_type.data_ptr<int16_t>() - skip * gp_len,
+              donor_size.data_ptr<int16_t>() - skip * gp_len, std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
+              std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, records_stamp, current_stream(dev));
     check_rc(rc, "breed_rows");
     return out;
 }
@@ -434,7 +467,7 @@ Tensor3 breed_rows_impl(int64_t pop_size, int64_t gp_len, const Tensor &value, c
 Tensor3 breed_rows(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
                    const Tensor &parent_rows, const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value, const Tensor &donor_type,
                    const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
-    return breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, rnd, mutate_below, donor_value, donor_type, donor_size,
+    return breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, &rnd, 0, 0, mutate_below, donor_value, donor_type, donor_size,
                            row_begin, row_count, nullptr);
 }
 
@@ -447,8 +480,19 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> breed_rows_compiled(int64_t pop_size
                                                                 const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin,
                                                                 int64_t row_count) {
     unsigned long long stamp = 0;
-    Tensor3 out = breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, rnd, mutate_below, donor_value, donor_type,
+    Tensor3 out = breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, &rnd, 0, 0, mutate_below, donor_value, donor_type,
                                   donor_size, row_begin, row_count, &stamp);
+    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), (int64_t)stamp};
+}
+
+// breed_rows_compiled with the six words of every offspring computed in the kernel from (seed, generation) instead of read from `rnd`
+std::tuple<Tensor, Tensor, Tensor, int64_t> breed_rows_hashed(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type,
+                                                              const Tensor &size, const Tensor &elite_rows, const Tensor &parent_rows, int64_t seed,
+                                                              int64_t generation, int64_t mutate_below, const Tensor &donor_value,
+                                                              const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
+    unsigned long long stamp = 0;
+    Tensor3 out = breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, nullptr, seed, generation, mutate_below, donor_value,
+                                  donor_type, donor_size, row_begin, row_count, &stamp);
     return {std::get<0>(out), std::get<1>(out), std::get<2>(out), (int64_t)stamp};
 }
 
@@ -501,6 +545,12 @@ TORCH_LIBRARY(evogp_hip, m) {
     m.def("breed_rows_compiled(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows,"
           " Tensor parent_rows, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin,"
           " int row_count) -> (Tensor value, Tensor node_type, Tensor subtree_size, int records_stamp)");
+    m.def("breed_rows_hashed(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows, Tensor parent_rows,"
+          " int seed, int generation, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin, int row_count)"
+          " -> (Tensor value, Tensor node_type, Tensor subtree_size, int records_stamp)");
+    m.def("tree_generate_masked_hashed(int pop_size, int gp_len, int var_len, int out_len, int const_samples_len, float out_prob, float const_prob,"
+          " Tensor depth2leaf_probs, Tensor roulette_funcs, Tensor const_samples, int tree_index_offset, int seed, int generation, int active_below)"
+          " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
     m.def("tree_SR_fitness_stamped(int pop_size, int data_points, int gp_len, int var_len, int out_len, bool use_mse, Tensor value,"
           " Tensor node_type, Tensor subtree_size, Tensor variables, Tensor labels, int kernel_type, int records_stamp) -> Tensor");
 }
@@ -518,6 +568,8 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("breed_default_rows", &breed_default_rows);
     m.impl("breed_rows", &breed_rows);
     m.impl("breed_rows_compiled", &breed_rows_compiled);
+    m.impl("breed_rows_hashed", &breed_rows_hashed);
+    m.impl("tree_generate_masked_hashed", &tree_generate_masked_hashed);
     m.impl("tree_SR_fitness_stamped", &tree_SR_fitness_stamped);
     m.impl("select_survivors", &select_survivors);
     m.impl("tournament_select", &tournament_select);

@@ -301,20 +301,20 @@ class ShardedGeneticProgramming:
         d = self.descriptor
         rows = hi - lo
         o_lo, o_hi = max(lo, n_elite) - n_elite, max(hi, n_elite) - n_elite   # my offspring indices
-        # the words of MY offspring only (the breeding pass indexes the array by offspring number: the other columns are
-        # never read and stay uninitialised), and this generation's two generation keys
-        rnd = torch.ops.evogp_hip.random_words(self.seed, self.generation, 6, n_new, o_lo, o_hi, dev)   # one launch, this rank's columns
-        keys = (torch.ops.evogp_hip.random_words(self.seed, self.generation, 8, 2, 0, 2, dev)[7] % 1000000).to(torch.uint32)   # row 7: not an offspring word
+        # no array of random words: both kernels compute word k of offspring i = hash(seed, generation, k, i) themselves (the
+        # numbers evogp_hip_random_words / random_words give), and the generation keys are words (7, 0 / 1): every rank builds
+        # its rows from the same words whatever the world size, with two launches (donors, breeding pass)
         if o_hi > o_lo:
-            donors = torch.ops.evogp_hip.tree_generate_masked(
-                o_hi - o_lo, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob, keys,
-                d.depth2leaf_probs, d.roulette_funcs, d.const_samples, o_lo, rnd[4, o_lo:o_hi].contiguous(), below)
+            donors = torch.ops.evogp_hip.tree_generate_masked_hashed(
+                o_hi - o_lo, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob,
+                d.depth2leaf_probs, d.roulette_funcs, d.const_samples, o_lo, self.seed, self.generation, below)
             # donors cover my offspring rows only; the breeding pass skips the elite rows at the head of the range
         else:  # a slice of elites only: donors are never read
             donors = (torch.empty((rows, L), dtype=torch.float32, device=dev), torch.empty((rows, L), dtype=torch.int16, device=dev),
                       torch.empty((rows, L), dtype=torch.int16, device=dev))
         value, ntype, size = full._tensors()
-        nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_compiled(pop, L, value, ntype, size, elite_rows, parent_rows, rnd, below, *donors, lo, rows)
+        nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elite_rows, parent_rows, self.seed, self.generation,
+                                                                  below, *donors, lo, rows)
         return Forest(full.input_len, full.output_len, nv, nt, ns).set_compiled_records(stamp)
 
     def slice_torch(self, table: Forest, elite_rows: torch.Tensor, parent_rows: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:

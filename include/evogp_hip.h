@@ -184,6 +184,24 @@ int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsign
                                  const float *variables, const float *labels, float *fitnesses, unsigned kernel_type,
                                  unsigned long long records_stamp, evogp_stream_t stream);
 
+/* The same two passes with their random words computed in the kernels (no counterpart in the reference): word k of offspring i is
+ * hash(seed, generation, k, i) -- exactly the numbers evogp_hip_random_words writes -- so no array of words is drawn, written and read
+ * (one launch and 24 B per offspring less per generation), and the two generation keys are words (7, 0) and (7, 1) modulo 10^6.
+ * evogp_hip_generate_masked_hashed generates the trees n whose word (4, n + tree_index_offset) is below active_below;
+ * evogp_hip_breed_lists_hashed is evogp_hip_breed_lists_compiled without `rnd`.  Results equal those of the array forms fed with
+ * evogp_hip_random_words(seed, generation, ...) bit for bit (tests/test_gpu_breed.py). */
+int evogp_hip_generate_masked_hashed(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                     unsigned const_samples_len, float out_prob, float const_prob, const float *depth2leaf_probs,
+                                     const float *roulette_funcs, const float *const_samples, float *value_res, int16_t *type_res,
+                                     int16_t *size_res, unsigned tree_index_offset, long long seed, long long generation,
+                                     unsigned active_below, evogp_stream_t stream);
+int evogp_hip_breed_lists_hashed(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
+                                 const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
+                                 long long seed, long long generation, unsigned mutate_below, const float *donor_value,
+                                 const int16_t *donor_type, const int16_t *donor_size, float *value_res, int16_t *type_res,
+                                 int16_t *size_res, int *decisions, int row_begin, int row_count,
+                                 unsigned long long *records_stamp, evogp_stream_t stream);
+
 /* Counter-based random words for the breeding pass of a sharded run (no counterpart in the reference, which draws with
  * torch's generator): out[k][i] for k < rows, i in [lo, hi) = hash(seed, generation, k, i) mapped to [0, 2^31 - 1), the value
  * evogp_amd/parallel.py random_words computes on any device; out: i32[rows][n_cols], only columns [lo, hi) are written.  Every

@@ -500,3 +500,49 @@ def test_breeding_pass_compiles_ahead_and_stale_stamps_recompile(g, compile_ahea
     algo.step(torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit))
     half.set_compiled_records(algo.forest._records[0])
     same(half.SR_fitness(X, y), plain(half).SR_fitness(X, y), "stamp of another population size")
+
+
+def test_hashed_words_equal_the_array_forms(g, oracle):
+    """evogp_hip_generate_masked_hashed / evogp_hip_breed_lists_hashed compute the counter-based words in the kernels; fed the
+    words evogp_hip_random_words writes for the same (seed, generation), the array forms must build the same rows bit for bit —
+    whole population and a rank's slice with its tree-index offset."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.parallel import random_words
+    from evogp_amd.tree import GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    for L, funcs in ((64, ["+", "-", "*", "/"]), (50, ["+", "*", "sin", "if"])):      # (50: the one-row-per-wave kernels)
+        desc = GenerateDescriptor(max_tree_len=L, input_len=5, output_len=1, using_funcs=funcs, max_layer_cnt=3 if "if" in funcs else 5,
+                                  const_samples=[-1.0, 0.5, 2.0])
+        d = desc.update(max_layer_cnt=3)
+        pop, n_elite, n_surv, seed, generation = 6000, 60, 1800, 1234567, 42
+        forest = oracle.generate(pop, L, 5, 1, 0.5, 0.5, [3, 4], np.asarray(desc.depth2leaf_probs.cpu()), np.asarray(desc.roulette_funcs.cpu()), [-1.0, 0.5, 2.0])
+        v, t, s = (torch.from_numpy(a).to(dev) for a in forest)
+        gen = torch.Generator().manual_seed(L)
+        elites = torch.randperm(pop, generator=gen)[:n_elite].to(torch.int32).to(dev)
+        parents = torch.randint(0, pop, (n_surv,), generator=gen).to(torch.int32).to(dev)
+        n_new = pop - n_elite
+        below = int(0.3 * (2**31 - 1))
+        rnd = torch.ops.evogp_hip.random_words(seed, generation, 6, n_new, 0, n_new, dev)
+        assert torch.equal(rnd.cpu(), random_words(seed, generation, 6, 0, n_new, "cpu"))
+        keys = (torch.ops.evogp_hip.random_words(seed, generation, 8, 2, 0, 2, dev)[7] % 1000000).to(torch.uint32)
+        args = (L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob)
+        tabs = (d.depth2leaf_probs, d.roulette_funcs, d.const_samples)
+        for lo, hi in ((0, pop), (1000, 2500), (0, 40), (30, 100)):     # whole population; slices inside, of elites only, across the elite border
+            o_lo, o_hi = max(lo, n_elite) - n_elite, max(hi, n_elite) - n_elite
+            rows = hi - lo
+            if o_hi > o_lo:
+                don_a = torch.ops.evogp_hip.tree_generate_masked(o_hi - o_lo, *args, keys, *tabs, o_lo, rnd[4, o_lo:o_hi].contiguous(), below)
+                don_h = torch.ops.evogp_hip.tree_generate_masked_hashed(o_hi - o_lo, *args, *tabs, o_lo, seed, generation, below)
+                act = rnd[4, o_lo:o_hi].to(torch.int64) < below
+                assert 0.2 < float(act.float().mean()) < 0.4
+                for a, b in zip(don_a, don_h):
+                    assert torch.equal(a[act].view(torch.uint8), b[act].view(torch.uint8)), "donors differ"
+            else:
+                don_a = don_h = tuple(torch.zeros((rows, L), dtype=dt, device=dev) for dt in (torch.float32, torch.int16, torch.int16))
+            out_a = torch.ops.evogp_hip.breed_rows(pop, L, v, t, s, elites, parents, rnd, below, *don_a, lo, rows)
+            out_h = torch.ops.evogp_hip.breed_rows_hashed(pop, L, v, t, s, elites, parents, seed, generation, below, *don_h, lo, rows)[:3]
+            for a, b in zip(out_a, out_h):
+                assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (L, lo, hi)
