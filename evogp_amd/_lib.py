@@ -41,6 +41,7 @@ PROTOTYPES = {
     "evogp_hip_evaluate_prepared": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "evogp_hip_random_words": [C.c_longlong, C.c_longlong, _i, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp],
     "evogp_hip_select": [_u, _u, _u, _vp, _vp, _vp, _vp],
+    "evogp_hip_select_alternating": [_u, _u, _u, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_tournament_select": [_u, _u, _u, C.c_longlong, C.c_longlong, _vp, _vp, _vp],
     "evogp_hip_set_program_buffer_limit": [C.c_ulonglong],
     "evogp_hip_set_breed_compile": [_i],

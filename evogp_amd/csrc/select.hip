@@ -55,6 +55,7 @@ struct SelectParams {
     const float *fitness;
     int *order;
     unsigned *ws;
+    unsigned *zero_next;   // optional: the workspace of the NEXT call on this stream, zeroed here (no memset launch per call)
     int n, n_elite, n_keep;
 };
 
@@ -118,6 +119,8 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectParams p) {
     unsigned *g0 = p.ws + kSelHist, *g1e = g0 + kSelBins, *g1k = g1e + kSelBins, *g2e = g1k + kSelBins, *g2k = g2e + kSelBins;
     unsigned *counts = p.ws + kSelCounts;
     const int nb = (int)gridDim.x, b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (p.zero_next && b == nb - 1)
+        for (int i = tid; i < kSelWords; i += kSelThreads) p.zero_next[i] = 0u;
     const int chunk = ((p.n + nb - 1) / nb + kSelThreads - 1) / kSelThreads * kSelThreads;   // contiguous slice per workgroup
     const int lo = b * chunk < p.n ? b * chunk : p.n, hi = lo + chunk < p.n ? lo + chunk : p.n;
     const unsigned ke = (unsigned)p.n_elite, kk = (unsigned)p.n_keep;
@@ -278,9 +281,15 @@ extern "C" size_t evogp_hip_select_workspace_bytes(void) { return (size_t)kSelWo
 
 extern "C" int evogp_hip_select(unsigned n, unsigned n_elite, unsigned n_keep, const float *fitness, int *order, void *zeroed_workspace,
                                 evogp_stream_t stream_) {
+    return evogp_hip_select_alternating(n, n_elite, n_keep, fitness, order, zeroed_workspace, nullptr, stream_);
+}
+
+extern "C" int evogp_hip_select_alternating(unsigned n, unsigned n_elite, unsigned n_keep, const float *fitness, int *order,
+                                            void *zeroed_workspace, void *next_workspace, evogp_stream_t stream_) {
     if (n == 0 || n_keep == 0 || n_keep > n || n_elite > n_keep) return EVOGP_E_BADARG;
     if (!fitness || !order || !zeroed_workspace) return EVOGP_E_NULLPTR;
-    SelectParams p{fitness, order, (unsigned *)zeroed_workspace, (int)n, (int)n_elite, (int)n_keep};
+    if (next_workspace == zeroed_workspace) return EVOGP_E_BADARG;
+    SelectParams p{fitness, order, (unsigned *)zeroed_workspace, (unsigned *)next_workspace, (int)n, (int)n_elite, (int)n_keep};
     // The grid barrier needs every workgroup resident at once: never launch more than the occupancy calculator says fit
     // (register growth, partitioned modes).  EVOGP_SELECT_COOP=1 additionally asks the runtime for a cooperative launch, which
     // fails instead of hanging when the grid would not be co-resident (a CU mask the occupancy query does not see) -- opt-in,

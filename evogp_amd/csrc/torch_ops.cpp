@@ -16,7 +16,12 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <mutex>
 #include <tuple>
+#include <utility>
 
 #include "../../include/evogp_hip.h"
 
@@ -333,9 +338,28 @@ Tensor select_survivors(const Tensor &fitness, int64_t n_elite, int64_t n_keep) 
     const c10::Device dev = fitness.device();
     c10::DeviceGuard guard(dev);
     Tensor order = at::empty({n_keep}, at::TensorOptions().dtype(at::kInt).device(dev));
-    Tensor ws = at::zeros({(int64_t)(evogp_hip_select_workspace_bytes() / 4)}, at::TensorOptions().dtype(at::kInt).device(dev));
-    check_rc(evogp_hip_select((unsigned)n, (unsigned)n_elite, (unsigned)n_keep, fitness.data_ptr<float>(), order.data_ptr<int>(), ws.data_ptr(),
-                              current_stream(dev)), "select_survivors");
+    const int64_t words = (int64_t)(evogp_hip_select_workspace_bytes() / 4);
+    const evogp_stream_t stream = current_stream(dev);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (capturing) {   // a replayed graph cannot alternate: a fresh zeroed workspace per captured call
+        Tensor ws = at::zeros({words}, at::TensorOptions().dtype(at::kInt).device(dev));
+        check_rc(evogp_hip_select((unsigned)n, (unsigned)n_elite, (unsigned)n_keep, fitness.data_ptr<float>(), order.data_ptr<int>(), ws.data_ptr(),
+                                  stream), "select_survivors");
+        return order;
+    }
+    // two workspaces per (device, stream): this call's was zeroed by the previous call's kernel on the same stream
+    struct Slot { Tensor ws; int parity = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, void *>, Slot> slots;
+    std::lock_guard<std::mutex> lock(mu);
+    Slot &sl = slots[{(int)dev.index(), (void *)stream}];
+    if (!sl.ws.defined()) sl.ws = at::zeros({2 * words}, at::TensorOptions().dtype(at::kInt).device(dev));
+    int *base = sl.ws.data_ptr<int>();
+    int *mine = base + (int64_t)sl.parity * words, *next = base + (int64_t)(1 - sl.parity) * words;
+    sl.parity ^= 1;
+    check_rc(evogp_hip_select_alternating((unsigned)n, (unsigned)n_elite, (unsigned)n_keep, fitness.data_ptr<float>(), order.data_ptr<int>(), mine,
+                                          next, stream), "select_survivors");
     return order;
 }
 

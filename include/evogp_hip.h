@@ -217,6 +217,10 @@ int evogp_hip_random_words(long long seed, long long generation, int rows, long 
 size_t evogp_hip_select_workspace_bytes(void);
 int evogp_hip_select(unsigned n, unsigned n_elite, unsigned n_keep, const float *fitness, int *order, void *zeroed_workspace,
                      evogp_stream_t stream);
+/* The same launch for a caller that alternates between two workspaces on one stream: `next_workspace` (the other one, used by the
+ * previous call on that stream) is zeroed by this launch, so the steady state needs no memset per call (3-4 us). */
+int evogp_hip_select_alternating(unsigned n, unsigned n_elite, unsigned n_keep, const float *fitness, int *order,
+                                 void *zeroed_workspace, void *next_workspace, evogp_stream_t stream);
 
 /* Tournament selection in one launch (no counterpart in the reference's ABI; src/evogp/algorithm/selection/tournament.py:59-133 with its
  * default arguments, which is also the setting of example/uci_sr.py:73-75: contenders drawn WITH replacement, the best contender
