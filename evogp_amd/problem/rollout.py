@@ -130,7 +130,9 @@ class RolloutProblem(BaseProblem):
             self._step(forest, s_state, s_total, s_done)
         torch.cuda.current_stream(dev).wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: in a multi-rank process the RCCL watchdog thread queries events while this thread captures; under the
+        # default ("global") that invalidates the capture although the two have nothing to do with each other
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             a, b, c = self._step(forest, s_state, s_total, s_done)
             s_state.copy_(a); s_total.copy_(b); s_done.copy_(c)
         for _ in range(self.max_episode_length):

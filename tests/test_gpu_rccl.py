@@ -40,14 +40,20 @@ def _run(rank, world, port, outdir):
     g = torch.Generator().manual_seed(1234)
     X = (torch.rand(256, 10, generator=g) * 10 - 5).to(dev)
     y = (X[:, 0] * X[:, 1] - X[:, 4])[:, None].contiguous()
-    gp = ShardedGeneticProgramming(local, 0.2, desc.update(max_layer_cnt=3), seed=123)
-    for _ in range(GENS):
-        fit = -gp.forest.SR_fitness(X, y)
-        fit = torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit)
-        gp.step(fit)
-    f = gp.forest
-    np.savez(os.path.join(outdir, f"w{world}_r{rank}.npz"), v=f.batch_node_value.cpu().numpy(), t=f.batch_node_type.cpu().numpy(),
-             s=f.batch_subtree_size.cpu().numpy())
+    from evogp_amd.algorithm.selection import DefaultSelection, TournamentSelection
+
+    # DefaultSelection over two all-gathers, and BASELINE configs[2]'s tournament selection over ONE packed all-gather
+    for name, sel, exchange in (("default", DefaultSelection(0.3, elite_rate=0.01), "rows"),
+                                ("tournament", TournamentSelection(20, survivor_rate=0.5, elite_rate=0.1), "packed")):
+        start = Forest(local.input_len, local.output_len, local.batch_node_value.clone(), local.batch_node_type.clone(), local.batch_subtree_size.clone())
+        gp = ShardedGeneticProgramming(start, 0.2, desc.update(max_layer_cnt=3), selection=sel, seed=123, exchange=exchange)
+        for _ in range(GENS):
+            fit = -gp.forest.SR_fitness(X, y)
+            fit = torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit)
+            gp.step(fit)
+        f = gp.forest
+        np.savez(os.path.join(outdir, f"w{world}_r{rank}_{name}.npz"), v=f.batch_node_value.cpu().numpy(), t=f.batch_node_type.cpu().numpy(),
+                 s=f.batch_subtree_size.cpu().numpy())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -61,9 +67,10 @@ def test_rccl_shards_equal_the_single_device_population(tmp_path):
     world = 2 if torch.cuda.device_count() < 4 else 4
     mp.spawn(_run, args=(1, _free_port(), out), nprocs=1, join=True)
     mp.spawn(_run, args=(world, _free_port(), out), nprocs=world, join=True)
-    one = np.load(os.path.join(out, "w1_r0.npz"))
-    parts = [np.load(os.path.join(out, f"w{world}_r{r}.npz")) for r in range(world)]
-    for k in ("v", "t", "s"):
-        got = np.concatenate([p[k] for p in parts])
-        a, b = (got.view(np.uint32), one[k].view(np.uint32)) if k == "v" else (got, one[k])
-        assert np.array_equal(a, b), f"{k}: the union of the {world} RCCL shards differs from the single-device population"
+    for name in ("default", "tournament"):
+        one = np.load(os.path.join(out, f"w1_r0_{name}.npz"))
+        parts = [np.load(os.path.join(out, f"w{world}_r{r}_{name}.npz")) for r in range(world)]
+        for k in ("v", "t", "s"):
+            got = np.concatenate([p[k] for p in parts])
+            a, b = (got.view(np.uint32), one[k].view(np.uint32)) if k == "v" else (got, one[k])
+            assert np.array_equal(a, b), f"{name}, {k}: the union of the {world} RCCL shards differs from the single-device population"
