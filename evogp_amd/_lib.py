@@ -35,6 +35,7 @@ PROTOTYPES = {
     "evogp_hip_generate_masked_hashed": [_u, _u, _u, _u, _u, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_longlong, C.c_longlong, _u, _vp],
     "evogp_hip_breed_lists_hashed": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, C.c_longlong, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "evogp_hip_sr_fitness_stamped": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_ulonglong, _vp],
+    "evogp_hip_sr_fitness_hinted": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_ulonglong, _u, _vp],
     "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_batch_argmax_count": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_evaluate_prepare": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_size_t, _vp],

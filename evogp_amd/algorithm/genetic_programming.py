@@ -129,5 +129,5 @@ class GeneticProgramming:
         # (the pass also compiles the rows it builds for the next tree_SR_fitness call when that experiment is on: csrc/sr_tc.hip)
         nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elites, parents, self._word_seed, self._steps,
                                                                   below, *donors, 0, pop)
-        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns).set_compiled_records(stamp)
+        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns, func_mask=Forest.join_masks(f.func_mask, d.func_mask)).set_compiled_records(stamp)
         return self.forest

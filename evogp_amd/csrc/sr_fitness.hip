@@ -483,6 +483,23 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         const TcHints h = tc_hints();
         p.hint_general = h.general ? 1 : 0; p.hint_heavy = h.heavy ? 1 : 0; p.hint_words = h.device_words;
     }
+    if (!STORE && asm_depth == 3 && !mo && !profiling && p.func_mask != 0u && p.gp_len <= 64) {
+        // The caller knows the forest's function set.  Nothing but + - * / and the unary functions with handlers of their own:
+        // no tree can be left for the general compiler (rows of at most 64 nodes), so that launch is not made; no sin / cos / tan
+        // either: no run-time bail-out can occur, and the FULL register build is not launched for the few trees whose operand stack
+        // is too deep for the threaded code -- the scratch-stack kernel (mode 3) takes every tree that still carries a sentinel, so
+        // a mask that promises too much costs speed, never a result.  Decided by the mask alone: the same forest always takes the
+        // same kernels (unlike the history-driven hints above).  5 launches -> 3 on the headline's function set.
+        constexpr unsigned kOwnHandlers = (1u << F_ADD) | (1u << F_SUB) | (1u << F_MUL) | (1u << F_DIV) | (1u << F_SIN) | (1u << F_COS) | (1u << F_TAN) |
+                                          (1u << F_LOG) | (1u << F_LOOSE_LOG) | (1u << F_EXP) | (1u << F_INV) | (1u << F_NEG) | (1u << F_ABS) |
+                                          (1u << F_SQRT) | (1u << F_LOOSE_SQRT);
+        constexpr unsigned kBailOut = (1u << F_SIN) | (1u << F_COS) | (1u << F_TAN);
+        static const int env_mask = env_int("EVOGP_TC_FUNC_MASK", 1);   // 0: ignore the caller's mask (A/B)
+        if (env_mask && (p.func_mask & ~kOwnHandlers) == 0u) {
+            p.hint_general = 0;
+            if ((p.func_mask & kBailOut) == 0u) p.hint_heavy = 0;
+        }
+    }
     if (!STORE && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
         p.stats = g_stats;
@@ -515,7 +532,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         e = p.var_len <= 16 ? launch_pair<1, 32, 16, true, 16, STORE>(p, stream) : launch_pair<1, 32, 32, true, 16, STORE>(p, stream);
     }
     if (e != hipSuccess) return (int)e;
-    e = launch_general<STORE>(p, tc_done && !mo && p.hint_words ? 3 : 1, stream);
+    e = launch_general<STORE>(p, tc_done && !mo && (p.hint_words || !p.hint_general || !p.hint_heavy) ? 3 : 1, stream);
     prof_done(tc_done);
     return (int)e;
 }
@@ -558,6 +575,15 @@ extern "C" int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_poi
                                             const int16_t *size, const float *variables, const float *labels,
                                             float *fitnesses, unsigned kernel_type, unsigned long long records_stamp,
                                             evogp_stream_t stream_) {
+    return evogp_hip_sr_fitness_hinted(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels,
+                                       fitnesses, kernel_type, records_stamp, 0u, stream_);
+}
+
+extern "C" int evogp_hip_sr_fitness_hinted(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len,
+                                           unsigned out_len, int use_mse, const float *value, const int16_t *type,
+                                           const int16_t *size, const float *variables, const float *labels,
+                                           float *fitnesses, unsigned kernel_type, unsigned long long records_stamp,
+                                           unsigned function_mask, evogp_stream_t stream_) {
     // argument contract of torch_wrapper.cu:250-254
     if (pop_size == 0 || data_points == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len == 0)
         return EVOGP_E_BADARG;
@@ -569,6 +595,7 @@ extern "C" int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_poi
     p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len;
     p.out_len = (int)out_len; p.use_mse = use_mse ? 1 : 0;
     p.stamp = records_stamp;
+    p.func_mask = function_mask;
     return run_population<false>(p, (hipStream_t)stream_);
 }
 

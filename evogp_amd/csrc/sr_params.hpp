@@ -38,6 +38,9 @@ struct SrParams {
     int hint_general;         // != 0: launch the general compiler (trees the one-chunk compiler marks for it occurred recently)
     int hint_heavy;           // != 0: launch the FULL register build for marked trees (such marks occurred recently)
     unsigned *hint_words;     // host-mapped words the last follow-up kernel reports this call's marks into (or nullptr)
+    unsigned func_mask;       // bit f: function id f (defs.h:10-57) may occur in the forest; 0 = unknown.  A caller that knows the
+                              // forest's function set (evogp_amd.tree.Forest tracks it from the descriptors its trees came from) lets
+                              // the call skip launches that such a forest cannot need -- decided by the mask, never by history
     unsigned long long stamp; // != 0: the caller believes the program records of the breeding pass with this stamp belong to this population
     unsigned *marks; // [0] != 0: some tree carries kSentinelHeavy, [1] != 0: some tree carries kSentinelDeep,
                      // [2]: how many of the mark_sample sampled trees were marked heavy (may be nullptr)

@@ -196,7 +196,7 @@ Tensor tree_evaluate(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t 
 
 Tensor sr_fitness_impl(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
                        const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
-                       int64_t kernel_type, int64_t records_stamp) {
+                       int64_t kernel_type, int64_t records_stamp, int64_t func_mask = 0) {
     check_sizes(pop_size, gp_len);
     TORCH_CHECK(var_len > 0, "var_len must be larger than 0, but got ", var_len);
     TORCH_CHECK(out_len > 0, "out_len must be larger than 0, but got ", out_len);
@@ -208,10 +208,11 @@ Tensor sr_fitness_impl(int64_t pop_size, int64_t data_points, int64_t gp_len, in
     check_tensor(labels, {data_points, out_len}, "labels", dev, at::kFloat);
     c10::DeviceGuard guard(dev);
     Tensor fitness = at::empty({pop_size}, value.options());
-    const int rc = evogp_hip_sr_fitness_stamped((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len,
-                                                use_mse ? 1 : 0, value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(),
-                                                variables.data_ptr<float>(), labels.data_ptr<float>(), fitness.data_ptr<float>(),
-                                                (unsigned)kernel_type, (unsigned long long)records_stamp, current_stream(dev));
+    TORCH_CHECK(func_mask >= 0 && func_mask < (1LL << 32), "func_mask must fit in 32 bits");
+    const int rc = evogp_hip_sr_fitness_hinted((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len,
+                                               use_mse ? 1 : 0, value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(),
+                                               variables.data_ptr<float>(), labels.data_ptr<float>(), fitness.data_ptr<float>(),
+                                               (unsigned)kernel_type, (unsigned long long)records_stamp, (unsigned)func_mask, current_stream(dev));
     check_rc(rc, "tree_SR_fitness");
     return fitness;
 }
@@ -222,12 +223,13 @@ Tensor tree_SR_fitness(int64_t pop_size, int64_t data_points, int64_t gp_len, in
     return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type, 0);
 }
 
-// tree_SR_fitness for a forest the breeding pass compiled ahead (breed_rows_compiled returned `records_stamp` for exactly these rows)
+// tree_SR_fitness for a caller that knows more about the forest: the stamp of the records the breeding pass compiled ahead for
+// exactly these rows (0: none) and the set of functions that can occur in it (0: unknown) -- include/evogp_hip.h
 Tensor tree_SR_fitness_stamped(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
                                const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
-                               int64_t kernel_type, int64_t records_stamp) {
+                               int64_t kernel_type, int64_t records_stamp, int64_t func_mask) {
     return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type,
-                           records_stamp);
+                           records_stamp, func_mask);
 }
 
 // ---- extra ops (no counterpart in the reference) ------------------------------------------------------------------------
@@ -576,7 +578,7 @@ TORCH_LIBRARY(evogp_hip, m) {
           " Tensor depth2leaf_probs, Tensor roulette_funcs, Tensor const_samples, int tree_index_offset, int seed, int generation, int active_below)"
           " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
     m.def("tree_SR_fitness_stamped(int pop_size, int data_points, int gp_len, int var_len, int out_len, bool use_mse, Tensor value,"
-          " Tensor node_type, Tensor subtree_size, Tensor variables, Tensor labels, int kernel_type, int records_stamp) -> Tensor");
+          " Tensor node_type, Tensor subtree_size, Tensor variables, Tensor labels, int kernel_type, int records_stamp, int func_mask) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(evogp_hip, CompositeExplicitAutograd, m) { m.impl("random_words", &random_words); }  // no tensor argument to dispatch on

@@ -69,6 +69,22 @@ class GenerateDescriptor:
         self.depth2leaf_probs = self._leaf_probabilities(depth2leaf_probs, max_tree_len, using_funcs, max_layer_cnt, layer_leaf_prob)
         self.roulette_funcs, self.roulette_ufuncs, self.roulette_bfuncs, self.roulette_tfuncs = self._roulettes(roulette_funcs, using_funcs)
         self.const_samples = self._constants(const_samples, const_range, sample_cnt)
+        self.func_mask = self._function_mask(roulette_funcs, using_funcs)
+
+    @staticmethod
+    def _function_mask(roulette_funcs, using_funcs) -> int:
+        """bit f = function id f can be generated (its weight is positive); 0 = unknown.  Forests remember the masks of the
+        descriptors their trees came from, and tree_SR_fitness skips launches such a forest cannot need (include/evogp_hip.h
+        evogp_hip_sr_fitness_hinted).  A descriptor given a ready-made roulette tensor says "unknown" (reading it back would
+        synchronise with the device)."""
+        if roulette_funcs is not None or not isinstance(using_funcs, (dict, list)):
+            return 0
+        weights = dict.fromkeys(using_funcs, 1.0) if isinstance(using_funcs, list) else using_funcs
+        mask = 0
+        for name, w in weights.items():
+            if w > 0 and name in FUNCS_NAMES:
+                mask |= 1 << FUNCS_NAMES.index(name)
+        return mask
 
     @staticmethod
     def _as_f32(t, what, shape=None) -> Tensor:

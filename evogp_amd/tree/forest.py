@@ -35,7 +35,10 @@ _SR_MODES = {"hybrid parallel": 0, "data parallel": 1, "tree parallel": 2, "auto
 
 class Forest:
     def __init__(self, input_len, output_len, batch_node_value: Tensor, batch_node_type: Tensor,
-                 batch_subtree_size: Tensor):
+                 batch_subtree_size: Tensor, func_mask: int = 0):
+        """``func_mask`` (no counterpart in the reference): bit f = function id f may occur in the trees, 0 = unknown.  Set by
+        ``random_generate`` from the descriptor and handed on by the operators that combine forests; a forest built from raw
+        tensors is "unknown".  ``SR_fitness`` passes it on as long as the tensors are untouched."""
         self.input_len = input_len
         self.output_len = output_len
         self.pop_size, self.max_tree_len = batch_node_value.shape
@@ -46,6 +49,26 @@ class Forest:
         self.batch_node_value = batch_node_value
         self.batch_node_type = batch_node_type
         self.batch_subtree_size = batch_subtree_size
+        self._func_mask = (int(func_mask), self._forest_key()) if func_mask else None
+
+    @property
+    def func_mask(self) -> int:
+        """the functions that may occur in this forest (bit f = function id f), 0 when unknown or when a tensor was replaced or
+        written in place since the mask was set"""
+        m = getattr(self, "_func_mask", None)
+        if m is None or m[1] != self._forest_key():
+            return 0
+        return m[0]
+
+    @staticmethod
+    def join_masks(*masks: int) -> int:
+        """the mask of a forest whose trees come from forests / descriptors with these masks: unknown if any is"""
+        out = 0
+        for m in masks:
+            if not m:
+                return 0
+            out |= m
+        return out
 
     # ---- construction -------------------------------------------------------------------------
     @staticmethod
@@ -65,7 +88,7 @@ class Forest:
             value, ntype, size = torch.ops.evogp_hip.tree_generate_offset(*args, tree_index_offset)
         else:
             value, ntype, size = torch.ops.evogp_cuda.tree_generate(*args)
-        return Forest(descriptor.input_len, descriptor.output_len, value, ntype, size)
+        return Forest(descriptor.input_len, descriptor.output_len, value, ntype, size, func_mask=descriptor.func_mask)
 
     @staticmethod
     def zero_generate(pop_size: int, max_tree_len: int, input_len: int, output_len: int) -> "Forest":
@@ -156,12 +179,15 @@ class Forest:
         # rows the breeding pass compiled ahead of this call (set_compiled_records): present the stamp as long as the three
         # tensors are the ones that pass returned, unmodified (identity + version counters); the engine checks the rest
         rec = getattr(self, "_records", None)
-        if rec is not None and inputs.is_cuda:
-            if rec[1] == self._forest_key():
-                return torch.ops.evogp_hip.tree_SR_fitness_stamped(self.pop_size, n, self.max_tree_len, self.input_len, self.output_len, use_MSE,
-                                                                   *self._tensors(), inputs.contiguous().to(torch.float32),
-                                                                   labels.contiguous().to(torch.float32), _SR_MODES[execute_mode], rec[0])
-            self._records = None
+        if rec is not None and rec[1] != self._forest_key():
+            rec = self._records = None
+        mask = self.func_mask
+        if inputs.is_cuda and (rec is not None or mask):
+            # what this object knows beyond the tensors: the stamp of records compiled ahead, the function set of the trees
+            return torch.ops.evogp_hip.tree_SR_fitness_stamped(self.pop_size, n, self.max_tree_len, self.input_len, self.output_len, use_MSE,
+                                                               *self._tensors(), inputs.contiguous().to(torch.float32),
+                                                               labels.contiguous().to(torch.float32), _SR_MODES[execute_mode],
+                                                               rec[0] if rec is not None else 0, mask)
         return torch.ops.evogp_cuda.tree_SR_fitness(self.pop_size, n, self.max_tree_len, self.input_len,
                                                     self.output_len, use_MSE, *self._tensors(),
                                                     inputs.contiguous().to(torch.float32),
@@ -179,7 +205,7 @@ class Forest:
         value, ntype, size = torch.ops.evogp_cuda.tree_mutate(
             self.pop_size, self.max_tree_len, *self._tensors(), replace_pos.contiguous().to(torch.int32),
             *new_sub_forest._tensors())
-        return Forest(self.input_len, self.output_len, value, ntype, size)
+        return Forest(self.input_len, self.output_len, value, ntype, size, func_mask=Forest.join_masks(self.func_mask, new_sub_forest.func_mask))
 
     def crossover(self, left_indices: Tensor, right_indices: Tensor, left_pos: Tensor, right_pos: Tensor) -> "Forest":
         """out[n] = self[left_indices[n]] with subtree left_pos[n] replaced by subtree right_pos[n] of
@@ -190,7 +216,7 @@ class Forest:
             assert t.shape == (n,), f"{name} shape should be ({n}, ), but got {t.shape}"
         value, ntype, size = torch.ops.evogp_cuda.tree_crossover(self.pop_size, n, self.max_tree_len,
                                                                  *self._tensors(), *idx)
-        return Forest(self.input_len, self.output_len, value, ntype, size)
+        return Forest(self.input_len, self.output_len, value, ntype, size, func_mask=self.func_mask)
 
     # ---- container protocol -------------------------------------------------------------------
     def __getitem__(self, index):
@@ -199,7 +225,7 @@ class Forest:
                         self.batch_subtree_size[index])
         if isinstance(index, (slice, Tensor, np.ndarray)):
             return Forest(self.input_len, self.output_len, self.batch_node_value[index],
-                          self.batch_node_type[index], self.batch_subtree_size[index])
+                          self.batch_node_type[index], self.batch_subtree_size[index], func_mask=self.func_mask)
         raise Exception(f"Do not support index type {type(index)}")
 
     def __setitem__(self, index, value):
@@ -210,9 +236,11 @@ class Forest:
             self.batch_subtree_size[index] = value.subtree_size
         elif isinstance(index, (slice, Tensor, np.ndarray)):
             assert isinstance(value, Forest), f"value should be Forest when index is slice, but got {type(value)}"
+            joined = Forest.join_masks(self.func_mask, value.func_mask)
             self.batch_node_value[index] = value.batch_node_value
             self.batch_node_type[index] = value.batch_node_type
             self.batch_subtree_size[index] = value.batch_subtree_size
+            self._func_mask = (joined, self._forest_key()) if joined else None
         else:
             raise NotImplementedError
 
@@ -234,7 +262,8 @@ class Forest:
         return Forest(self.input_len, self.output_len,
                       torch.cat([self.batch_node_value, parts[0]], dim=0),
                       torch.cat([self.batch_node_type, parts[1]], dim=0),
-                      torch.cat([self.batch_subtree_size, parts[2]], dim=0))
+                      torch.cat([self.batch_subtree_size, parts[2]], dim=0),
+                      func_mask=Forest.join_masks(self.func_mask, other.func_mask) if isinstance(other, Forest) else 0)
 
     def __radd__(self, other):
         return self.__add__(other)

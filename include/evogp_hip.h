@@ -183,6 +183,16 @@ int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsign
                                  int use_mse, const float *value, const int16_t *type, const int16_t *size,
                                  const float *variables, const float *labels, float *fitnesses, unsigned kernel_type,
                                  unsigned long long records_stamp, evogp_stream_t stream);
+/* ... and for a caller that also knows which functions can occur in the forest: bit f of function_mask = function id f
+ * (defs.h:10-57) may occur, 0 = unknown.  A fitness call is up to five launches of which three usually find nothing to do; a
+ * forest of + - * / and the unary functions of at most 64 nodes per tree cannot leave a tree for the general compiler, and without
+ * sin / cos / tan none can bail out at run time, so those launches are not made (5 -> 3 launches: ~10 us per call).  Whatever a
+ * tree carries that the mask did not promise is still evaluated correctly by the last follow-up kernel: a wrong mask costs
+ * speed, never a result.  evogp_amd.tree.Forest derives the mask from the GenerateDescriptors its trees came from. */
+int evogp_hip_sr_fitness_hinted(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len, unsigned out_len,
+                                int use_mse, const float *value, const int16_t *type, const int16_t *size,
+                                const float *variables, const float *labels, float *fitnesses, unsigned kernel_type,
+                                unsigned long long records_stamp, unsigned function_mask, evogp_stream_t stream);
 
 /* The same two passes with their random words computed in the kernels (no counterpart in the reference): word k of offspring i is
  * hash(seed, generation, k, i) -- exactly the numbers evogp_hip_random_words writes -- so no array of words is drawn, written and read

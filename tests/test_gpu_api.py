@@ -199,3 +199,52 @@ def test_program_record_buffer_is_capped_and_released():
     assert torch.equal(a.view(torch.int32), c.view(torch.int32))
     ok = torch.isfinite(a)
     assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.allclose(a[ok], b[ok], rtol=1e-5, atol=0)
+
+
+def test_function_mask_skips_launches_but_never_changes_a_result():
+    """A Forest remembers the function set of the descriptors its trees came from and tree_SR_fitness then leaves out the launches
+    such a forest cannot need (include/evogp_hip.h evogp_hip_sr_fitness_hinted: 5 -> 3 launches on + - * /).  The mask decides
+    which kernels run, never what they compute: bit-identical fitness where no tree needs a follow-up kernel, within the contract
+    where one does (a 40-entry operand stack), and a mask that promises too much (max / if / sin in a forest declared + - * /) is
+    caught by the last follow-up kernel."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.tree import Forest, GenerateDescriptor
+    from oracle.pyoracle import Oracle
+
+    dev = torch.device("cuda", 0)
+    oracle = Oracle("port")
+    X, y = c2_dataset()
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+
+    def raw(f):   # the same rows without any knowledge attached
+        return Forest(f.input_len, f.output_len, f.batch_node_value.clone(), f.batch_node_type.clone(), f.batch_subtree_size.clone())
+
+    desc = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6, const_samples=[-1, 0, 1])
+    f = Forest.random_generate(30_000, desc, keys=torch.tensor([42, 0], dtype=torch.uint32, device=dev))
+    assert f.func_mask == 0b11110 and raw(f).func_mask == 0
+    a, b = f.SR_fitness(Xd, yd), raw(f).SR_fitness(Xd, yd)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # handed on by the operators, dropped by an in-place edit
+    child = f.crossover(*(torch.zeros(100, dtype=torch.int32, device=dev) for _ in range(4)))
+    assert child.func_mask == f.func_mask and (f[:10] + f[10:20]).func_mask == f.func_mask
+    # a tree that needs a follow-up kernel: a left-deep chain of 31 subtractions (operand stack of 32 entries)
+    g = raw(f); g._func_mask = (0b11110, g._forest_key())
+    n = 63; k = (n - 1) // 2
+    v, t, s = g.batch_node_value, g.batch_node_type, g.batch_subtree_size
+    v[7] = 0; t[7] = 0; s[7] = 0
+    t[7, :k] = 3; v[7, :k] = 2.0; s[7, :k] = (n - 2 * torch.arange(k, device=dev)).to(torch.int16)
+    t[7, k:n] = 0; v[7, k:n] = (torch.arange(n - k, device=dev) % 10).float(); s[7, k:n] = 1
+    g._func_mask = (0b11110, g._forest_key())                     # (the edits above dropped it)
+    want = oracle.sr_fitness(v.cpu().numpy(), t.cpu().numpy(), s.cpu().numpy(), X, y)
+    for forest in (g, raw(g)):
+        assert_close_classes(forest.SR_fitness(Xd, yd).cpu().numpy(), want, 1e-5, what="deep tree")
+    # a mask that promises too much
+    wild = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "*", "max", "if", "sin"], max_layer_cnt=4, const_samples=[-1, 0, 1])
+    h = Forest.random_generate(5000, wild, keys=torch.tensor([5, 0], dtype=torch.uint32, device=dev))
+    honest = h.SR_fitness(Xd, yd)
+    lying = raw(h); lying._func_mask = (0b11110, lying._forest_key())
+    got = lying.SR_fitness(Xd, yd).cpu().numpy()
+    ok = np.isfinite(honest.cpu().numpy())
+    assert np.array_equal(np.isnan(got), np.isnan(honest.cpu().numpy())) and np.allclose(got[ok], honest.cpu().numpy()[ok], rtol=1e-4)

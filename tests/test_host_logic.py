@@ -194,3 +194,23 @@ def test_tournament_selection_replays_the_reference(case):
         for k in range(passes):
             block = c[k * per_pass:(k + 1) * per_pass].reshape(-1)
             assert block.unique().numel() == block.numel()
+
+
+def test_forest_function_mask_follows_the_trees():
+    """bit f of Forest.func_mask = function id f may occur; set from the descriptor, joined by the operators, unknown (0) for raw
+    tensors, after an in-place edit, or as soon as one source is unknown"""
+    d = desc()
+    assert d.func_mask == 0b11110
+    assert desc(using_funcs={"+": 1.0, "sin": 0.0, "if": 2.0}, max_layer_cnt=3).func_mask == 0b11          # zero weight: cannot be generated
+    assert GenerateDescriptor(64, 3, 1, roulette_funcs=d.roulette_funcs, depth2leaf_probs=d.depth2leaf_probs, const_samples=[0.0]).func_mask == 0
+    f = Forest.random_generate(30, d, keys=torch.tensor([1, 2]))
+    g = Forest.random_generate(30, desc(using_funcs=["sin", "+"]), keys=torch.tensor([3, 4]))
+    assert f.func_mask == 0b11110 and g.func_mask == (1 << 14) | 0b10
+    assert (f + g).func_mask == f.func_mask | g.func_mask and f[3:9].func_mask == f.func_mask
+    assert f.mutate(torch.zeros(30, dtype=torch.int32), g).func_mask == f.func_mask | g.func_mask
+    raw = Forest(3, 1, f.batch_node_value.clone(), f.batch_node_type.clone(), f.batch_subtree_size.clone())
+    assert raw.func_mask == 0 and (f + raw).func_mask == 0
+    f[0:5] = g[0:5]
+    assert f.func_mask == 0b11110 | (1 << 14)
+    f.batch_node_value[0, 0] = 3.0
+    assert f.func_mask == 0
