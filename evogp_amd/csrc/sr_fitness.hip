@@ -33,6 +33,7 @@
 // outputs) run entirely on the general kernel.  Malformed trees (stack underflow, final height
 // != 1 — the reference asserts, forward.cu:298-301) get a NaN fitness.
 #include "interp.hpp"
+#include <cstdio>
 #include "launch.hpp"
 #include <mutex>
 #include <vector>
@@ -292,10 +293,12 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
     // 3: the ONLY follow-up behind the threaded code when the launch hints skipped the general compiler and / or the FULL register
     // build: every tree that still carries a sentinel (too deep, heavy / run-time bail-out, left for the general compiler); it also
     // reports the call's marks for the hints of later calls
-    if (only_marked == 3 && p.marks) {
+    // 4: like 3, but the FULL register build ran in front (it has taken the heavy marks): too deep, or left for a general compiler
+    // that was not launched
+    if (only_marked >= 3 && p.marks) {
         const bool heavy = marks_pending(p, 0), general = marks_pending(p, 4);
         if (p.hint_words && blockIdx.x == 0 && lane == 0) { p.hint_words[0] = heavy ? 1u : 0u; p.hint_words[1] = general ? 1u : 0u; }
-        if (!heavy && !general && uni((int)p.marks[1]) == 0) return;
+        if ((!heavy || only_marked == 4) && !general && uni((int)p.marks[1]) == 0) return;
     }
     if (only_marked == 1 && p.marks && uni((int)p.marks[1]) == 0) return;  // no tree needs the general path
     if (only_marked == 2 && p.marks && !marks_pending(p, 0) && uni((int)p.marks[1]) == 0) return;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
         if (t < c1) {
             const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
             const uint32_t w = f2bits(*mark);
-            hit = w == kSentinelDeep || (only_marked >= 2 && w == kSentinelHeavy) || (only_marked == 3 && w == kSentinelGeneral);
+            hit = w == kSentinelDeep || (only_marked >= 2 && w == kSentinelHeavy) || (only_marked >= 3 && w == kSentinelGeneral);
         }
         unsigned long long m = __ballot(hit);
         while (m) {
@@ -485,20 +488,26 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     }
     if (!STORE && asm_depth == 3 && !mo && !profiling && p.func_mask != 0u && p.gp_len <= 64) {
         // The caller knows the forest's function set.  Nothing but + - * / and the unary functions with handlers of their own:
-        // no tree can be left for the general compiler (rows of at most 64 nodes), so that launch is not made; no sin / cos / tan
-        // either: no run-time bail-out can occur, and the FULL register build is not launched for the few trees whose operand stack
-        // is too deep for the threaded code -- the scratch-stack kernel (mode 3) takes every tree that still carries a sentinel, so
-        // a mask that promises too much costs speed, never a result.  Decided by the mask alone: the same forest always takes the
-        // same kernels (unlike the history-driven hints above).  5 launches -> 3 on the headline's function set.
+        // no tree can be left for the general compiler (rows of at most 64 nodes), so that launch is not made.  The last follow-up
+        // kernel (mode 4: behind the FULL build) also takes a tree that carries the general compiler's sentinel after all, so a mask
+        // that promises too much costs speed, never a result.  Decided by the mask alone: the same forest always takes the same
+        // kernels (unlike the history-driven hints above).  5 launches -> 4 on the headline's function set.
         constexpr unsigned kOwnHandlers = (1u << F_ADD) | (1u << F_SUB) | (1u << F_MUL) | (1u << F_DIV) | (1u << F_SIN) | (1u << F_COS) | (1u << F_TAN) |
                                           (1u << F_LOG) | (1u << F_LOOSE_LOG) | (1u << F_EXP) | (1u << F_INV) | (1u << F_NEG) | (1u << F_ABS) |
                                           (1u << F_SQRT) | (1u << F_LOOSE_SQRT);
         constexpr unsigned kBailOut = (1u << F_SIN) | (1u << F_COS) | (1u << F_TAN);
-        static const int env_mask = env_int("EVOGP_TC_FUNC_MASK", 1);   // 0: ignore the caller's mask (A/B)
-        if (env_mask && (p.func_mask & ~kOwnHandlers) == 0u) {
-            p.hint_general = 0;
-            if ((p.func_mask & kBailOut) == 0u) p.hint_heavy = 0;
-        }
+        // OFF by default (EVOGP_TC_FUNC_MASK=1 switches it on).  The promise does not hold: tree_generate's roulette scan returns
+        // function id 29 -- no function, a unary node worth 0 (forward.cu:117) -- whenever its uniform draw is exactly 1.0, which
+        // the reference's float(u32) * 2^-32 reaches once in ~3e7 draws (generate.cu:77-84): the headline's 1 M-tree forest holds
+        // one such tree (index 549654, EVOGP_DEBUG_MARKS=1 prints it), only the general compiler takes it, and without that launch
+        // the scratch-stack kernel spends 65 us on this ONE tree: 1.54 instead of 1.44 ms per call at 1 M trees, against 0.209
+        // instead of 0.214 at 125 k (profiles/r03r_shard_model*.log, r03s_kernel_stats_mask*.md).
+        static const int env_mask = env_int("EVOGP_TC_FUNC_MASK", 0);
+        if (env_mask && (p.func_mask & ~kOwnHandlers) == 0u) p.hint_general = 0;
+        // (Also leaving out the FULL register build where no run-time bail-out can occur was measured and taken back: the few
+        // trees whose operand stack is too deep for the threaded code -- there are always some in a million -- then go to the
+        // scratch-stack kernel, 1.54 instead of 1.44 ms at 1 M trees, profiles/r03r_shard_model.log.)
+        (void)kBailOut;
     }
     if (!STORE && asm_depth == 3) {
         // threaded-code path (sr_tc.hip); trees it cannot take come back marked for the FULL register build
@@ -532,7 +541,15 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         e = p.var_len <= 16 ? launch_pair<1, 32, 16, true, 16, STORE>(p, stream) : launch_pair<1, 32, 32, true, 16, STORE>(p, stream);
     }
     if (e != hipSuccess) return (int)e;
-    e = launch_general<STORE>(p, tc_done && !mo && (p.hint_words || !p.hint_general || !p.hint_heavy) ? 3 : 1, stream);
+    e = launch_general<STORE>(p, tc_done && !mo && (p.hint_words || !p.hint_general || !p.hint_heavy) ? (p.hint_heavy ? 4 : 3) : 1, stream);
+    static const bool dbg_marks = getenv("EVOGP_DEBUG_MARKS") != nullptr;   // diagnostics: the call's flag words (synchronises)
+    if (dbg_marks && p.marks) {
+        unsigned h[8] = {};
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, p.marks, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[evogp] sr_fitness pop %d: marks %u %u %u %u %u %u %u %u, hints general %d heavy %d, chunks %d\n", p.pop, h[0], h[1], h[2], h[3], h[4],
+                h[5], h[6], h[7], p.hint_general, p.hint_heavy, p.mark_chunks);
+    }
     prof_done(tc_done);
     return (int)e;
 }

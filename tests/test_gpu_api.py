@@ -203,7 +203,7 @@ def test_program_record_buffer_is_capped_and_released():
 
 def test_function_mask_skips_launches_but_never_changes_a_result():
     """A Forest remembers the function set of the descriptors its trees came from and tree_SR_fitness then leaves out the launches
-    such a forest cannot need (include/evogp_hip.h evogp_hip_sr_fitness_hinted: 5 -> 3 launches on + - * /).  The mask decides
+    such a forest cannot need (include/evogp_hip.h evogp_hip_sr_fitness_hinted: no general compiler on + - * /).  The mask decides
     which kernels run, never what they compute: bit-identical fitness where no tree needs a follow-up kernel, within the contract
     where one does (a 40-entry operand stack), and a mask that promises too much (max / if / sin in a forest declared + - * /) is
     caught by the last follow-up kernel."""
@@ -217,6 +217,8 @@ def test_function_mask_skips_launches_but_never_changes_a_result():
     oracle = Oracle("port")
     X, y = c2_dataset()
     Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    # (the engine honours the mask only under EVOGP_TC_FUNC_MASK=1, read once per process: whichever way this process reads it,
+    # the results below must hold)
 
     def raw(f):   # the same rows without any knowledge attached
         return Forest(f.input_len, f.output_len, f.batch_node_value.clone(), f.batch_node_type.clone(), f.batch_subtree_size.clone())
