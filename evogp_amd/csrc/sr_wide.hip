@@ -64,7 +64,9 @@ __global__ __launch_bounds__(64) void wide_deep_count_kernel(WideParams p) {
     const int lane = threadIdx.x;
     float stk[kMaxStack + 2];
     float o16[kMaxOutRegs];
-    const int d = (int)blockIdx.y * 64 + lane, dc = d < p.D ? d : p.D - 1;
+    const int nrb = (p.D + 63) / 64;
+    for (int rb = (int)blockIdx.y; rb < nrb; rb += (int)gridDim.y) {   // (the grid's y extent is capped: datasets beyond 4 M rows loop)
+    const int d = rb * 64 + lane, dc = d < p.D ? d : p.D - 1;
     for (int t0 = blockIdx.x * 64; t0 < p.pop; t0 += gridDim.x * 64) {
         // 64 count words at a time: which of these trees are marked
         const int tl = t0 + lane;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(64) void wide_deep_count_kernel(WideParams p) {
             if (lane == 0 && hits) atomicAdd(p.counts + t, hits);
         }
     }
+    }
 }
 
 // the three launches behind a fused count (threaded code: the count words of marked trees are bare marks already)
@@ -89,7 +92,8 @@ static hipError_t launch_deep_recount(const WideParams &p, bool words_are_bare_m
     if (!words_are_bare_marks) hipLaunchKernelGGL(wide_deep_clear_kernel, dim3(tb), dim3(256), 0, stream, p, 0);
     long blocks = ((long)p.pop + 63) / 64;
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks, (unsigned)((p.D + 63) / 64)), dim3(64), 0, stream, p);
+    const unsigned row_blocks = (unsigned)((p.D + 63) / 64);
+    hipLaunchKernelGGL(wide_deep_count_kernel, dim3((unsigned)blocks, row_blocks > 65535u ? 65535u : row_blocks), dim3(64), 0, stream, p);
     hipLaunchKernelGGL(wide_deep_clear_kernel, dim3(tb), dim3(256), 0, stream, p, 1);
     return hipGetLastError();
 }

@@ -222,8 +222,13 @@ class ShardedGeneticProgramming:
             lists = counter_based(fit_all, self.seed, self.generation)
             if lists is not None:
                 return lists
+        seed = int(_mix64(torch.tensor([self.seed * 1000003 + self.generation], dtype=torch.int64))[0]) & 0x7FFFFFFFFFFF
         with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else [], enabled=True):
-            torch.manual_seed(int(_mix64(torch.tensor([self.seed * 1000003 + self.generation], dtype=torch.int64))[0]) & 0x7FFFFFFFFFFF)
+            # seed exactly the generators that were forked: the CPU's and this device's (torch.manual_seed would also reseed the
+            # other devices of a process that holds several, and those are not restored)
+            torch.default_generator.manual_seed(seed)
+            if dev.type == "cuda":
+                torch.cuda.manual_seed(seed) if dev.index is None else torch.cuda.default_generators[dev.index].manual_seed(seed)
             try:
                 elites, parents = self.selection(_Population(pop), fit_all)
             except AttributeError as e:
