@@ -496,13 +496,14 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
                                           (1u << F_LOG) | (1u << F_LOOSE_LOG) | (1u << F_EXP) | (1u << F_INV) | (1u << F_NEG) | (1u << F_ABS) |
                                           (1u << F_SQRT) | (1u << F_LOOSE_SQRT);
         constexpr unsigned kBailOut = (1u << F_SIN) | (1u << F_COS) | (1u << F_TAN);
-        // OFF by default (EVOGP_TC_FUNC_MASK=1 switches it on).  The promise does not hold: tree_generate's roulette scan returns
-        // function id 29 -- no function, a unary node worth 0 (forward.cu:117) -- whenever its uniform draw is exactly 1.0, which
-        // the reference's float(u32) * 2^-32 reaches once in ~3e7 draws (generate.cu:77-84): the headline's 1 M-tree forest holds
-        // one such tree (index 549654, EVOGP_DEBUG_MARKS=1 prints it), only the general compiler takes it, and without that launch
-        // the scratch-stack kernel spends 65 us on this ONE tree: 1.54 instead of 1.44 ms per call at 1 M trees, against 0.209
-        // instead of 0.214 at 125 k (profiles/r03r_shard_model*.log, r03s_kernel_stats_mask*.md).
-        static const int env_mask = env_int("EVOGP_TC_FUNC_MASK", 0);
+        // (EVOGP_TC_FUNC_MASK=0 ignores the mask.)  The promise used to fail about once per million trees: tree_generate's roulette
+        // scan returns function id 29 -- no function, a unary node worth 0 (forward.cu:117) -- whenever its uniform draw is exactly
+        // 1.0, which the reference's float(u32) * 2^-32 reaches once in ~3e7 draws (generate.cu:77-84); the headline's forest holds
+        // one such tree (index 549654), only the general compiler took it, and without that launch the scratch-stack kernel spent
+        // 65 us on this ONE tree (1.54 instead of 1.44 ms per call, profiles/r03r_*, r03s_*).  The one-chunk compiler now takes
+        // such nodes itself (kUnaryZero, sr_tc.hip), which also spares the unmasked call the general compiler's scan of a million
+        // mark words: 1.443 -> 1.420 ms without the mask, 1.409 with it; 125 k trees 0.2115 / 0.2095 (profiles/r03u_shard_model_mask.log).
+        static const int env_mask = env_int("EVOGP_TC_FUNC_MASK", 1);
         if (env_mask && (p.func_mask & ~kOwnHandlers) == 0u) p.hint_general = 0;
         // (Also leaving out the FULL register build where no run-time bail-out can occur was measured and taken back: the few
         // trees whose operand stack is too deep for the threaded code -- there are always some in a million -- then go to the

@@ -187,9 +187,9 @@ int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsign
  * (defs.h:10-57) may occur, 0 = unknown.  A fitness call is up to five launches of which three usually find nothing to do; a
  * forest of + - * / and the unary functions of at most 64 nodes per tree cannot leave a tree for the general compiler, so that
  * launch need not be made (5 -> 4 launches: 5-11 us per call).  Whatever a tree carries that the mask did not promise is still
- * evaluated correctly by the last follow-up kernel: a wrong mask costs speed, never a result.  The engine IGNORES the mask unless
- * EVOGP_TC_FUNC_MASK=1: the promise fails once in a while -- tree_generate emits the invalid function id 29 when its uniform draw is
- * exactly 1.0 (generate.cu:77-84; one tree in the 1 M-tree headline forest) -- and that one tree then costs more than the launch saved.  evogp_amd.tree.Forest derives the mask from the GenerateDescriptors its trees came from. */
+ * evaluated correctly by the last follow-up kernel: a wrong mask costs speed, never a result.  (tree_generate emits the
+ * invalid function id 29 when its uniform draw is exactly 1.0 -- generate.cu:77-84, one tree in the 1 M-tree headline forest; the
+ * compiler takes such nodes itself, so they do not break the promise.)  EVOGP_TC_FUNC_MASK=0 makes the engine ignore the mask.  evogp_amd.tree.Forest derives the mask from the GenerateDescriptors its trees came from. */
 int evogp_hip_sr_fitness_hinted(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len, unsigned out_len,
                                 int use_mse, const float *value, const int16_t *type, const int16_t *size,
                                 const float *variables, const float *labels, float *fitnesses, unsigned kernel_type,
