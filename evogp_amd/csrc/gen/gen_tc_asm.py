@@ -73,7 +73,7 @@ GBIN = ("ldiv", "max", "min", "lt", "gt", "le", "ge", "pow", "lpow")  # bodies b
 GUN = ("zero", "sinh", "cosh", "tanh", "one", "rcp")                  # bodies behind the generic unary stubs (sr_tc.hip GU_*)
 HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top of the operand stack (the compiler keeps it free)
 SLOT = 256  # bytes per handler slot
-DIVIP_REGS = 5  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
+DIVIP_REGS = 6  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
 DIVIP = ("SS", "SC", "CS")  # division forms with an in-place handler (operands read where they are, temporaries above the stack)
 NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls
 
@@ -81,6 +81,9 @@ NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
 SPLAT = False    # EVOGP_TC_GEN_SPLAT=1: copy a constant operand into a VGPR before the row loop (experiment: 1.5 % SLOWER at 1 M trees)
 FMA_LOSS = False  # EVOGP_TC_GEN_FMA_LOSS=1: accumulate squared errors with one fused multiply-add (timing experiment)
+DIVFIX = False   # the range-tested rows end in v_div_fixup (EVOGP_TC_GEN_DIVFIX=1: an experiment; it changes nothing but NaN payloads)
+DIVRANGE = True  # short division: blocks whose operands all lie in [2^-46, 2^46] take rows without range scaling, residuals as v_pk_fma over row pairs (EVOGP_TC_GEN_DIVRANGE=0: off)
+DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such operands alone (|exponent difference| < 96, no denormal in sight)
 KWARM = True  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=0 at generation time disables it)
 
 
@@ -584,6 +587,126 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"v_fma_f32 v{d3}, -v{d3}, v{d7}, v{d6}")
             a(f"v_div_fmas_f32 v{q}, v{d3}, v{d4}, v{d7}")
 
+    # ---- the short division without its range scaling.  v_div_scale changes an operand only when an exponent is extreme
+    # (numerator and denominator 2^96 apart, a denormal operand, reciprocal or quotient; MI300 ISA, V_DIV_SCALE_F32); where it
+    # does not, the short rows are  r = rcp(y), q0 = x * r, e = fma(-y, q0, x), q = fma(e, r, q0)  -- v_div_fmas is a plain fma
+    # when VCC is clear -- and v_div_fixup hands a finite quotient of finite operands through.  A block whose 2 K operands all
+    # lie in [2^-46, 2^46] (NaN operands pass: they give NaN either way) runs exactly these operations, the two fmas as
+    # v_pk_fma_f32 over row pairs (two fmas for the issue slot of one, scripts/ubench/valu_rates.hip), the second one straight
+    # into the result's place: 14 instead of 31 VALU clocks per row, the same bits for every quotient that is a number (a NaN
+    # may carry another payload: the tree's sum is canonicalised where it leaves the wave).  The test is one v_min3 and one
+    # v_max3 per two values, kept apart for numerator and denominator, because the blocks that fail it are nearly always
+    # (headline forest: always) a numerator or a denominator that is +-0 in every row and lane -- the constant 0 and what
+    # multiplications make of it: such a block is K v_div_fixup (0 / y) or K moves of NaN (x / 0, forward.cu:183-187).
+    # Any other block takes the rows with v_div_scale / v_div_fmas.
+    use_range = DIVRANGE and fast == 2 and K >= 2
+
+    def minmax(vals, lo, hi):
+        vals = [opnd(o) for o in vals]
+        assert all(o.startswith("v") for o in vals) and len(vals) >= 3
+        a(f"v_min3_f32 v{lo}, |{vals[0]}|, |{vals[1]}|, |{vals[2]}|")
+        a(f"v_max3_f32 v{hi}, |{vals[0]}|, |{vals[1]}|, |{vals[2]}|")
+        rest = vals[3:]
+        while len(rest) >= 2:
+            a(f"v_min3_f32 v{lo}, v{lo}, |{rest[0]}|, |{rest[1]}|")
+            a(f"v_max3_f32 v{hi}, v{hi}, |{rest[0]}|, |{rest[1]}|")
+            rest = rest[2:]
+        if rest:
+            a(f"v_min_f32 v{lo}, v{lo}, |{rest[0]}|")
+            a(f"v_max_f32 v{hi}, v{hi}, |{rest[0]}|")
+
+    def range_test(xvals, yvals, t, slow, between=None):
+        """-> registers {lox, hix, loy, hiy} (those of an operand that is no constant); falls through when every value is in
+        range or NaN, goes to `slow` otherwise.  between(): scalar tests placed behind the statistics"""
+        st = {}
+        if xvals:
+            minmax(xvals, t[0], t[1])
+            st["lox"], st["hix"] = t[0], t[1]
+        if yvals:
+            minmax(yvals, t[2], t[3])
+            st["loy"], st["hiy"] = t[2], t[3]
+        if xvals and yvals:
+            a(f"v_min_f32 v{t[4]}, v{t[0]}, v{t[2]}")
+            a(f"v_max_f32 v{t[5]}, v{t[1]}, v{t[3]}")
+            lo, hi = t[4], t[5]
+        else:
+            lo, hi = (t[0], t[1]) if xvals else (t[2], t[3])
+        if between:
+            between()
+        a(f"v_cmp_gt_f32 vcc, {hex(DIV_LO)}, v{lo}")
+        a(f"s_cbranch_vccnz {slow}")
+        a(f"v_cmp_lt_f32 vcc, {hex(DIV_HI)}, v{hi}")
+        a(f"s_cbranch_vccnz {slow}")
+        return st
+
+    def pk(o, k):
+        """operand of a packed instruction for rows k, k + 1: an aligned register pair -> (text, op_sel_hi bit); a constant's
+        SGPR is read for both rows (op_sel_hi 0: the high lane takes the low dword too)"""
+        if isinstance(o, str):
+            n = int(o[1:])
+            assert o[0] == "s" and n % 2 == 0, o
+            return f"s[{n}:{n + 1}]", 0
+        assert o[k] % 2 == 0 and o[k + 1] == o[k] + 1, o
+        return f"v[{o[k]}:{o[k] + 1}]", 1
+
+    def fast_pair_rows(xs, ys, temps, out, out_m0=None):
+        """rows of a range-tested block.  xs / ys: K VGPR numbers, or ONE SGPR string for a constant operand; the quotient of
+        row k goes to out[k].  out_m0: SGPR holding the M0 that indexes the destination (gather bodies: only the result is
+        indexed, so M0 is switched around the one instruction that writes it); None: M0 stays as it is (in-place handlers:
+        every operand is indexed)"""
+        r0, r1, q0, q1, e0, e1 = temps
+        assert r0 % 2 == 0 and q0 % 2 == 0 and e0 % 2 == 0 and (r1, q1, e1) == (r0 + 1, q0 + 1, e0 + 1)
+        cx, cy = isinstance(xs, str), isinstance(ys, str)
+        if cy:  # one reciprocal serves the block
+            a(f"v_rcp_f32 v{r0}, {ys}")
+            a("s_nop 0")
+            a(f"v_mov_b32 v{r1}, v{r0}")
+        for k in range(0, K, 2):
+            x = [xs, xs] if cx else [f"v{xs[k]}", f"v{xs[k + 1]}"]
+            y = [ys, ys] if cy else [f"v{ys[k]}", f"v{ys[k + 1]}"]
+            if not cy:
+                a(f"v_rcp_f32 v{r0}, {y[0]}")
+                a(f"v_rcp_f32 v{r1}, {y[1]}")   # (also the wait state between a transcendental and the reader of its result)
+            a(f"v_mul_f32 v{q0}, {x[0]}, v{r0}")
+            a(f"v_mul_f32 v{q1}, {x[1]}, v{r1}")
+            xp, xh = pk(xs, k)
+            yp, yh = pk(ys, k)
+            assert out[k] % 2 == 0 and out[k + 1] == out[k] + 1
+            a(f"v_pk_fma_f32 v[{e0}:{e1}], {yp}, v[{q0}:{q1}], {xp} op_sel_hi:[{yh},1,{xh}] neg_lo:[1,0,0] neg_hi:[1,0,0]")
+            if DIVFIX:
+                a(f"v_pk_fma_f32 v[{e0}:{e1}], v[{e0}:{e1}], v[{r0}:{r1}], v[{q0}:{q1}]")
+            if out_m0 is not None:
+                a(f"s_mov_b32 m0, s{out_m0}")
+            if DIVFIX:
+                a(f"v_div_fixup_f32 v{out[k]}, v{e0}, {y[0]}, {x[0]}")
+                a(f"v_div_fixup_f32 v{out[k + 1]}, v{e1}, {y[1]}, {x[1]}")
+            else:
+                a(f"v_pk_fma_f32 v[{out[k]}:{out[k] + 1}], v[{e0}:{e1}], v[{r0}:{r1}], v[{q0}:{q1}]")
+            if out_m0 is not None and k + 2 < K:
+                a("s_mov_b32 m0, 0")
+
+    def zero_blocks(st, xzero, yzero):
+        """behind a failed range test: a numerator that is +-0 (or NaN) in every row and lane -> label xzero, a denominator
+        likewise -> yzero; falls through for any other block.  The two labels' rows are emitted by zero_rows."""
+        if "hix" in st:
+            a(f"v_cmp_neq_f32 vcc, 0, v{st['hix']}")
+            a(f"s_cbranch_vccz {xzero}")
+        if "hiy" in st:
+            a(f"v_cmp_neq_f32 vcc, 0, v{st['hiy']}")
+            a(f"s_cbranch_vccz {yzero}")
+
+    def zero_rows(kind, xs, ys, out, relative):
+        """kind 'x': 0 / y  = +-0, or NaN where y is 0 or NaN -- v_div_fixup's own rules, its quotient operand is not looked at;
+        kind 'y': x / 0 = NaN whatever x is (forward.cu:183-187).  relative: the sources are indexed too (in-place handlers), so
+        the NaN comes as a literal and not from v8"""
+        for k in range(K):
+            x = xs if isinstance(xs, str) else f"v{xs[k]}"
+            y = ys if isinstance(ys, str) else f"v{ys[k]}"
+            if kind == "x":
+                a(f"v_div_fixup_f32 v{out[k]}, {y if not isinstance(ys, str) else x}, {y}, {x}")
+            else:
+                a(f"v_mov_b32 v{out[k]}, " + ("0x7fc00000" if relative else "v8"))
+
     for fl in (0, 1):
         cur, nxt = P[fl], P[1 - fl]
         for op in ("add", "sub", "mul"):
@@ -831,7 +954,41 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 xs, ys = [f"s{sA}"] * K, [S0 + k for k in range(K)]
             else:
                 xs, ys = [S0 + k for k in range(K)], [f"s{sBop}"] * K
-            if form != "SC":  # (the compiler turns a division by the constant 0 into a multiplication by NaN)
+            out = [S0 + k for k in range(K)]
+            if use_range:
+                slow, gen_, xz, yz = (lab(f"divip_{n}_{form}{fl}") for n in ("slow", "gen", "xz", "yz"))
+                cx, cy = (f"s{sA}" if form == "CS" else None), (f"s{sBop}" if form == "SC" else None)
+                if form != "SS":
+                    a(f"s_and_b32 s{T1}, s{sA}, 0x7fffffff")
+                if form == "CS":  # 0 / y needs no look at y
+                    a(f"s_cmp_eq_u32 s{T1}, 0")
+                    a(f"s_cbranch_scc1 {xz}")
+
+                def const_range():  # the constant operand: one scalar test
+                    a(f"s_sub_u32 s{T1}, s{T1}, {hex(DIV_LO)}")
+                    a(f"s_cmp_gt_u32 s{T1}, {hex(DIV_HI - DIV_LO)}")
+                    a(f"s_cbranch_scc1 {gen_}")
+
+                st = range_test([] if cx else xs, [] if cy else ys, tmp, slow, between=const_range if form != "SS" else None)
+                fast_pair_rows(cx or xs, cy or ys, tmp, out)
+                if form == "SS":
+                    a(f"s_sub_u32 s{sH}, s{sH}, {K}")
+                epilogue()
+                for kind, l in (("x", xz), ("y", yz)):
+                    if kind == "y" and form == "SC":
+                        continue  # (the compiler turns a division by the constant 0 into a multiplication by NaN)
+                    a(f"{l}:")
+                    zero_rows(kind, cx or xs, cy or ys, out, relative=True)
+                    if form == "SS":
+                        a(f"s_sub_u32 s{sH}, s{sH}, {K}")
+                    epilogue()
+                a(f"{slow}:")
+                zero_blocks(st, xz, yz)
+                a(f"{gen_}:")
+                if form != "SC":
+                    a(f"v_cmp_eq_f32 vcc, 0, v{st['loy']}")
+                    a(f"s_cbranch_vccnz {lab(f'divold_{form}{fl}')}")
+            elif form != "SC":  # (the compiler turns a division by the constant 0 into a multiplication by NaN)
                 if K >= 3:
                     a(f"v_min3_f32 v{acc}, |v{ys[0]}|, |v{ys[1]}|, |v{ys[2]}|")
                     rest = ys[3:]
@@ -846,7 +1003,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 a(f"v_cmp_eq_f32 vcc, 0, v{acc}")
                 a(f"s_cbranch_vccnz {lab(f'divold_{form}{fl}')}")
             for k in range(K):
-                div_rows([xs[k]], [ys[k]], [q], nanfix=False, temps=tmp)
+                div_rows([xs[k]], [ys[k]], [q], nanfix=False, temps=tmp[:5])
                 a(f"v_div_fixup_f32 v{S0 + k}, v{q}, {opnd(ys[k])}, {opnd(xs[k])}")
             if form == "SS":
                 a(f"s_sub_u32 s{sH}, s{sH}, {K}")
@@ -862,18 +1019,34 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             # turn the numerator into NaN.  (A NaN divisor drops out of the minimum and makes its quotient NaN anyway.)
             ys_ = [y + k for k in range(K)]
             acc = DT[0]
-            if K >= 3:
-                a(f"v_min3_f32 v{acc}, |v{ys_[0]}|, |v{ys_[1]}|, |v{ys_[2]}|")
-                rest = ys_[3:]
+            xs_ = [x + k for k in range(K)]
+            out = [S0 + k for k in range(K)]
+            if use_range:
+                slow, xz, yz = (lab(f"div{n}_{kind}{fl}") for n in ("slow", "xz", "yz"))
+                st = range_test(xs_, ys_, [18, 19, 20, 21, 22, 23], slow)
+                fast_pair_rows(xs_, ys_, [18, 19, 20, 21, 22, 23], out, out_m0=sDST)
+                epilogue()
+                for kd, l in (("x", xz), ("y", yz)):
+                    a(f"{l}:")
+                    a(f"s_mov_b32 m0, s{sDST}")
+                    zero_rows(kd, xs_, ys_, out, relative=False)
+                    epilogue()
+                a(f"{slow}:")
+                zero_blocks(st, xz, yz)
+                a(f"v_cmp_eq_f32 vcc, 0, v{st['loy']}")
             else:
-                a(f"v_and_b32 v{acc}, 0x7fffffff, v{ys_[0]}")
-                rest = ys_[1:]
-            while len(rest) >= 2:
-                a(f"v_min3_f32 v{acc}, v{acc}, |v{rest[0]}|, |v{rest[1]}|")
-                rest = rest[2:]
-            if rest:
-                a(f"v_min_f32 v{acc}, v{acc}, |v{rest[0]}|")
-            a(f"v_cmp_eq_f32 vcc, 0, v{acc}")
+                if K >= 3:
+                    a(f"v_min3_f32 v{acc}, |v{ys_[0]}|, |v{ys_[1]}|, |v{ys_[2]}|")
+                    rest = ys_[3:]
+                else:
+                    a(f"v_and_b32 v{acc}, 0x7fffffff, v{ys_[0]}")
+                    rest = ys_[1:]
+                while len(rest) >= 2:
+                    a(f"v_min3_f32 v{acc}, v{acc}, |v{rest[0]}|, |v{rest[1]}|")
+                    rest = rest[2:]
+                if rest:
+                    a(f"v_min_f32 v{acc}, v{acc}, |v{rest[0]}|")
+                a(f"v_cmp_eq_f32 vcc, 0, v{acc}")
             a(f"s_cbranch_vccnz {lab(f'divzero_{kind}{fl}')}")
             for variant in (False, True):
                 if variant:
@@ -1526,6 +1699,11 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"v_add_f32_dpp v6, v6, v6 {ctl}")
     a("s_nop 1")
     a(f"v_readlane_b32 s{T1}, v6, 63")
+    # a NaN sum leaves as THE quiet NaN: which operand's payload an instruction hands on is its own business (the division rows
+    # above differ in it), and a payload must never look like one of the register kernels' sentinels
+    a(f"s_and_b32 s{T2}, s{T1}, 0x7fffffff")
+    a(f"s_cmp_gt_u32 s{T2}, 0x7f800000")
+    a(f"s_cselect_b32 s{T1}, 0x7fc00000, s{T1}")
     a(f"s_mov_b32 m0, s{sB}")
     a(f"s_bitset1_b64 s[{sOK}:{sOK + 1}], s{sB}")
     a(f"v_writelane_b32 v7, s{T1}, m0")
@@ -1636,6 +1814,8 @@ if __name__ == "__main__":
     NOPF = os.environ.get("EVOGP_TC_GEN_NOPF", "0") == "1"
     FMA_LOSS = os.environ.get("EVOGP_TC_GEN_FMA_LOSS", "0") == "1"
     SPLAT = os.environ.get("EVOGP_TC_GEN_SPLAT", "0") == "1"
+    DIVRANGE = os.environ.get("EVOGP_TC_GEN_DIVRANGE", "1") != "0"
+    DIVFIX = os.environ.get("EVOGP_TC_GEN_DIVFIX", "0") == "1"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}

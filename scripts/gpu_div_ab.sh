@@ -1,0 +1,22 @@
+#!/bin/bash
+# A/B of interpreter builds: the library in evogp_amd/lib against every evogp_amd/lib/libevogp_hip_<variant>.so
+# (scripts/build_variant.sh), fitness words compared bit for bit.   gpurun -- 'bash scripts/gpu_div_ab.sh TAG'
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+TAG=${1:-divab}
+mkdir -p $OUT
+cd $R
+{
+  timeout 600 python scripts/dbg/div_range_ab.py run new
+  cp evogp_amd/lib/libevogp_hip.so /tmp/keep.so
+  for alt in evogp_amd/lib/libevogp_hip_*.so; do
+    v=$(basename $alt .so); v=${v#libevogp_hip_}
+    cp $alt evogp_amd/lib/libevogp_hip.so
+    timeout 600 python scripts/dbg/div_range_ab.py run $v
+    cp /tmp/keep.so evogp_amd/lib/libevogp_hip.so
+    python scripts/dbg/div_range_ab.py cmp new $v
+    echo "cmp new $v rc=$?"
+  done
+} > $OUT/${TAG}_divab.log 2>&1
+rm -f $OUT/divab_*.npz
+grep -v "amdgpu.ids\|RuntimeWarning\|Xw = " $OUT/${TAG}_divab.log | tail -60 | cut -c1-250
