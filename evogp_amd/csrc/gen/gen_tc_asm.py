@@ -81,6 +81,7 @@ NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
 SPLAT = False    # EVOGP_TC_GEN_SPLAT=1: copy a constant operand into a VGPR before the row loop (experiment: 1.5 % SLOWER at 1 M trees)
 FMA_LOSS = False  # EVOGP_TC_GEN_FMA_LOSS=1: accumulate squared errors with one fused multiply-add (timing experiment)
+TRUST = True     # divisions by / of a dataset variable whose whole column is in range skip the range test (EVOGP_TC_GEN_TRUST=0: off)
 DIVFIX = False   # the range-tested rows end in v_div_fixup (EVOGP_TC_GEN_DIVFIX=1: an experiment; it changes nothing but NaN payloads)
 DIVRANGE = True  # short division: blocks whose operands all lie in [2^-46, 2^46] take rows without range scaling, residuals as v_pk_fma over row pairs (EVOGP_TC_GEN_DIVRANGE=0: off)
 DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such operands alone (|exponent difference| < 96, no denormal in sight)
@@ -243,6 +244,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_load_dwordx2 s[{P3_}:{P4_}], %[karg], 0x10")  # work counter
     a("s_load_dwordx8 s[12:19], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, query, record stride
     a("s_waitcnt lgkmcnt(0)")
+    a(f"s_or_b32 s17, s17, {BASE}")               # BASE carries the trusted-variable bits (17-30, and 5-7) on entry
     a(f"v_mov_b32 v10, s{P3_}")
     a(f"v_mov_b32 v11, s{P4_}")
     a("s_mul_i32 s14, s14, s15")
@@ -501,7 +503,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         if form == "VV":
             a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
             read_bank(T, 5)
+        vtrust = use_range and TRUST and form in ("CV", "VV", "SV", "VS")
+        if vtrust:
+            a(f"s_movrels_b32 s{T1}, s{W}")  # this instruction's word: its top byte names the variable in the current bank
         prefetch(nxt)
+        if vtrust and form in ("CV", "VV"):
+            # a variable whose column lies in [2^-46, 2^46] (flags bits 17-30, sr_tc_kernel) needs no range test: c / v and v / w
+            # have bodies of their own that read the operands where they are; anything else comes back to the label below
+            a(f"s_branch {lab(f'divv_{form}{fl}')}")
+            a(f"{lab(f'divv_old_{form}{fl}')}:")
         if form in DIVIP:
             a(f"{lab(f'divold_{form}{fl}')}:")  # the in-place handler of this form arrives here when its block holds a zero divisor
         wait_cur()  # the current bank is overwritten or read below: its (possibly unused) prefetch must have landed
@@ -528,7 +538,24 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         if rb == "C":
             for k in range(K):
                 a(f"v_mov_b32 v{y + k}, s{sBop}")
-        a(f"s_branch {lab(f'divbody_{kind}{fl}')}")
+        if vtrust and form in ("SV", "VS"):  # only the stack operand (now in T) needs the test when the variable is trusted
+            trust_test(T1, 24, lab(f"divbody_{kind}{fl}"))
+            a(f"s_branch {lab(f'divbody_{kind}{fl}_t')}")
+        else:
+            a(f"s_branch {lab(f'divbody_{kind}{fl}')}")
+
+    def trust_test(reg, shift, untrusted):
+        """s{reg} >> (shift + flags[7:5]) = index of a variable (flags[7:5] = log2 of the 1-KiB units between two variables in LDS,
+        set with the trust bits by sr_tc_kernel's prologue, which trusts nobody when that distance is no power of two); falls
+        through when the prologue found the variable's whole column in range (flags bit 17 + index; bit 31 is never set and
+        stands for every variable from the 14th on)"""
+        a(f"s_bfe_u32 s{T2}, s17, 0x30005")
+        a(f"s_add_u32 s{T2}, s{T2}, {shift}")
+        a(f"s_lshr_b32 s{reg}, s{reg}, s{T2}")
+        a(f"s_add_u32 s{reg}, s{reg}, 17")
+        a(f"s_min_u32 s{reg}, s{reg}, 31")
+        a(f"s_bitcmp1_b32 s17, s{reg}")
+        a(f"s_cbranch_scc0 {untrusted}")
 
     def opnd(o):
         return o if isinstance(o, str) else f"v{o}"
@@ -1013,7 +1040,6 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     for fl in (0, 1):
         for kind in ("Tc", "cT"):
             x, y = (T, P[fl]) if kind == "Tc" else (P[fl], T)
-            a(f"{lab(f'divbody_{kind}{fl}')}:")
             # `b == 0 ? NaN : a / b` (forward.cu:183-187): ONE test for a zero divisor anywhere in the K x 64 block -- the
             # smallest |b| -- instead of a compare and a select per row; only a block with a zero takes the rows that
             # turn the numerator into NaN.  (A NaN divisor drops out of the minimum and makes its quotient NaN anyway.)
@@ -1021,20 +1047,35 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             acc = DT[0]
             xs_ = [x + k for k in range(K)]
             out = [S0 + k for k in range(K)]
+            TT = [18, 19, 20, 21, 22, 23]
             if use_range:
-                slow, xz, yz = (lab(f"div{n}_{kind}{fl}") for n in ("slow", "xz", "yz"))
-                st = range_test(xs_, ys_, [18, 19, 20, 21, 22, 23], slow)
-                fast_pair_rows(xs_, ys_, [18, 19, 20, 21, 22, 23], out, out_m0=sDST)
+                slow, slow_t, xz, yz, rows, gen_, nz = (lab(f"div{n}_{kind}{fl}") for n in ("slow", "slowt", "xz", "yz", "rows", "gen", "nz"))
+                if TRUST:
+                    # entry for a TRUSTED variable in the current bank (its column is in range, div_stub): only the other operand,
+                    # the copy of a stack entry in T, is tested
+                    a(f"{lab(f'divbody_{kind}{fl}_t')}:")
+                    st_t = range_test(xs_ if kind == "Tc" else [], ys_ if kind == "cT" else [], TT, slow_t)
+                    a(f"s_branch {rows}")
+                a(f"{lab(f'divbody_{kind}{fl}')}:")
+                st = range_test(xs_, ys_, TT, slow)
+                a(f"{rows}:")
+                fast_pair_rows(xs_, ys_, TT, out, out_m0=sDST)
                 epilogue()
                 for kd, l in (("x", xz), ("y", yz)):
                     a(f"{l}:")
                     a(f"s_mov_b32 m0, s{sDST}")
                     zero_rows(kd, xs_, ys_, out, relative=False)
                     epilogue()
+                if TRUST:
+                    a(f"{slow_t}:")
+                    zero_blocks(st_t, xz, yz)
+                    a(f"s_branch {nz if kind == 'Tc' else gen_}")  # a trusted divisor holds no zero
                 a(f"{slow}:")
                 zero_blocks(st, xz, yz)
+                a(f"{gen_}:")
                 a(f"v_cmp_eq_f32 vcc, 0, v{st['loy']}")
             else:
+                a(f"{lab(f'divbody_{kind}{fl}')}:")
                 if K >= 3:
                     a(f"v_min3_f32 v{acc}, |v{ys_[0]}|, |v{ys_[1]}|, |v{ys_[2]}|")
                     rest = ys_[3:]
@@ -1048,6 +1089,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                     a(f"v_min_f32 v{acc}, v{acc}, |v{rest[0]}|")
                 a(f"v_cmp_eq_f32 vcc, 0, v{acc}")
             a(f"s_cbranch_vccnz {lab(f'divzero_{kind}{fl}')}")
+            if use_range:
+                a(f"{nz}:")
             for variant in (False, True):
                 if variant:
                     a(f"{lab(f'divzero_{kind}{fl}')}:")
@@ -1057,6 +1100,56 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                     a(f"v_div_fixup_f32 v{S0 + k}, v{Q + k}, v{y + k}, v{x + k}")
                 epilogue()
 
+    # c / v and v / w with trusted variables: no gather, no test.  The operands are read where they are (the constant from its SGPR,
+    # variables from their banks), the quotient goes straight to the new stack entry.
+    if use_range and TRUST:
+        TT = [18, 19, 20, 21, 22, 23]
+        out = [S0 + k for k in range(K)]
+
+        def push_dst():
+            a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
+            a(f"s_add_u32 s{sH}, s{sH}, {K}")
+
+        for fl in (0, 1):
+            cur = [P[fl] + k for k in range(K)]
+            old_, rows, test, xz = (lab(f"divv_{n}_CV{fl}") for n in ("old", "rows", "test", "xz"))
+            a(f"{lab(f'divv_CV{fl}')}:")
+            a(f"s_and_b32 s{T2}, s{sA}, 0x7fffffff")
+            a(f"s_cmp_eq_u32 s{T2}, 0")
+            a(f"s_cbranch_scc1 {xz}")
+            a(f"s_sub_u32 s{T2}, s{T2}, {hex(DIV_LO)}")
+            a(f"s_cmp_gt_u32 s{T2}, {hex(DIV_HI - DIV_LO)}")
+            a(f"s_cbranch_scc1 {old_}")
+            trust_test(T1, 24, test)
+            wait_cur()
+            a(f"{rows}:")
+            push_dst()
+            fast_pair_rows(f"s{sA}", cur, TT, out, out_m0=sDST)
+            epilogue()
+            a(f"{test}:")  # a variable with a value out of range somewhere: this block's values decide
+            wait_cur()
+            minmax(cur, TT[2], TT[3])
+            a(f"v_cmp_gt_f32 vcc, {hex(DIV_LO)}, v{TT[2]}")
+            a(f"s_cbranch_vccnz {old_}")
+            a(f"v_cmp_lt_f32 vcc, {hex(DIV_HI)}, v{TT[3]}")
+            a(f"s_cbranch_vccnz {old_}")
+            a(f"s_branch {rows}")
+            a(f"{xz}:")    # 0 / v
+            wait_cur()
+            push_dst()
+            a(f"s_mov_b32 m0, s{sDST}")
+            zero_rows("x", f"s{sA}", cur, out, relative=False)
+            epilogue()
+            # v / w
+            old_ = lab(f"divv_old_VV{fl}")
+            a(f"{lab(f'divv_VV{fl}')}:")
+            trust_test(T1, 24, old_)
+            a(f"s_mov_b32 s{T1}, s{sBop}")
+            trust_test(T1, 6, old_)               # the second variable: its operand word is its LDS offset / 16
+            wait_cur()
+            push_dst()
+            fast_pair_rows(cur, [T + k for k in range(K)], TT, out, out_m0=sDST)
+            epilogue()
 
     # ---- library sequences run row by row (pow, sinh, cosh: 120-190 instructions and 14-24 registers each; K unrolled
     # copies would not fit anywhere).  The row loop reads its operands and writes its result through M0-relative
@@ -1816,6 +1909,7 @@ if __name__ == "__main__":
     SPLAT = os.environ.get("EVOGP_TC_GEN_SPLAT", "0") == "1"
     DIVRANGE = os.environ.get("EVOGP_TC_GEN_DIVRANGE", "1") != "0"
     DIVFIX = os.environ.get("EVOGP_TC_GEN_DIVFIX", "0") == "1"
+    TRUST = os.environ.get("EVOGP_TC_GEN_TRUST", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}

@@ -41,6 +41,23 @@ def forests():
     e = np.where(rng.random((1024, 10)) < 0.5, e, np.sign(e) * 46 + rng.integers(-2, 3, (1024, 10)))
     Xb = (np.ldexp(1.0 + (rng.random((1024, 10)) < 0.3) * rng.random((1024, 10)), e) * rng.choice([-1.0, 1.0], (1024, 10))).astype(np.float32)
     yield "boundary_200k", wide, torch.from_numpy(Xb).to(dev), torch.from_numpy(yw).to(dev)
+    # some variables trusted (their column in range), some not: one zero in column 3, column 7 beyond 2^46
+    Xm = X.copy()
+    Xm[5, 3] = 0.0
+    Xm[:, 7] *= 1e20
+    yield "mixed_trust_200k", forest[:200_000], torch.from_numpy(Xm).to(dev), yd
+    # three tiles (the distance between two variables in LDS is no power of two: nobody is trusted) and four
+    Xm2 = np.concatenate([Xm, Xm[::-1]]).astype(np.float32)
+    ym2 = np.concatenate([y, y[::-1]]).astype(np.float32)
+    yield "mixed_trust_1536rows", forest[:100_000], torch.from_numpy(Xm2[:1536].copy()).to(dev), torch.from_numpy(ym2[:1536].copy()).to(dev)
+    yield "mixed_trust_2048rows", forest[:100_000], torch.from_numpy(Xm2).to(dev), torch.from_numpy(ym2).to(dev)
+    # more variables than trust bits (14)
+    d20 = GenerateDescriptor(max_tree_len=64, input_len=20, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6, const_samples=[-1, 0, 1, 2.5])
+    f20 = Forest.random_generate(100_000, d20, keys=torch.tensor([3, 9], dtype=torch.uint32, device=dev))
+    X20 = rng.uniform(-5, 5, (1024, 20)).astype(np.float32)
+    X20[:, 16] *= 1e-30
+    X20[7, 2] = 0.0
+    yield "vars20_100k", f20, torch.from_numpy(X20).to(dev), yd
     # K = 4 and K = 1 interpreters (short datasets)
     yield "wide_200rows", wide[:50_000], torch.from_numpy(Xw[:200].copy()).to(dev), torch.from_numpy(yw[:200].copy()).to(dev)
     yield "wide_50rows", wide[:50_000], torch.from_numpy(Xw[:50].copy()).to(dev), torch.from_numpy(yw[:50].copy()).to(dev)
