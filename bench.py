@@ -283,9 +283,9 @@ def main():
         mode = evogp_amd.get_sr_division()
         info = table[f"K8_{mode}"]
         assert info["nhandlers"] == nh
-        per = np.zeros(nh); names = [None] * nh
+        per = np.zeros(nh); names = [None] * nh; clk = np.zeros(nh)
         for name, h in info["handlers"].items():
-            per[h["id"]] = h["valu"]; names[h["id"]] = name
+            per[h["id"]] = h["valu"]; names[h["id"]] = name; clk[h["id"]] = h.get("valu_clk", 4 * h["valu"])
         words = hist[:nh] + hist[nh:]
         tiles = (DATAPOINTS + 64 * info["K"] - 1) // (64 * info["K"])
         wave_insts = float((words * per).sum()) * tiles          # VALU instructions issued per launch (one per 64 lanes)
@@ -314,6 +314,13 @@ def main():
             "valu_insts_per_launch": wave_insts, "peak_insts_per_s": peak, "peak_insts_per_s_spec": peak_spec, "cus": cus, "clock_hz": clock_hz,
             "program_words": int(words.sum()), "words_per_tree": float(words.sum()) / pop, "passes_per_tree": tiles,
             "top_handlers": [f"{n}:{w}" for w, n in top],
+            "handlers": {names[i]: int(w) for i, w in enumerate(words) if w},
+            "valu_clocks_model": {"per_simd": float((words * clk).sum()) * tiles / (cus * 4),
+                                  "frac_of_kernel": float((words * clk).sum()) * tiles / (cus * 4) / (kernel_s * clock_hz) if kernel_s > 0 else None,
+                                  "division_share": float(sum(words[i] * clk[i] for i in range(nh) if names[i] and names[i].startswith("div"))) / max(float((words * clk).sum()), 1.0),
+                                  "what": "issue clocks of the VALU by instruction class (2 for a VOP2 add / sub / mul / mov on registers, 8 for a "
+                                          "transcendental, 4 for the rest; gen_tc_asm.py count_path) summed over the program words, per SIMD, and as a "
+                                          "fraction of the interpreter's clocks"},
             "what": "sum over program words of the handler's VALU instruction count (evogp_amd/lib/tc_handlers.json, from the generator) "
                     "x datapoint tiles, / interpreter launch time.  frac: against one instruction per 4 clocks and SIMD (the rate the VOP3 / 3-source / "
                     "SGPR-source class runs at: scripts/ubench/valu_rates.hip measures 4.1 clocks); frac_of_spec: against the chip's issue rate, one per 2 "

@@ -81,6 +81,7 @@ NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
 SPLAT = False    # EVOGP_TC_GEN_SPLAT=1: copy a constant operand into a VGPR before the row loop (experiment: 1.5 % SLOWER at 1 M trees)
 FMA_LOSS = False  # EVOGP_TC_GEN_FMA_LOSS=1: accumulate squared errors with one fused multiply-add (timing experiment)
+PKCONST = True   # + - * with a constant operand, and the push of a constant, as packed instructions over row pairs (EVOGP_TC_GEN_PKCONST=0: off)
 TRUST = True     # divisions by / of a dataset variable whose whole column is in range skip the range test (EVOGP_TC_GEN_TRUST=0: off)
 DIVFIX = False   # the range-tested rows end in v_div_fixup (EVOGP_TC_GEN_DIVFIX=1: an experiment; it changes nothing but NaN payloads)
 DIVRANGE = True  # short division: blocks whose operands all lie in [2^-46, 2^46] take rows without range scaling, residuals as v_pk_fma over row pairs (EVOGP_TC_GEN_DIVRANGE=0: off)
@@ -94,7 +95,7 @@ def count_path(L, start, taken):
     of the same tree).  bench.py multiplies the counts by the handler histogram of a population
     (evogp_hip_debug_tc_histogram) to state how much of the VALU issue rate the interpreter uses."""
     idx = {line[:-1]: i for i, line in enumerate(L) if line.endswith(":")}
-    c = {"valu": 0, "trans": 0, "salu": 0, "lds": 0, "vmem": 0, "smem": 0}
+    c = {"valu": 0, "trans": 0, "salu": 0, "lds": 0, "vmem": 0, "smem": 0, "valu_clk": 0}
     i, steps = idx[start], 0
     while steps < 20000:
         steps += 1
@@ -108,6 +109,15 @@ def count_path(L, start, taken):
             c["valu"] += 1
             if op.split("_")[1] in ("rcp", "sqrt", "exp", "log", "rsq", "sin", "cos"):
                 c["trans"] += 1
+                c["valu_clk"] += 8
+            else:
+                # issue clocks by class (scripts/ubench/valu_rates.hip, kernel wall time per 64-lane instruction): a VOP2 add / sub /
+                # mul / mov on VGPR sources 2, everything else (VOP3, three sources, an SGPR or literal source, packed) 4,
+                # transcendentals 8
+                srcs = " ".join(w[2:]) if len(w) > 2 else ""
+                fast = op in ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32") and not any(
+                    t in srcs for t in ("s", "0x", "|", "%"))
+                c["valu_clk"] += 2 if fast else 4
         elif op.startswith("ds_"):
             c["lds"] += 1
         elif op.startswith("global_") or op.startswith("buffer_"):
@@ -198,8 +208,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         """common head of a handler: address of the next handler and LDS offset of the next instruction's variable"""
         a(f"s_movrels_b32 s{sX}, s{W + 2}")                  # next word: {LDS offset / 1024 of its variable, aux, handler offset}
         a(f"s_pack_lh_b32_b16 s{sPC}, s{sX}, {BASE}")        # handler table is 64 KiB aligned: address = {base.hi16, offset}
-        a(f"s_lshr_b32 {PF}, s{sX}, 24")
-        a(f"s_lshl_b32 {PF}, {PF}, 10")
+        a(f"s_lshr_b32 {PF}, s{sX}, 24")                    # (in 1-KiB units: the shift rides in prefetch's v_lshl_add)
 
     def read_aux(dst):
         """aux field (bits 23:16) of the CURRENT instruction's word; M0 must still be J (i.e. before any m0_stack)"""
@@ -209,7 +218,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     def prefetch(nxt):
         if NOPF:  # timing experiment only: wrong results
             return
-        a(f"v_add_u32 v4, {PF}, v2")
+        a(f"v_lshl_add_u32 v4, {PF}, 10, v2")
         read_bank(nxt, 4)
 
     def warm(sreg):
@@ -383,8 +392,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_mov_b32 s{sJ}, 0")
     a(f"{lab('tile_go')}:")
     a(f"s_lshr_b32 {PF}, s{W}, 24")                # variable operand of the first instruction -> bank 0
-    a(f"s_lshl_b32 {PF}, {PF}, 10")
-    a(f"v_add_u32 v4, {PF}, v2")
+    a(f"v_lshl_add_u32 v4, {PF}, 10, v2")
     read_bank(P[0], 4)
     a(f"s_set_gpr_idx_on s{sJ}, 0")  # J == 0: enables indexing with no operand selected, M0 = 0
     a(f"s_pack_lh_b32_b16 s{sPC}, s{W}, {BASE}")
@@ -441,6 +449,16 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             wait_cur()
             for k in range(K):
                 a(f"{ins} v{S0 + k}, v{cur + k}, v{S0 + k}")
+        elif form in ("SC", "CS") and PKCONST and K >= 2:
+            # an SGPR source makes a VOP2 the slow class (4 clocks); a packed instruction takes the constant for two rows in
+            # the same 4 clocks (op_sel_hi 0: both halves read the SGPR).  a - b is a + (-b) bit for bit
+            a(f"s_movrels_b32 s{sA}, s{W + 1}")
+            prefetch(nxt)
+            m0_stack(MODE["SRC0"] | MODE["DST"], -K)
+            pkins = "v_pk_mul_f32" if op == "mul" else "v_pk_add_f32"
+            neg = "" if op != "sub" else (" neg_lo:[0,1] neg_hi:[0,1]" if form == "SC" else " neg_lo:[1,0] neg_hi:[1,0]")
+            for k in range(0, K, 2):
+                a(f"{pkins} v[{S0 + k}:{S0 + k + 1}], v[{S0 + k}:{S0 + k + 1}], s[{sA}:{sA + 1}] op_sel_hi:[1,0]{neg}")
         elif form == "SC":  # stack top op constant
             a(f"s_movrels_b32 s{sBop}, s{W + 1}")
             prefetch(nxt)
@@ -464,6 +482,16 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             wait_cur()
             for k in range(K):
                 a(f"{ins} v{S0 + k}, v{cur + k}, v{T + k}")
+            a(f"s_add_u32 s{sH}, s{sH}, {K}")
+        elif form in ("VC", "CV") and PKCONST and K >= 2:
+            a(f"s_movrels_b32 s{sA}, s{W + 1}")
+            prefetch(nxt)
+            m0_stack(MODE["DST"], 0)
+            pkins = "v_pk_mul_f32" if op == "mul" else "v_pk_add_f32"
+            neg = "" if op != "sub" else (" neg_lo:[0,1] neg_hi:[0,1]" if form == "VC" else " neg_lo:[1,0] neg_hi:[1,0]")
+            wait_cur()
+            for k in range(0, K, 2):
+                a(f"{pkins} v[{S0 + k}:{S0 + k + 1}], v[{cur + k}:{cur + k + 1}], s[{sA}:{sA + 1}] op_sel_hi:[1,0]{neg}")
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         elif form == "VC":  # variable op constant
             a(f"s_movrels_b32 s{sBop}, s{W + 1}")
@@ -747,9 +775,13 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_movrels_b32 s{sA}, s{W + 1}")
         prefetch(nxt)
         m0_stack(MODE["DST"], 0)
-        c = splat(sA)
-        for k in range(K):
-            a(f"v_mov_b32 v{S0 + k}, {c}")
+        if PKCONST and K >= 2:
+            for k in range(0, K, 2):
+                a(f"v_pk_mov_b32 v[{S0 + k}:{S0 + k + 1}], s[{sA}:{sA + 1}], s[{sA}:{sA + 1}] op_sel:[0,0]")
+        else:
+            c = splat(sA)
+            for k in range(K):
+                a(f"v_mov_b32 v{S0 + k}, {c}")
         a(f"s_add_u32 s{sH}, s{sH}, {K}")
         epilogue()
         # push variable (a tree that is a single variable)
@@ -829,7 +861,6 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a("s_waitcnt lgkmcnt(0)")
         a(f"s_pack_lh_b32_b16 s{sPC}, s{W}, {BASE}")
         a(f"s_lshr_b32 {PF}, s{W}, 24")
-        a(f"s_lshl_b32 {PF}, {PF}, 10")
         prefetch(nxt)
         a(f"s_mov_b32 s{sJ}, 0")
         a(f"s_mov_b32 m0, s{sJ}")
@@ -1910,6 +1941,7 @@ if __name__ == "__main__":
     DIVRANGE = os.environ.get("EVOGP_TC_GEN_DIVRANGE", "1") != "0"
     DIVFIX = os.environ.get("EVOGP_TC_GEN_DIVFIX", "0") == "1"
     TRUST = os.environ.get("EVOGP_TC_GEN_TRUST", "1") != "0"
+    PKCONST = os.environ.get("EVOGP_TC_GEN_PKCONST", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}
