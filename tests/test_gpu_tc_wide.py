@@ -368,3 +368,70 @@ def test_datasets_larger_than_lds_run_in_pieces(g, oracle, rng, D, var_len, out_
             assert (np.abs(got[ok] - want[ok]) <= 1e-4 * np.abs(want[ok]) + 1e-6).mean() > 0.9
         else:
             assert_close_classes(got, want, RTOL, what=f"D={D} mse={mse}")
+
+
+# ---- the division's block paths (gen_tc_asm.py DIVRANGE / TRUST): every operand form x every kind of block ---------------------
+DIV_SPECIALS = np.array([0.0, -0.0, 1.0, -3.0, 0.1, 1e-20, -1e-15, 2.0**-46, 2.0**-47, 2.0**46, -2.0**47, 1e30, -3e38, np.inf, np.nan, 1e-42],
+                        np.float32)
+
+
+def _division_forest(form, n):
+    """n * n trees `a / b`: a (index i) and b (index j) are a Stack operand (x + -0: every value but the sign of a zero passes
+    through, and the compiler cannot fold it), a Variable or a Constant (DIV_SPECIALS[index]), as the two letters of `form` say"""
+    L = 8
+    rows = []
+    for i in range(n):
+        for j in range(n):
+            def operand(kind, idx):
+                if kind == "S":
+                    return [(3, float(ADD), 3), (0, float(idx), 1), (1, -0.0, 1)]
+                if kind == "V":
+                    return [(0, float(idx), 1)]
+                return [(1, float(DIV_SPECIALS[idx]), 1)]
+            a, b = operand(form[0], i), operand(form[1], j)
+            rows.append([(3, float(DIV), 1 + len(a) + len(b))] + a + b)
+    v = np.zeros((len(rows), L), np.float32); t = np.zeros((len(rows), L), np.int16); s = np.zeros((len(rows), L), np.int16)
+    for r, nodes in enumerate(rows):
+        for k, (ty, val, sz) in enumerate(nodes):
+            t[r, k], v[r, k], s[r, k] = ty, val, sz
+    return v, t, s
+
+
+@pytest.mark.parametrize("D", [64, 200, 512, 1100, 1536])
+def test_division_blocks_of_every_kind(g, oracle, D):
+    """`a / b` in the eight operand forms of the interpreter's division handlers (S / S, S / c and c / S in place; s / v, v / s,
+    v / w, c / v, v / c through the banks) over datasets that make every kind of 64 x K-row block: all operands in
+    [2^-46, 2^46] (the rows without range scaling, with and without TRUSTED variables), a numerator or denominator that is
+    zero everywhere, one special value among ordinary ones, specials everywhere.  D covers the three interpreter builds
+    (K = 1, 4, 8), one / two (ragged) / three tiles.  Mean absolute error against labels 0 = mean |a / b| per tree, compared
+    with the oracle: identical NaN / inf classes, 1e-6 on the values (all terms are >= 0: only the rounding of the sum differs)."""
+    rng = np.random.default_rng(D)
+    n = len(DIV_SPECIALS)
+    y = np.zeros((D, 1), np.float32)
+    ordinary = rng.uniform(0.5, 4.0, (D, n)).astype(np.float32) * rng.choice(np.float32([-1.0, 1.0]), (D, n))
+    uniform = np.tile(DIV_SPECIALS[None, :], (D, 1))
+    shuffled = DIV_SPECIALS[(np.arange(n)[None, :] + 5 * np.arange(D)[:, None]) % n]
+    one_row = ordinary.copy(); one_row[min(77, D - 1)] = DIV_SPECIALS
+    zero_cols = ordinary.copy(); zero_cols[:, 0] = 0.0; zero_cols[:, 1] = -0.0; zero_cols[::2, 2] = 0.0
+    for form in ("SS", "SC", "CS", "SV", "VS", "VV", "CV", "VC"):
+        f = _division_forest(form, n)
+        for name, X in (("ordinary", ordinary), ("uniform", uniform), ("shuffled", shuffled), ("one special row", one_row), ("zero columns", zero_cols)):
+            X = np.ascontiguousarray(X, np.float32)
+            want = oracle.sr_fitness(*f, X, y, use_mse=False)
+            got = g.sr_fitness(*f, X, y, use_mse=False)
+            assert handler_histogram(g, n * n)["skip"] == 0
+            assert_close_classes(got, want, 1e-6, 0.0, f"{form}, {name} rows, D={D}")
+
+
+def test_nan_fitness_words_are_the_canonical_nan(g, oracle):
+    """A NaN sum leaves the interpreter as 0x7FC00000 whatever payloads and signs its operands carried (the payload an instruction
+    hands on depends on its operand order; a fitness word must never look like one of the register kernels' sentinels)."""
+    f = oracle.generate(5000, 64, 10, 1, 0.0, 0.5, [42, 0], depth2leaf(6), roulette_uniform(ARITH), [-1, 0, 1])
+    X, y = c2_dataset()
+    X = X.copy(); X[3, 4] = np.float32(np.nan); X[700, 2] = np.frombuffer(np.uint32(0xFFC12345).tobytes(), np.float32)[0]
+    for m in (True, False):
+        got = g.sr_fitness(*f, X, y, m)
+        assert handler_histogram(g, 5000)["skip"] == 0   # (every tree ran in the interpreter)
+        nan = np.isnan(got)
+        assert nan.sum() > 1000
+        assert (got.view(np.uint32)[nan] == 0x7FC00000).all()
