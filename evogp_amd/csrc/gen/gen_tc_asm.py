@@ -73,7 +73,7 @@ GBIN = ("ldiv", "max", "min", "lt", "gt", "le", "ge", "pow", "lpow")  # bodies b
 GUN = ("zero", "sinh", "cosh", "tanh", "one", "rcp")                  # bodies behind the generic unary stubs (sr_tc.hip GU_*)
 HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top of the operand stack (the compiler keeps it free)
 SLOT = 256  # bytes per handler slot
-DIVIP_REGS = 6  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
+DIVIP_REGS = 12  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
 DIVIP = ("SS", "SC", "CS")  # division forms with an in-place handler (operands read where they are, temporaries above the stack)
 NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls
 
@@ -81,6 +81,7 @@ NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
 SPLAT = False    # EVOGP_TC_GEN_SPLAT=1: copy a constant operand into a VGPR before the row loop (experiment: 1.5 % SLOWER at 1 M trees)
 FMA_LOSS = False  # EVOGP_TC_GEN_FMA_LOSS=1: accumulate squared errors with one fused multiply-add (timing experiment)
+DIVABREAST = True  # the range-tested division rows run two row pairs abreast (twelve temporaries; EVOGP_TC_GEN_DIVABREAST=0: one pair at a time)
 PKCONST = True   # + - * with a constant operand, and the push of a constant, as packed instructions over row pairs (EVOGP_TC_GEN_PKCONST=0: off)
 TRUST = True     # divisions by / of a dataset variable whose whole column is in range skip the range test (EVOGP_TC_GEN_TRUST=0: off)
 DIVFIX = False   # the range-tested rows end in v_div_fixup (EVOGP_TC_GEN_DIVFIX=1: an experiment; it changes nothing but NaN payloads)
@@ -135,6 +136,7 @@ def count_path(L, start, taken):
 
 def gen(K, DEPTH, stats=False, fast=0, info=None):
     assert K % 4 == 0 or K == 1
+    assert 24 + 4 * K + K * DEPTH <= 256
     G = max(K // 4, 1)   # 1-KiB groups of a variable's tile: 64 lanes x 16 bytes (K = 1 uses the first row of every lane's four)
     RPL = min(K, 4)      # rows per lane and group
     P = [24, 24 + K]
@@ -706,38 +708,51 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
 
     def fast_pair_rows(xs, ys, temps, out, out_m0=None):
         """rows of a range-tested block.  xs / ys: K VGPR numbers, or ONE SGPR string for a constant operand; the quotient of
-        row k goes to out[k].  out_m0: SGPR holding the M0 that indexes the destination (gather bodies: only the result is
-        indexed, so M0 is switched around the one instruction that writes it); None: M0 stays as it is (in-place handlers:
-        every operand is indexed)"""
-        r0, r1, q0, q1, e0, e1 = temps
-        assert r0 % 2 == 0 and q0 % 2 == 0 and e0 % 2 == 0 and (r1, q1, e1) == (r0 + 1, q0 + 1, e0 + 1)
+        row k goes to out[k].  temps: six registers (three aligned pairs) -- or twelve: two row pairs then run abreast, each
+        instruction four or more away from the one it depends on (a wave issues in order; the reciprocal's latency otherwise
+        waits for the other waves of the SIMD to fill).  out_m0: SGPR holding the M0 that indexes the destination (gather
+        bodies: only the result is indexed, so M0 is switched around the instructions that write it); None: M0 stays as it is
+        (in-place handlers: every operand is indexed)"""
+        sets = [temps[i:i + 6] for i in range(0, len(temps), 6)]
+        for r0, r1, q0, q1, e0, e1 in sets:
+            assert r0 % 2 == 0 and q0 % 2 == 0 and e0 % 2 == 0 and (r1, q1, e1) == (r0 + 1, q0 + 1, e0 + 1)
         cx, cy = isinstance(xs, str), isinstance(ys, str)
         if cy:  # one reciprocal serves the block
-            a(f"v_rcp_f32 v{r0}, {ys}")
+            a(f"v_rcp_f32 v{sets[0][0]}, {ys}")
             a("s_nop 0")
-            a(f"v_mov_b32 v{r1}, v{r0}")
-        for k in range(0, K, 2):
-            x = [xs, xs] if cx else [f"v{xs[k]}", f"v{xs[k + 1]}"]
-            y = [ys, ys] if cy else [f"v{ys[k]}", f"v{ys[k + 1]}"]
+            for st_ in sets:
+                for r in st_[:2]:
+                    if r != sets[0][0]:
+                        a(f"v_mov_b32 v{r}, v{sets[0][0]}")
+        pairs = list(range(0, K, 2))
+        for g0 in range(0, len(pairs), len(sets)):
+            grp = list(zip(pairs[g0:g0 + len(sets)], sets))
+            X = {k: ([xs, xs] if cx else [f"v{xs[k]}", f"v{xs[k + 1]}"]) for k, _ in grp}
+            Y = {k: ([ys, ys] if cy else [f"v{ys[k]}", f"v{ys[k + 1]}"]) for k, _ in grp}
             if not cy:
-                a(f"v_rcp_f32 v{r0}, {y[0]}")
-                a(f"v_rcp_f32 v{r1}, {y[1]}")   # (also the wait state between a transcendental and the reader of its result)
-            a(f"v_mul_f32 v{q0}, {x[0]}, v{r0}")
-            a(f"v_mul_f32 v{q1}, {x[1]}, v{r1}")
-            xp, xh = pk(xs, k)
-            yp, yh = pk(ys, k)
-            assert out[k] % 2 == 0 and out[k + 1] == out[k] + 1
-            a(f"v_pk_fma_f32 v[{e0}:{e1}], {yp}, v[{q0}:{q1}], {xp} op_sel_hi:[{yh},1,{xh}] neg_lo:[1,0,0] neg_hi:[1,0,0]")
+                for k, (r0, r1, *_) in grp:
+                    a(f"v_rcp_f32 v{r0}, {Y[k][0]}")
+                    a(f"v_rcp_f32 v{r1}, {Y[k][1]}")   # (also the wait state between a transcendental and the reader of its result)
+            for k, (r0, r1, q0, q1, e0, e1) in grp:
+                a(f"v_mul_f32 v{q0}, {X[k][0]}, v{r0}")
+                a(f"v_mul_f32 v{q1}, {X[k][1]}, v{r1}")
+            for k, (r0, r1, q0, q1, e0, e1) in grp:
+                xp, xh = pk(xs, k)
+                yp, yh = pk(ys, k)
+                assert out[k] % 2 == 0 and out[k + 1] == out[k] + 1
+                a(f"v_pk_fma_f32 v[{e0}:{e1}], {yp}, v[{q0}:{q1}], {xp} op_sel_hi:[{yh},1,{xh}] neg_lo:[1,0,0] neg_hi:[1,0,0]")
             if DIVFIX:
-                a(f"v_pk_fma_f32 v[{e0}:{e1}], v[{e0}:{e1}], v[{r0}:{r1}], v[{q0}:{q1}]")
+                for k, (r0, r1, q0, q1, e0, e1) in grp:
+                    a(f"v_pk_fma_f32 v[{e0}:{e1}], v[{e0}:{e1}], v[{r0}:{r1}], v[{q0}:{q1}]")
             if out_m0 is not None:
                 a(f"s_mov_b32 m0, s{out_m0}")
-            if DIVFIX:
-                a(f"v_div_fixup_f32 v{out[k]}, v{e0}, {y[0]}, {x[0]}")
-                a(f"v_div_fixup_f32 v{out[k + 1]}, v{e1}, {y[1]}, {x[1]}")
-            else:
-                a(f"v_pk_fma_f32 v[{out[k]}:{out[k] + 1}], v[{e0}:{e1}], v[{r0}:{r1}], v[{q0}:{q1}]")
-            if out_m0 is not None and k + 2 < K:
+            for k, (r0, r1, q0, q1, e0, e1) in grp:
+                if DIVFIX:
+                    a(f"v_div_fixup_f32 v{out[k]}, v{e0}, {Y[k][0]}, {X[k][0]}")
+                    a(f"v_div_fixup_f32 v{out[k + 1]}, v{e1}, {Y[k][1]}, {X[k][1]}")
+                else:
+                    a(f"v_pk_fma_f32 v[{out[k]}:{out[k] + 1}], v[{e0}:{e1}], v[{r0}:{r1}], v[{q0}:{q1}]")
+            if out_m0 is not None and g0 + len(sets) < len(pairs):
                 a("s_mov_b32 m0, 0")
 
     def zero_blocks(st, xzero, yzero):
@@ -1028,7 +1043,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                     a(f"s_cbranch_scc1 {gen_}")
 
                 st = range_test([] if cx else xs, [] if cy else ys, tmp, slow, between=const_range if form != "SS" else None)
-                fast_pair_rows(cx or xs, cy or ys, tmp, out)
+                fast_pair_rows(cx or xs, cy or ys, tmp if DIVABREAST and K >= 8 else tmp[:6], out)
                 if form == "SS":
                     a(f"s_sub_u32 s{sH}, s{sH}, {K}")
                 epilogue()
@@ -1079,6 +1094,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             xs_ = [x + k for k in range(K)]
             out = [S0 + k for k in range(K)]
             TT = [18, 19, 20, 21, 22, 23]
+            QT = [Q + i for i in range(6)]   # the quotient bank is free where the rows write their results themselves
             if use_range:
                 slow, slow_t, xz, yz, rows, gen_, nz = (lab(f"div{n}_{kind}{fl}") for n in ("slow", "slowt", "xz", "yz", "rows", "gen", "nz"))
                 if TRUST:
@@ -1090,7 +1106,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 a(f"{lab(f'divbody_{kind}{fl}')}:")
                 st = range_test(xs_, ys_, TT, slow)
                 a(f"{rows}:")
-                fast_pair_rows(xs_, ys_, TT, out, out_m0=sDST)
+                fast_pair_rows(xs_, ys_, TT + (QT if DIVABREAST and K >= 8 else []), out, out_m0=sDST)
                 epilogue()
                 for kd, l in (("x", xz), ("y", yz)):
                     a(f"{l}:")
@@ -1135,6 +1151,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     # variables from their banks), the quotient goes straight to the new stack entry.
     if use_range and TRUST:
         TT = [18, 19, 20, 21, 22, 23]
+        QT = [Q + i for i in range(6)]
         out = [S0 + k for k in range(K)]
 
         def push_dst():
@@ -1155,7 +1172,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             wait_cur()
             a(f"{rows}:")
             push_dst()
-            fast_pair_rows(f"s{sA}", cur, TT, out, out_m0=sDST)
+            fast_pair_rows(f"s{sA}", cur, TT + (QT if DIVABREAST and K >= 8 else []), out, out_m0=sDST)
             epilogue()
             a(f"{test}:")  # a variable with a value out of range somewhere: this block's values decide
             wait_cur()
@@ -1179,7 +1196,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             trust_test(T1, 6, old_)               # the second variable: its operand word is its LDS offset / 16
             wait_cur()
             push_dst()
-            fast_pair_rows(cur, [T + k for k in range(K)], TT, out, out_m0=sDST)
+            fast_pair_rows(cur, [T + k for k in range(K)], TT + (QT if DIVABREAST and K >= 8 else []), out, out_m0=sDST)
             epilogue()
 
     # ---- library sequences run row by row (pow, sinh, cosh: 120-190 instructions and 14-24 registers each; K unrolled
@@ -1782,18 +1799,25 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"{lab(f'end_full{fl}')}:")
         a("s_bitcmp0_b32 s17, 0")
         a(f"s_cbranch_scc1 {lab(f'end_abs{fl}')}")
-        for k in range(K):
-            a(f"v_sub_f32 v9, v{Y + k}, v{S0 + k}")
-            if FMA_LOSS:
+        # (differences and squares in the result's own registers, row after row independent: only the K additions into the
+        # accumulator form a chain -- with one temporary the 3 K instructions were one)
+        if FMA_LOSS:
+            for k in range(K):
+                a(f"v_sub_f32 v9, v{Y + k}, v{S0 + k}")
                 a("v_fmac_f32 v6, v9, v9")
-            else:
-                a("v_mul_f32 v9, v9, v9")
-                a("v_add_f32 v6, v6, v9")
+        else:
+            for k in range(K):
+                a(f"v_sub_f32 v{S0 + k}, v{Y + k}, v{S0 + k}")
+            for k in range(K):
+                a(f"v_mul_f32 v{S0 + k}, v{S0 + k}, v{S0 + k}")
+            for k in range(K):
+                a(f"v_add_f32 v6, v6, v{S0 + k}")
         a(f"s_branch {lab('end_acc')}")
         a(f"{lab(f'end_abs{fl}')}:")
         for k in range(K):
-            a(f"v_sub_f32 v9, v{Y + k}, v{S0 + k}")
-            a("v_add_f32_e64 v6, v6, |v9|")
+            a(f"v_sub_f32 v{S0 + k}, v{Y + k}, v{S0 + k}")
+        for k in range(K):
+            a(f"v_add_f32_e64 v6, v6, |v{S0 + k}|")
         if fl == 0:
             a(f"s_branch {lab('end_acc')}")
     a(f"{lab('end_acc')}:")
@@ -1942,9 +1966,13 @@ if __name__ == "__main__":
     DIVFIX = os.environ.get("EVOGP_TC_GEN_DIVFIX", "0") == "1"
     TRUST = os.environ.get("EVOGP_TC_GEN_TRUST", "1") != "0"
     PKCONST = os.environ.get("EVOGP_TC_GEN_PKCONST", "1") != "0"
+    DIVABREAST = os.environ.get("EVOGP_TC_GEN_DIVABREAST", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}
+    # (K = 16 -- tiles of 1024 rows, 248 VGPRs, two waves per SIMD, half the dispatches and scalar instructions per row --
+    # generates and runs, fitness words identical, but is 7 % SLOWER at 1 M trees, with the division's row pairs abreast or not:
+    # profiles/r03M_div_range_ab.log; DESIGN.md section 3.1d.  Not built.)
     for K, depth in ((8, 9), (4, 15), (1, 44)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:
             for fast, tag in ((0, "ieee"), (1, "fast"), (2, "short")):  # division: IEEE / no range scaling / one correction
