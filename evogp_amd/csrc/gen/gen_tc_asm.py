@@ -656,7 +656,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     # (headline forest: always) a numerator or a denominator that is +-0 in every row and lane -- the constant 0 and what
     # multiplications make of it: such a block is K v_div_fixup (0 / y) or K moves of NaN (x / 0, forward.cu:183-187).
     # Any other block takes the rows with v_div_scale / v_div_fmas.
-    use_range = DIVRANGE and fast == 2 and K >= 2
+    use_range = DIVRANGE and fast in (1, 2) and K >= 2   # (the fast mode's own rows only run in blocks that fail the test)
 
     def minmax(vals, lo, hi):
         vals = [opnd(o) for o in vals]

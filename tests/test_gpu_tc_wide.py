@@ -435,3 +435,22 @@ def test_nan_fitness_words_are_the_canonical_nan(g, oracle):
         nan = np.isnan(got)
         assert nan.sum() > 1000
         assert (got.view(np.uint32)[nan] == 0x7FC00000).all()
+
+
+def test_a_dataset_beyond_64_kib_of_lds_still_runs_in_the_interpreter(g, oracle, rng):
+    """Ten outputs over 1024 rows of ten variables: 80 KiB of LDS (the kernel needs its dynamic-LDS ceiling raised for it).  A refused
+    ceiling sends the call to the register kernels -- same results, a sixth of the speed -- so the result alone proves nothing:
+    the call's stage timer must have seen the interpreter."""
+    pop, L, var_len, out_len, D = 3000, 64, 10, 10, 1024
+    f = oracle.generate(pop, L, var_len, out_len, 0.5, 0.5, [21, 4], depth2leaf(5), roulette_uniform(ARITH), CS)
+    X = rng.uniform(-2, 2, (D, var_len)).astype(np.float32)
+    y = rng.uniform(-2, 2, (D, out_len)).astype(np.float32)
+    assert g.L.evogp_hip_debug_profile(1) == 0
+    try:
+        got = g.sr_fitness(*f, X, y, True)
+        st = (ctypes.c_float * 3)(); n = ctypes.c_int(0)
+        assert g.L.evogp_hip_debug_profile_read(st, ctypes.byref(n)) == 0
+    finally:
+        g.L.evogp_hip_debug_profile(0)
+    assert n.value == 1 and st[1] > 0.0, f"the interpreter did not run (stage times {list(st)})"
+    assert_close_classes(got, oracle.sr_fitness(*f, X, y, True), RTOL, 0.0, "ten outputs, 80 KiB of LDS")
