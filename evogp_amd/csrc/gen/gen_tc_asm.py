@@ -32,7 +32,11 @@ DESIGN.md section 3.1 has the numbers):
   * divisions of S / S, S / c, c / S have in-place handlers (operands read where they are -- every operand position M0-relative --,
     temporaries in the registers above the stack top), used where the compiler finds that entry free;
   * the division comes in three selectable row sequences (ieee / short / fast, evogp_hip_set_sr_division); the
-    reference's "b == 0 -> NaN" is tested once per K x 64 block (min |b|), not per row;
+    reference's "b == 0 -> NaN" is tested once per K x 64 block (min |b|), not per row; under short / fast a block whose
+    operands all lie in [2^-46, 2^46] skips the range scaling (rcp, mul, two packed fmas per row pair, the quotient written in
+    place), a numerator or denominator that is +-0 in the whole block is one instruction per row, and dataset variables whose
+    whole column is in range (flags bits 17-30, set by sr_tc_kernel's prologue) need no test (DIVRANGE / TRUST below);
+  * constants enter + - * and PUSH_C through packed instructions (one SGPR source for two rows per issue slot, PKCONST);
   * the dataset lives in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per four rows.
     Variable operands are PREFETCHED one instruction ahead: every handler starts by issuing the LDS reads for the NEXT
     instruction's variable into the other of two operand banks.  Handlers therefore come in two flavours (current bank
@@ -44,7 +48,7 @@ DESIGN.md section 3.1 has the numbers):
 
 The block is ONE `asm volatile` statement that never returns (it ends the wave).  Register map (fixed):
 
-  SGPR  s[8:9] records  s[10:11] fitness  s12 pop, then end of this XCD's dynamic region  s13 D  s14 LDS distance X->y  s15 tiles  s16 batch  s17 flags
+  SGPR  s[8:9] records  s[10:11] fitness  s12 pop, then end of this XCD's dynamic region  s13 D  s14 LDS distance X->y  s15 tiles  s16 batch  s17 flags (bits 5-7, 17-30: trusted variables)
         s18 static phase  s19 record stride  s[20:21] jump target  s22 J = dword offset of the current instruction
         s23 H = K * stack height  s24 scatter M0 of the division / scratch  s25 tile  s26 b (tree in batch)
         s27 trees in batch  s28 t0  s29 next dynamic t0 / program block  s[30:31] mask of evaluated trees
@@ -52,7 +56,7 @@ The block is ONE `asm volatile` statement that never returns (it ends the wave).
         in/out operands of the statement: static cursor, static end, static stride, first dynamic tree, prefetch offset
   VGPR  v0 lane  v1 X base of the lane  v2 X base of the tile  v3 y address of the tile  v4,v5 addresses
         v6 error accumulator  v7 batch results (lane b = tree b)  v8 NaN  v9 scratch  v[10:11] counter address
-        v12 grabbed t0  v13 warm-up offset  v[14:17] warm-up sink  v18..v22 division temporaries
+        v12 grabbed t0  v13 warm-up offset  v[14:17] warm-up sink  v18..v23 division temporaries
         P0 P1 (variable-operand banks)  T (second operand / labels)  Q (quotients)  then the operand stack
         (slot e of row k = S0 + K*e + k)
 

@@ -328,10 +328,13 @@ const char *evogp_hip_error_string(int code);
  *                   operations per quotient instead of 13.  Faithfully rounded; it is the correctly rounded quotient
  *                   except for about 1 operand pair in 4e9 (1 of 2^32 random mantissa pairs, scripts/ubench/
  *                   div_faithful.hip), where it is the neighbouring float.  Fitness vectors of 200 k trees x 1024 rows
- *                   were bit-identical to the IEEE mode (scripts/div_modes.py).
- *   EVOGP_DIV_IEEE  every quotient is the correctly rounded IEEE-754 quotient, as the CPU oracle computes it (+20 % time).
- *   EVOGP_DIV_FAST  reciprocal, quotient, one residual correction, no range scaling: |b| > 2^126 gives 0 and
- *                   |a/b| >= 2^128 gives NaN instead of inf (-4 % time against SHORT).
+ *                   were bit-identical to the IEEE mode (scripts/div_modes.py).  A block of 64 lanes x K rows whose operands
+ *                   all lie in [2^-46, 2^46] -- where the range scaling does nothing -- runs the same four operations
+ *                   without it (same quotients, bit for bit).
+ *   EVOGP_DIV_IEEE  every quotient is the correctly rounded IEEE-754 quotient, as the CPU oracle computes it (+45 % time).
+ *   EVOGP_DIV_FAST  as SHORT, but a block with an operand outside [2^-46, 2^46] takes rows without range scaling:
+ *                   |b| > 2^126 gives 0 and |a/b| >= 2^128 gives NaN instead of inf (-2 % time against SHORT).
+ * A NaN fitness is always the canonical quiet NaN 0x7FC00000 on this path.
  * Affects only tree_SR_fitness with one output on the + - * / function set (the threaded-code path); every other
  * kernel (evaluate, batch_evaluate, the register interpreters) divides with the IEEE sequence.
  * Environment: EVOGP_SR_DIV=ieee|short|fast selects the mode of a process that never calls the setter. */
