@@ -435,7 +435,9 @@ def main():
         evogp_amd.set_sr_division(default_mode)
         extras["division"] = {"mode": default_mode, "call_ms_by_mode": div_ms,
                               "what": "short = IEEE range/special handling with one residual correction (default; bit-identical fitness "
-                                      "to ieee on this workload), ieee = correctly rounded always, fast = no range scaling"}
+                                      "to ieee on this workload); blocks of rows whose operands all lie in [2^-46, 2^46] skip the range "
+                                      "scaling, which does nothing there (same bits).  ieee = correctly rounded always.  fast = as short, "
+                                      "but blocks outside that range take rows without range scaling"}
 
         from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
         from evogp_amd.tree import Forest, GenerateDescriptor

@@ -91,7 +91,9 @@ TRUST = True     # divisions by / of a dataset variable whose whole column is in
 DIVFIX = False   # the range-tested rows end in v_div_fixup (EVOGP_TC_GEN_DIVFIX=1: an experiment; it changes nothing but NaN payloads)
 DIVRANGE = True  # short division: blocks whose operands all lie in [2^-46, 2^46] take rows without range scaling, residuals as v_pk_fma over row pairs (EVOGP_TC_GEN_DIVRANGE=0: off)
 DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such operands alone (|exponent difference| < 96, no denormal in sight)
-KWARM = True  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=0 at generation time disables it)
+L2WARM = True    # vector loads that pull the next batch's records into L2 (EVOGP_TC_GEN_L2WARM=0: off)
+KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_TC_GEN_KWARM_LINES)
+KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
 
 
 def count_path(L, start, taken):
@@ -229,6 +231,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
 
     def warm(sreg):
         """pull the eight records starting at tree `sreg` into L2 (results discarded)"""
+        if not L2WARM:
+            return
         a(f"s_mul_hi_u32 s{T2}, {sreg}, s19")
         a(f"s_mul_i32 s{T1}, {sreg}, s19")
         a(f"s_add_u32 s{T1}, s{T1}, s8")
@@ -372,7 +376,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         # (asserted on the host), the next tree of the batch is the next record; the slack behind the last record
         # covers the last tree.  Handlers count LDS completions with s_waitcnt lgkmcnt(n): scalar loads in flight can only
         # make such a wait longer, never shorter, because LDS operations complete in order.
-        for i in range(4):
+        for i in range(KWARM_LINES):
             a(f"s_load_dwordx2 %[karg], s[{sREC}:{sREC + 1}], {hex(256 + 64 * i)}")
         # ... and, on the last tree of a STATIC batch, the first record of the wave's next batch (CUR already points at it)
         a(f"s_add_u32 s{T1}, s{sB}, 1")
@@ -386,7 +390,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_mul_i32 s{T1}, {CUR}, s19")
         a(f"s_add_u32 s{T1}, s{T1}, s8")
         a(f"s_addc_u32 s{T2}, s{T2}, s9")
-        for i in range(4):
+        for i in range(KWARM_LINES):
             a(f"s_load_dwordx2 %[karg], s[{T1}:{T2}], {hex(64 * i)}")
         a(f"{lab('kwarm_done')}:")
     # ------------------------------------------------------------------ tile loop (one pass of the program)
@@ -1775,6 +1779,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         if stats:
             pass
         a(f"s_add_u32 s{T1}, s{sTILE}, 1")
+        a(f"s_and_b32 s{T2}, s17, 0x12")   # a launch without a ragged tile (neither bit 1 nor bit 4) needs none of the following
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"s_cbranch_scc0 {lab(f'end_full{fl}')}")
         a(f"s_cmp_lt_u32 s{T1}, s15")
         a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile ...
         a("s_bitcmp1_b32 s17, 4")
@@ -1962,7 +1969,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
 
 if __name__ == "__main__":
     import os
-    KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "1") != "0"
+    KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "0") == "1"
+    L2WARM = os.environ.get("EVOGP_TC_GEN_L2WARM", "1") != "0"
+    KWARM_LINES = int(os.environ.get("EVOGP_TC_GEN_KWARM_LINES", "4"))
     NOPF = os.environ.get("EVOGP_TC_GEN_NOPF", "0") == "1"
     FMA_LOSS = os.environ.get("EVOGP_TC_GEN_FMA_LOSS", "0") == "1"
     SPLAT = os.environ.get("EVOGP_TC_GEN_SPLAT", "0") == "1"
