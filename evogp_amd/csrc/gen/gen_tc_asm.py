@@ -91,6 +91,7 @@ TRUST = True     # divisions by / of a dataset variable whose whole column is in
 DIVFIX = False   # the range-tested rows end in v_div_fixup (EVOGP_TC_GEN_DIVFIX=1: an experiment; it changes nothing but NaN payloads)
 DIVRANGE = True  # short division: blocks whose operands all lie in [2^-46, 2^46] take rows without range scaling, residuals as v_pk_fma over row pairs (EVOGP_TC_GEN_DIVRANGE=0: off)
 DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such operands alone (|exponent difference| < 96, no denormal in sight)
+EARLYREC = True  # END of a tree's last tile sends for the record of the batch's next tree (EVOGP_TC_GEN_EARLYREC=0: the tree loop does)
 L2WARM = True    # vector loads that pull the next batch's records into L2 (EVOGP_TC_GEN_L2WARM=0: off)
 KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_TC_GEN_KWARM_LINES)
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
@@ -364,6 +365,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     tick_begin()
     for i in range(4):
         a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+    a(f"{lab('tree_loaded')}:")   # (END of the batch's previous tree arrives here with this record already on its way)
     a("v_mov_b32 v6, 0")
     a(f"s_mov_b32 s{sTILE}, 0")
     a("s_waitcnt lgkmcnt(0)")
@@ -1779,8 +1781,25 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         if stats:
             pass
         a(f"s_add_u32 s{T1}, s{sTILE}, 1")
-        a(f"s_and_b32 s{T2}, s17, 0x12")   # a launch without a ragged tile (neither bit 1 nor bit 4) needs none of the following
         a("s_waitcnt lgkmcnt(0)")
+        if EARLYREC and not stats:
+            # the last tile of a tree that has a successor in its batch: the program window is dead from here on, so the next
+            # tree's record starts its way now -- under the rows of END and the reduction -- and not after them (flags bit 10,
+            # set by the host for single-output launches, tells tree_done that it did)
+            a(f"s_cmp_lt_u32 s{T1}, s15")
+            a(f"s_cbranch_scc1 {lab(f'no_early{fl}')}")
+            a(f"s_add_u32 s{T2}, s{sB}, 1")
+            a(f"s_cmp_lt_u32 s{T2}, s{sNB}")
+            a(f"s_cbranch_scc0 {lab(f'no_early{fl}')}")
+            a(f"s_add_u32 s{T2}, s{T2}, s{sT0}")
+            a(f"s_mul_hi_u32 s{sREC + 1}, s{T2}, s19")
+            a(f"s_mul_i32 s{sREC}, s{T2}, s19")
+            a(f"s_add_u32 s{sREC}, s{sREC}, s8")
+            a(f"s_addc_u32 s{sREC + 1}, s{sREC + 1}, s9")
+            for i in range(4):
+                a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+            a(f"{lab(f'no_early{fl}')}:")
+        a(f"s_and_b32 s{T2}, s17, 0x12")   # a launch without a ragged tile (neither bit 1 nor bit 4) needs none of the following
         a(f"s_cbranch_scc0 {lab(f'end_full{fl}')}")
         a(f"s_cmp_lt_u32 s{T1}, s15")
         a(f"s_cselect_b32 s{T2}, 0, s17")  # flag bit 1 (ragged) survives only on the last tile ...
@@ -1866,10 +1885,18 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_mov_b32 m0, s{sB}")
     a(f"s_bitset1_b64 s[{sOK}:{sOK + 1}], s{sB}")
     a(f"v_writelane_b32 v7, s{T1}, m0")
+    if EARLYREC and not stats:
+        a(f"s_add_u32 s{sB}, s{sB}, 1")
+        a(f"s_cmp_lt_u32 s{sB}, s{sNB}")
+        a(f"s_cbranch_scc0 {lab('batch_end')}")
+        a("s_bitcmp1_b32 s17, 10")                 # single-output launch: END has sent for this tree's record
+        a(f"s_cbranch_scc1 {lab('tree_loaded')}")
+        a(f"s_branch {lab('tree')}")
     a(f"{lab('next_tree')}:")
     a(f"s_add_u32 s{sB}, s{sB}, 1")
     a(f"s_cmp_lt_u32 s{sB}, s{sNB}")
     a(f"s_cbranch_scc1 {lab('tree')}")
+    a(f"{lab('batch_end')}:")
     # batch finished: everything outstanding has long landed (warm-up load, the next dynamic grab); take the grab
     # first, then mean = sum / D and one coalesced store for the evaluated trees
     tick_begin()
@@ -1971,6 +1998,7 @@ if __name__ == "__main__":
     import os
     KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "0") == "1"
     L2WARM = os.environ.get("EVOGP_TC_GEN_L2WARM", "1") != "0"
+    EARLYREC = os.environ.get("EVOGP_TC_GEN_EARLYREC", "1") != "0"
     KWARM_LINES = int(os.environ.get("EVOGP_TC_GEN_KWARM_LINES", "4"))
     NOPF = os.environ.get("EVOGP_TC_GEN_NOPF", "0") == "1"
     FMA_LOSS = os.environ.get("EVOGP_TC_GEN_FMA_LOSS", "0") == "1"
