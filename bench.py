@@ -49,6 +49,7 @@ POP_PER_GPU = 100_000          # configs[1]
 DATAPOINTS = 1024
 VAR_LEN = 10
 GP_LEN = 64
+PREWARM = 40       # untimed passes in front of the warm-up steps: the device's clock ramp (see main)
 
 
 def self_launch(args):
@@ -258,6 +259,13 @@ def main():
     pop = hi - lo
     forest, Xd, yd, X, y = sr_inputs(lo, pop, device)
     total_nodes = int(forest.batch_subtree_size[:, 0].to(torch.int64).sum())
+    # The device reaches its steady clocks only after ~25 ms of work (scripts/dbg/first_calls.py, profiles/r03_first_calls.log: calls
+    # 1-4 of a fresh process take 1.28 ms, 5-9 1.23, 10-19 1.18, every later one 1.14): the W warm-up steps the driver asks for
+    # (5) end inside that ramp.  PREWARM untimed passes of the same step precede them, so that W + K measure the state a run of
+    # thousands of generations is in; the count is reported in the JSON line (`device_prewarm_calls`).
+    for _ in range(PREWARM):
+        forest.SR_fitness(Xd, yd, True, "auto")
+    torch.cuda.synchronize()
     elapsed, call_ms = timed_steps(forest, Xd, yd, args.warmup, args.steps)
     all_nodes = sum_over_ranks(total_nodes)
 
@@ -368,6 +376,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not share_gpu else "synthetic; FUNCTIONAL CHECK ONLY: ranks share a GPU over gloo",
+            "device_prewarm_calls": PREWARM,
             "config": {
                 "workload": f"BASELINE north_star / configs[2] shape: SymbolicRegression synthetic 10-var, GLOBAL pop={P} x 1024 datapoints, "
                             "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass over every rank's shard per step",
