@@ -85,6 +85,7 @@ NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
 SPLAT = False    # EVOGP_TC_GEN_SPLAT=1: copy a constant operand into a VGPR before the row loop (experiment: 1.5 % SLOWER at 1 M trees)
 FMA_LOSS = False  # EVOGP_TC_GEN_FMA_LOSS=1: accumulate squared errors with one fused multiply-add (timing experiment)
+PKARITH = True   # register-register + - *, moves and the division's quotient estimates as packed instructions over row pairs (EVOGP_TC_GEN_PKARITH=0: VOP2)
 DIVABREAST = True  # the range-tested division rows run two row pairs abreast (twelve temporaries; EVOGP_TC_GEN_DIVABREAST=0: one pair at a time)
 PKCONST = True   # + - * with a constant operand, and the push of a constant, as packed instructions over row pairs (EVOGP_TC_GEN_PKCONST=0: off)
 TRUST = True     # divisions by / of a dataset variable whose whole column is in range skip the range test (EVOGP_TC_GEN_TRUST=0: off)
@@ -97,7 +98,7 @@ KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_T
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
 
 
-def count_path(L, start, taken):
+def count_path(L, start, taken, idx_on=True):
     """Instruction counts along the usual path of one handler: from its label to the jump to the next handler, following
     unconditional branches; of the conditional ones only those to a label in `taken` (END: a full tile, then the next tile
     of the same tree).  bench.py multiplies the counts by the handler histogram of a population
@@ -120,10 +121,11 @@ def count_path(L, start, taken):
                 c["valu_clk"] += 8
             else:
                 # issue clocks by class (scripts/ubench/valu_rates.hip, kernel wall time per 64-lane instruction): a VOP2 add / sub /
-                # mul / mov on VGPR sources 2, everything else (VOP3, three sources, an SGPR or literal source, packed) 4,
-                # transcendentals 8
+                # mul / mov on VGPR sources 2 -- but only while VGPR indexing is off (k_add_idx_* in the same table: 4 with it on, and it
+                # is on from a program's first instruction to its END) --, everything else (VOP3, three sources, an SGPR or literal
+                # source, packed) 4, transcendentals 8
                 srcs = " ".join(w[2:]) if len(w) > 2 else ""
-                fast = op in ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32") and not any(
+                fast = not idx_on and op in ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32") and not any(
                     t in srcs for t in ("s", "0x", "|", "%"))
                 c["valu_clk"] += 2 if fast else 4
         elif op.startswith("ds_"):
@@ -437,6 +439,29 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"v_mov_b32 v9, s{sreg}")
         return "v9"
 
+    def rows_op(op, dst, x, y):
+        """K rows of dst = x op y on registers.  While VGPR indexing is enabled a VOP2 add / sub / mul issues at the 4-clock rate like
+        everything else (scripts/ubench/valu_rates.hip: k_add_idx_* against k_add_vop2; the interpreter's SQ_ACTIVE_INST_VALU /
+        SQ_INSTS_VALU is 4.3), so a packed instruction -- two rows in those 4 clocks -- halves the cost.  a - b is a + (-b)."""
+        if PKARITH and K >= 2:
+            pkins = "v_pk_mul_f32" if op == "mul" else "v_pk_add_f32"
+            neg = " neg_lo:[0,1] neg_hi:[0,1]" if op == "sub" else ""
+            for k in range(0, K, 2):
+                a(f"{pkins} v[{dst + k}:{dst + k + 1}], v[{x + k}:{x + k + 1}], v[{y + k}:{y + k + 1}]{neg}")
+        else:
+            ins = {"add": "v_add_f32", "sub": "v_sub_f32", "mul": "v_mul_f32"}[op]
+            for k in range(K):
+                a(f"{ins} v{dst + k}, v{x + k}, v{y + k}")
+
+    def rows_mov(dst, src):
+        """K rows of dst = src (registers), packed where it pays (see rows_op)"""
+        if PKARITH and K >= 2:
+            for k in range(0, K, 2):
+                a(f"v_pk_mov_b32 v[{dst + k}:{dst + k + 1}], v[{src + k}:{src + k + 1}], v[{src + k}:{src + k + 1}] op_sel:[0,1]")
+        else:
+            for k in range(K):
+                a(f"v_mov_b32 v{dst + k}, v{src + k}")
+
     def arith(op, form, fl):
         cur, nxt = P[fl], P[1 - fl]
         ins = {"add": "v_add_f32", "sub": "v_sub_f32", "mul": "v_mul_f32"}[op]
@@ -446,21 +471,18 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         if form == "SS":
             prefetch(nxt)
             m0_stack(MODE["SRC0"] | MODE["SRC1"] | MODE["DST"], -2 * K)
-            for k in range(K):
-                a(f"{ins} v{S0 + k}, v{S0 + K + k}, v{S0 + k}")
+            rows_op(op, S0, S0 + K, S0)
             a(f"s_sub_u32 s{sH}, s{sH}, {K}")
         elif form == "SV":  # stack top (left) op variable
             prefetch(nxt)
             m0_stack(MODE["SRC0"] | MODE["DST"], -K)
             wait_cur()
-            for k in range(K):
-                a(f"{ins} v{S0 + k}, v{S0 + k}, v{cur + k}")
+            rows_op(op, S0, S0, cur)
         elif form == "VS":  # variable (left) op stack top
             prefetch(nxt)
             m0_stack(MODE["SRC1"] | MODE["DST"], -K)
             wait_cur()
-            for k in range(K):
-                a(f"{ins} v{S0 + k}, v{cur + k}, v{S0 + k}")
+            rows_op(op, S0, cur, S0)
         elif form in ("SC", "CS") and PKCONST and K >= 2:
             # an SGPR source makes a VOP2 the slow class (4 clocks); a packed instruction takes the constant for two rows in
             # the same 4 clocks (op_sel_hi 0: both halves read the SGPR).  a - b is a + (-b) bit for bit
@@ -492,8 +514,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             prefetch(nxt)
             m0_stack(MODE["DST"], 0)
             wait_cur()
-            for k in range(K):
-                a(f"{ins} v{S0 + k}, v{cur + k}, v{T + k}")
+            rows_op(op, S0, cur, T)
             a(f"s_add_u32 s{sH}, s{sH}, {K}")
         elif form in ("VC", "CV") and PKCONST and K >= 2:
             a(f"s_movrels_b32 s{sA}, s{W + 1}")
@@ -556,17 +577,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"{lab(f'divold_{form}{fl}')}:")  # the in-place handler of this form arrives here when its block holds a zero divisor
         wait_cur()  # the current bank is overwritten or read below: its (possibly unused) prefetch must have landed
         if form == "SS":
-            m0_stack(MODE["SRC0"], -2 * K)
-            for k in range(K):
-                a(f"v_mov_b32 v{x + k}, v{S0 + K + k}")
-                a(f"v_mov_b32 v{y + k}, v{S0 + k}")
+            m0_stack(MODE["SRC0"] | MODE["SRC1"], -2 * K)   # (a packed move reads its two rows through source 0 and source 1)
+            rows_mov(x, S0 + K)
+            rows_mov(y, S0)
             a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - 2 * K)}")
             a(f"s_sub_u32 s{sH}, s{sH}, {K}")
         elif la == "S" or rb == "S":
-            m0_stack(MODE["SRC0"], -K)
+            m0_stack(MODE["SRC0"] | MODE["SRC1"], -K)
             bank = x if la == "S" else y
-            for k in range(K):
-                a(f"v_mov_b32 v{bank + k}, v{S0 + k}")
+            rows_mov(bank, S0)
             a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
         else:
             a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
@@ -743,9 +762,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 for k, (r0, r1, *_) in grp:
                     a(f"v_rcp_f32 v{r0}, {Y[k][0]}")
                     a(f"v_rcp_f32 v{r1}, {Y[k][1]}")   # (also the wait state between a transcendental and the reader of its result)
+            if PKARITH and not cy and len(grp) == 1:
+                a("s_nop 0")  # one pair at a time: the packed product reads the reciprocal issued just before it (one wait state)
             for k, (r0, r1, q0, q1, e0, e1) in grp:
-                a(f"v_mul_f32 v{q0}, {X[k][0]}, v{r0}")
-                a(f"v_mul_f32 v{q1}, {X[k][1]}, v{r1}")
+                if PKARITH:
+                    xp, xh = pk(xs, k)
+                    a(f"v_pk_mul_f32 v[{q0}:{q1}], {xp}, v[{r0}:{r1}] op_sel_hi:[{xh},1]")
+                else:
+                    a(f"v_mul_f32 v{q0}, {X[k][0]}, v{r0}")
+                    a(f"v_mul_f32 v{q1}, {X[k][1]}, v{r1}")
             for k, (r0, r1, q0, q1, e0, e1) in grp:
                 xp, xh = pk(xs, k)
                 yp, yh = pk(ys, k)
@@ -815,8 +840,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         prefetch(nxt)
         m0_stack(MODE["DST"], 0)
         wait_cur()
-        for k in range(K):
-            a(f"v_mov_b32 v{S0 + k}, v{cur + k}")
+        rows_mov(S0, cur)
         a(f"s_add_u32 s{sH}, s{sH}, {K}")
         epilogue()
         begin("end", fl)
@@ -1973,7 +1997,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
 
     if info is not None:
         info["K"], info["depth"], info["nhandlers"], info["slot"] = K, DEPTH, NHF, SLOT
-        info["handlers"] = {n: dict(id=i, **count_path(L, lab("h0_" + n), {lab("end_full0"), lab("tile")})) for n, i in hid.items()}
+        info["handlers"] = {n: dict(id=i, **count_path(L, lab("h0_" + n), {lab("end_full0"), lab("tile")}, idx_on=not n.startswith("end")))
+                            for n, i in hid.items()}
     body = "\n".join(f'    "{line}\\n\\t"' for line in L)
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV)]
     clob_txt = ", ".join(clob)
@@ -2008,6 +2033,7 @@ if __name__ == "__main__":
     TRUST = os.environ.get("EVOGP_TC_GEN_TRUST", "1") != "0"
     PKCONST = os.environ.get("EVOGP_TC_GEN_PKCONST", "1") != "0"
     DIVABREAST = os.environ.get("EVOGP_TC_GEN_DIVABREAST", "1") != "0"
+    PKARITH = os.environ.get("EVOGP_TC_GEN_PKARITH", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}
