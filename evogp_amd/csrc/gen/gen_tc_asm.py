@@ -994,12 +994,10 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         entry()
         read_aux(T2)
         prefetch(nxt)
-        m0_stack(MODE["SRC0"], -K)
-        for k in range(K):
-            a(f"v_mov_b32 v{T + k}, v{S0 + k}")
+        m0_stack(MODE["SRC0"] | MODE["SRC1"], -K)
+        rows_mov(T, S0)
         a(f"s_add_u32 m0, s{T2}, {hex((MODE['SRC0'] | MODE['DST']) << 12)}")
-        for k in range(K):
-            a(f"v_add_f32 v{S0 + k}, v{S0 + k}, v{T + k}")
+        rows_op("add", S0, S0, T)
         a(f"s_sub_u32 s{sH}, s{sH}, {K}")
         epilogue()
         begin("mo_begin", fl)
@@ -1009,8 +1007,12 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_mov_b32 s{T1}, 0")
         a(f"{lab(f'mobegin_loop{fl}')}:")
         a(f"s_add_u32 m0, s{T1}, {hex(MODE['DST'] << 12)}")
-        for k in range(K):
-            a(f"v_mov_b32 v{S0 + k}, 0")
+        if PKARITH and K >= 2:
+            for k in range(0, K, 2):
+                a(f"v_pk_mov_b32 v[{S0 + k}:{S0 + k + 1}], 0, 0")
+        else:
+            for k in range(K):
+                a(f"v_mov_b32 v{S0 + k}, 0")
         a(f"s_add_u32 s{T1}, s{T1}, {K}")
         a(f"s_cmp_lt_u32 s{T1}, s{T2}")
         a(f"s_cbranch_scc1 {lab(f'mobegin_loop{fl}')}")
@@ -1672,14 +1674,13 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"v_cndmask_b32 v{T + k}, 0, v{T + k}, vcc")  # a zero difference adds nothing, squared or not
     a(f"s_branch {lab('endmo_sum')}")
     a(f"{lab('endmo_full')}:")
-    for k in range(K):
-        a(f"v_sub_f32 v{T + k}, v{T + k}, v{Q + k}")
+    rows_op("sub", T, T, Q)       # (M0 is 0 here, but VGPR indexing is on: packed instructions, see rows_op)
     a(f"{lab('endmo_sum')}:")
     a("s_bitcmp0_b32 s17, 0")
     a(f"s_cbranch_scc1 {lab('endmo_abs')}")
+    rows_op("mul", T, T, T)
     for k in range(K):
-        a(f"v_mul_f32 v9, v{T + k}, v{T + k}")
-        a("v_add_f32 v6, v6, v9")
+        a(f"v_add_f32 v6, v6, v{T + k}")
     a(f"s_branch {lab('endmo_next')}")
     a(f"{lab('endmo_abs')}:")
     for k in range(K):

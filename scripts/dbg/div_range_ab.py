@@ -58,6 +58,12 @@ def forests():
     X20[:, 16] *= 1e-30
     X20[7, 2] = 0.0
     yield "vars20_100k", f20, torch.from_numpy(X20).to(dev), yd
+    # multi-output programs (accumulators, END_MO), K = 8 and K = 4
+    for outs in (4, 10):
+        dm = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=outs, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6, const_samples=[-1, 0, 1, 0.5])
+        fm = Forest.random_generate(50_000, dm, keys=torch.tensor([17, outs], dtype=torch.uint32, device=dev))
+        ym = torch.from_numpy(rng.uniform(-3, 3, (1024, outs)).astype(np.float32)).to(dev)
+        yield f"outputs{outs}_50k", fm, Xd, ym
     # K = 4 and K = 1 interpreters (short datasets)
     yield "wide_200rows", wide[:50_000], torch.from_numpy(Xw[:200].copy()).to(dev), torch.from_numpy(yw[:200].copy()).to(dev)
     yield "wide_50rows", wide[:50_000], torch.from_numpy(Xw[:50].copy()).to(dev), torch.from_numpy(yw[:50].copy()).to(dev)
@@ -83,6 +89,16 @@ def run(tag):
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b) / 5)
             print(f"{tag}: headline call {np.median(ts):.4f} ms (min {min(ts):.4f})")
+        else:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(5):
+                forest.SR_fitness(Xd, yd)
+            a.record()
+            for _ in range(20):
+                forest.SR_fitness(Xd, yd)
+            b.record()
+            torch.cuda.synchronize()
+            print(f"{tag}: {name} call {a.elapsed_time(b) / 20:.4f} ms")
         f = res[name].view(np.float32)
         print(f"{tag}: {name}: {len(f)} trees, NaN {np.isnan(f).sum()}, inf {np.isinf(f).sum()}, finite median {np.nanmedian(np.where(np.isfinite(f), f, np.nan)):.6g}")
     os.makedirs(OUT, exist_ok=True)
