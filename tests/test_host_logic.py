@@ -214,3 +214,36 @@ def test_forest_function_mask_follows_the_trees():
     assert f.func_mask == 0b11110 | (1 << 14)
     f.batch_node_value[0, 0] = 3.0
     assert f.func_mask == 0
+
+
+def test_interpreter_generator_switches_still_generate():
+    """gen/gen_tc_asm.py is the source of the interpreter; its A/B switches (scripts/build_variant.sh) must keep
+    producing a program for every build (K = 8, 4, 1; the three division modes), with the per-handler instruction counts bench.py
+    reads.  (Assembling is the build's job: a handler that outgrows its 256-byte slot fails there.)"""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "evogp_amd", "csrc", "gen", "gen_tc_asm.py")
+    spec = importlib.util.spec_from_file_location("gen_tc_asm_under_test", path)
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    defaults = {k: getattr(g, k) for k in ("DIVRANGE", "TRUST", "PKCONST", "PKARITH", "DIVABREAST", "DIVFIX", "EARLYREC", "L2WARM", "KWARM")}
+    try:
+        for flip in [None] + list(defaults):
+            for k, v in defaults.items():
+                setattr(g, k, v)
+            if flip:
+                setattr(g, flip, not defaults[flip])
+            for K, depth in ((8, 9), (4, 15), (1, 44)):
+                for fast in (0, 1, 2):
+                    info = {}
+                    text = g.gen(K, depth, fast=fast, info=info)
+                    assert "s_setpc_b64" in text and info["nhandlers"] == g.NHF
+                    h = info["handlers"]
+                    assert set(("end", "mul_SS", "divip_SS", "div_VV", "push_c")) <= set(h)
+                    assert all(v["valu_clk"] >= v["valu"] for v in h.values())
+                    packed = "v_pk_fma_f32" in text
+                    assert packed == (g.DIVRANGE and fast in (1, 2) and K >= 2), (flip, K, fast)
+    finally:
+        for k, v in defaults.items():
+            setattr(g, k, v)
