@@ -263,6 +263,9 @@ def main():
     # 1-4 of a fresh process take 1.28 ms, 5-9 1.23, 10-19 1.18, every later one 1.14): the W warm-up steps the driver asks for
     # (5) end inside that ramp.  PREWARM untimed passes of the same step precede them, so that W + K measure the state a run of
     # thousands of generations is in; the count is reported in the JSON line (`device_prewarm_calls`).
+    # (for the record, the same W + K steps are timed once BEFORE those passes: `cold_start.ms_per_step` in the JSON line is what a
+    # process that has done nothing else yet measures)
+    cold_elapsed, _ = timed_steps(forest, Xd, yd, args.warmup, args.steps)
     for _ in range(PREWARM):
         forest.SR_fitness(Xd, yd, True, "auto")
     torch.cuda.synchronize()
@@ -377,6 +380,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic" if not share_gpu else "synthetic; FUNCTIONAL CHECK ONLY: ranks share a GPU over gloo",
             "device_prewarm_calls": PREWARM,
+            "cold_start": {"ms_per_step": cold_elapsed / args.steps * 1e3,
+                           "what": "the same W warm-up + K timed steps run once before the untimed passes: a fresh process, device clocks still ramping"},
             "config": {
                 "workload": f"BASELINE north_star / configs[2] shape: SymbolicRegression synthetic 10-var, GLOBAL pop={P} x 1024 datapoints, "
                             "max_tree_len=64, funcs + - * /, one tree_SR_fitness pass over every rank's shard per step",
