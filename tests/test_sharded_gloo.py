@@ -1,4 +1,4 @@
-"""CPU, world_size = 2 on the gloo backend: the sharded generation step (evogp_amd/parallel.py)
+"""CPU, world_size = 2 and 4 on the gloo backend: the sharded generation step (evogp_amd/parallel.py)
 produces the same population as the single-process run — the N > 1 path of bench.py / multi-GPU
 pipelines, exercised without a GPU (tree ops are served by the test-only oracle-backed CPU ops)."""
 import os
@@ -97,7 +97,21 @@ def runs(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("sharded"))
     mp.spawn(_run, args=(1, _free_port(), out), nprocs=1, join=True)  # separate process: leaves this one's state alone
     mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_run, args=(4, _free_port(), out), nprocs=4, join=True)   # more than two blocks per collective
     return out
+
+
+@pytest.mark.parametrize("sel", SELECTIONS)
+@pytest.mark.parametrize("exchange,cap", MODES)
+def test_four_ranks_equal_one_rank(runs, sel, exchange, cap):
+    """world 4 == world 1 (the shape bench.py --gpus 4 / 8 has: several blocks per all-gather, shards of a quarter of the population)"""
+    one = np.load(os.path.join(runs, f"w1_r0_{sel}_rows_exact.npz"))
+    parts = [np.load(os.path.join(runs, f"w4_r{r}_{sel}_{exchange}_{cap}.npz")) for r in range(4)]
+    for k in ("v", "t", "s"):
+        both = np.concatenate([p[k] for p in parts])
+        a = one[k].view(np.uint32) if k == "v" else one[k]
+        b = both.view(np.uint32) if k == "v" else both
+        assert np.array_equal(a, b), f"sharded population differs in {k}"
 
 
 @pytest.mark.parametrize("sel", SELECTIONS)
