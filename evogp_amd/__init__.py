@@ -41,6 +41,13 @@ def program_buffer_bytes() -> int:
     return int(_lib.lib.evogp_hip_program_buffer_bytes())
 
 
+def record_ring_bytes() -> int:
+    """bytes of record rings the one-kernel fitness call holds on the current device (include/evogp_hip.h: a fixed size per stream)"""
+    from . import _lib
+
+    return int(_lib.lib.evogp_hip_record_ring_bytes())
+
+
 def release_workspaces() -> None:
     """Wait for the current device and free the engine-owned program-record buffer; the next fitness call allocates again."""
     from . import _lib

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # EVOGP_HIP_LIB: alternative build of the same engine (A/B benchmarking of compiler flags only)
 LIB_PATH = os.environ.get("EVOGP_HIP_LIB") or os.path.join(_HERE, "lib", "libevogp_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = C.c_void_p
 _u = C.c_uint
@@ -78,6 +78,8 @@ def _load() -> C.CDLL:
     lib.evogp_hip_select_workspace_bytes.restype = C.c_size_t
     lib.evogp_hip_program_buffer_bytes.argtypes = []
     lib.evogp_hip_program_buffer_bytes.restype = C.c_ulonglong
+    lib.evogp_hip_record_ring_bytes.argtypes = []
+    lib.evogp_hip_record_ring_bytes.restype = C.c_ulonglong
     lib.evogp_hip_error_string.argtypes = [_i]
     lib.evogp_hip_error_string.restype = C.c_char_p
     got = lib.evogp_hip_abi_version()

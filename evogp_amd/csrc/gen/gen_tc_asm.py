@@ -95,6 +95,8 @@ DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such 
 EARLYREC = True  # END of a tree's last tile sends for the record of the batch's next tree (EVOGP_TC_GEN_EARLYREC=0: the tree loop does)
 L2WARM = True    # vector loads that pull the next batch's records into L2 (EVOGP_TC_GEN_L2WARM=0: off)
 KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_TC_GEN_KWARM_LINES)
+TOUCH = True     # fused build: the block's entry touches the rows of the wave's next batch (EVOGP_TC_GEN_TOUCH=0: off)
+RECGLC = False   # fused build: the record loads carry glc (EVOGP_TC_GEN_RECGLC=1) instead of one s_dcache_inv per batch
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
 
 
@@ -143,7 +145,7 @@ def count_path(L, start, taken, idx_on=True):
     return c
 
 
-def gen(K, DEPTH, stats=False, fast=0, info=None):
+def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
     assert K % 4 == 0 or K == 1
     assert 24 + 4 * K + K * DEPTH <= 256
     G = max(K // 4, 1)   # 1-KiB groups of a variable's tile: 64 lanes x 16 bytes (K = 1 uses the first row of every lane's four)
@@ -160,6 +162,30 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     T4 = sDST    # free outside the division stubs
     P1_, P2_, P3_, P4_ = 20, 21, 22, 23  # prologue scratch (control registers that are not live yet)
     CUR, END_, STRIDE, DYN, PF, BASE = "%[cur]", "%[lim]", "%[stride]", "%[dyn]", "%[pf]", "%[base]"
+    if fused:
+        # FUSED build (sr_fused_kernel, sr_tc.hip): the statement runs ONE batch of compiled trees and RETURNS.  The wave's C++ loop
+        # owns the work distribution and compiles the batch into the wave's own ring of records (hot in L2) right before it
+        # enters; nothing here touches s12 / s16 / s18 / s19 / s29 as batch bookkeeping or v12-v17 (the compiler keeps what it
+        # needs across the statement there), so the prefetch scratch and the table base live in two of those scalars.
+        assert not stats
+        PF, BASE = "s16", "s18"
+    GLC = " glc" if (fused and RECGLC) else ""
+
+    def rec_addr(lo, hi, index, tmp):
+        """address of the first block of the record of tree `index` (an SGPR name: tree number, or slot of the wave's ring)"""
+        if fused:
+            a(f"s_lshl_b32 s{tmp}, {index}, 8")
+            a(f"s_add_u32 s{lo}, s8, s{tmp}")
+            a(f"s_addc_u32 s{hi}, s9, 0")
+        else:
+            a(f"s_mul_hi_u32 s{hi}, {index}, s19")
+            a(f"s_mul_i32 s{lo}, {index}, s19")
+            a(f"s_add_u32 s{lo}, s{lo}, s8")
+            a(f"s_addc_u32 s{hi}, s{hi}, s9")
+
+    def load_window():
+        for i in range(4):
+            a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}{GLC}")
     uid = "%="
     L = []
     sect = [L]   # the list instructions are appended to (the program's tail is generated late but placed early, see below)
@@ -257,116 +283,150 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a("s_mov_b64 exec, -1")
 
     # ------------------------------------------------------------------ prologue
-    a("v_mbcnt_lo_u32_b32 v0, -1, 0")
-    a("v_mbcnt_hi_u32_b32 v0, -1, v0")
-    a("v_lshlrev_b32 v1, 4, v0")
-    a(f"v_add_u32 v1, {END_}, v1")               # END_ carries the LDS base of X on entry
-    a("v_mov_b32 v8, 0x7fc00000")
-    a("s_load_dwordx4 s[8:11], %[karg], 0x0")    # program records, fitness
-    a(f"s_load_dwordx2 s[{P3_}:{P4_}], %[karg], 0x10")  # work counter
-    a("s_load_dwordx8 s[12:19], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, query, record stride
-    a("s_waitcnt lgkmcnt(0)")
-    a(f"s_or_b32 s17, s17, {BASE}")               # BASE carries the trusted-variable bits (17-30, and 5-7) on entry
-    a(f"v_mov_b32 v10, s{P3_}")
-    a(f"v_mov_b32 v11, s{P4_}")
-    a("s_mul_i32 s14, s14, s15")
-    a(f"s_mul_i32 s14, s14, {G * 1024}")          # s14 = LDS distance from X to y
-    a("v_lshrrev_b32 v13, 4, v0")                 # warm-up offset: 16 lanes per record, 16 bytes per lane
-    a("v_mul_lo_u32 v13, v13, s19")
-    a("v_and_b32 v9, 15, v0")
-    a("v_lshl_add_u32 v13, v9, 4, v13")
-    a(f"s_load_dwordx4 s[{P1_}:{P4_}], %[karg], 0x48")  # static trees per workgroup, first dynamic tree, waves per workgroup
-    a("s_waitcnt lgkmcnt(0)")
-    a(f"s_mul_i32 {CUR}, {CUR}, s{P1_}")          # CUR carries the workgroup id on entry: first tree of its static share
-    a(f"s_add_u32 {END_}, {CUR}, s{P1_}")         # end of the static share
-    a(f"s_mul_i32 {STRIDE}, {STRIDE}, s16")       # STRIDE carries the wave id on entry
-    a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")        # this wave's first static batch
-    a(f"s_mul_i32 {STRIDE}, s{P3_}, s16")         # distance between two batches of one wave
-    a(f"s_mov_b32 {DYN}, s{P2_}")                 # first tree of the dynamic region
-    # one dynamic region and one counter line per XCD: region = XCC_ID & flags[15:12], s18 still holds trees per region
-    a(f"s_getreg_b32 s{P1_}, hwreg(HW_REG_XCC_ID, 0, 4)")
-    a(f"s_bfe_u32 s{P2_}, s17, 0x4000c")
-    a(f"s_and_b32 s{P1_}, s{P1_}, s{P2_}")
-    a(f"s_mul_i32 s{P2_}, s{P1_}, s18")
-    a(f"s_add_u32 {DYN}, {DYN}, s{P2_}")          # first tree of this XCD's region
-    a(f"s_add_u32 s{P2_}, {DYN}, s18")
-    a(f"s_min_u32 s12, s12, s{P2_}")              # s12: end of this XCD's region (the population size is not needed again)
-    a(f"s_lshl_b32 s{P1_}, s{P1_}, 7")            # this XCD's counter: 128 bytes per region
-    a(f"v_add_co_u32 v10, vcc, s{P1_}, v10")
-    a("v_addc_co_u32 v11, vcc, 0, v11, vcc")
-    a(f"s_getpc_b64 s[{T1}:{T2}]")
-    a(f"{lab('pc')}:")
-    a(f"s_add_u32 s{T1}, s{T1}, {lab('hbase')}-{lab('pc')}")
-    a(f"s_addc_u32 s{T2}, s{T2}, 0")
-    a(f"s_mov_b32 {BASE}, s{T1}")                 # 64 KiB aligned: its low half is zero
-    a(f"s_mov_b32 s{sPC + 1}, s{T2}")
-    a(f"{lab('run')}:")
-    if stats:
-        for r in (A_REC, A_WORK, A_TREES, A_DISP):
-            a(f"v_mov_b32 v{r}, 0")
-        a(f"s_memtime s[{T1}:{T2}]")
+    if fused:
+        # entry of a batch: the records were written by this wave's vector stores a moment ago -- wait for them, and drop what the
+        # scalar cache may still hold of the ring's previous contents
+        a("s_waitcnt vmcnt(0)")
+        if not RECGLC:
+            a("s_dcache_inv")
+        if TOUCH:
+            # one line per lane of the rows of the wave's NEXT batch: they arrive in L2 while this batch is interpreted (v12 is the
+            # sink; the batch's end waits for it with everything else)
+            a("global_load_ushort v12, %[taddr], off")
+        a("v_mbcnt_lo_u32_b32 v0, -1, 0")
+        a("v_mbcnt_hi_u32_b32 v0, -1, v0")
+        a("v_lshlrev_b32 v1, 4, v0")
+        a("v_add_u32 v1, %[ldsx], v1")
+        a("v_mov_b32 v8, 0x7fc00000")
+        a("s_load_dwordx4 s[8:11], %[karg], 0x0")    # base of the record rings, fitness
+        a(f"s_load_dwordx2 s[{P3_}:{P4_}], %[karg], 0x10")  # word 0 of the call's scratch block (the register kernels' pending flag)
+        a("s_load_dwordx8 s[12:19], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, -, -
         a("s_waitcnt lgkmcnt(0)")
-        a(f"v_mov_b32 v{A_START}, s{T1}")
-    a("s_mov_b32 s18, 1")  # 1 while this wave's part of the static share lasts
-    a(f"s_cmp_lt_u32 {CUR}, {END_}")
-    a(f"s_cbranch_scc0 {lab('batch')}")
-    warm(CUR)
-    # ------------------------------------------------------------------ batch loop
-    a(f"{lab('batch')}:")
-    a("s_cmp_eq_u32 s18, 0")
-    a(f"s_cbranch_scc1 {lab('dyn')}")
-    a(f"s_cmp_lt_u32 {CUR}, {END_}")
-    a(f"s_cbranch_scc0 {lab('to_dyn')}")
-    a(f"s_mov_b32 s{sT0}, {CUR}")
-    a(f"s_sub_u32 s{sNB}, {END_}, s{sT0}")
-    a(f"s_min_u32 s{sNB}, s{sNB}, s16")
-    a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")
-    a(f"s_cmp_lt_u32 {CUR}, {END_}")
-    a(f"s_cbranch_scc0 {lab('last_static')}")
-    warm(CUR)                                      # the records of this wave's NEXT batch
-    a(f"s_branch {lab('have_batch')}")
-    # this was the wave's last static batch: reserve its first dynamic batch now, one batch ahead like every later
-    # one (asked for only when the static share is used up, all waves queue at the counter at the same moment:
-    # ~11 ns per same-address atomic, 45 us for 4096 waves)
-    a(f"{lab('last_static')}:")
-    grab()
-    a("s_mov_b32 s18, 2")
-    a(f"s_branch {lab('have_batch')}")
-    a(f"{lab('to_dyn')}:")
-    a("s_cmp_eq_u32 s18, 2")
-    a("s_mov_b32 s18, 0")
-    a(f"s_cbranch_scc1 {lab('to_dyn_got')}")
-    tick_begin()
-    grab()  # a wave without a static batch (tiny populations)
-    a("s_waitcnt vmcnt(0)")
-    tick_end(A_WORK)
-    a(f"{lab('to_dyn_got')}:")
-    a("s_waitcnt vmcnt(0)")
-    a(f"v_readfirstlane_b32 s{sT0N}, v12")
-    a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
-    a(f"{lab('dyn')}:")
-    a(f"s_mov_b32 s{sT0}, s{sT0N}")
-    a(f"s_cmp_ge_u32 s{sT0}, s12")
-    a(f"s_cbranch_scc1 {lab('exit')}")
-    grab()                                         # the next batch, consumed at the end of this one
-    warm(f"s{sT0}")
-    a(f"s_sub_u32 s{sNB}, s12, s{sT0}")
-    dyn_batch(T1)
-    a(f"s_min_u32 s{sNB}, s{sNB}, s{T1}")
+        a("s_or_b32 s17, s17, %[trust]")              # the trusted-variable bits (17-30, and 5-7)
+        a(f"v_mov_b32 v10, s{P3_}")
+        a(f"v_mov_b32 v11, s{P4_}")
+        a("s_mul_i32 s14, s14, s15")
+        a(f"s_mul_i32 s14, s14, {G * 1024}")          # s14 = LDS distance from X to y
+        a("s_add_u32 s8, s8, %[roff]")                # this wave's ring of records
+        a("s_addc_u32 s9, s9, 0")
+        a(f"s_getpc_b64 s[{T1}:{T2}]")
+        a(f"{lab('pc')}:")
+        a(f"s_add_u32 s{T1}, s{T1}, {lab('hbase')}-{lab('pc')}")
+        a(f"s_addc_u32 s{T2}, s{T2}, 0")
+        a(f"s_mov_b32 {BASE}, s{T1}")                 # 64 KiB aligned: its low half is zero
+        a(f"s_mov_b32 s{sPC + 1}, s{T2}")
+        a(f"s_mov_b32 s{sT0}, %[t0]")
+        a(f"s_mov_b32 s{sNB}, %[nb]")
+    else:
+        a("v_mbcnt_lo_u32_b32 v0, -1, 0")
+        a("v_mbcnt_hi_u32_b32 v0, -1, v0")
+        a("v_lshlrev_b32 v1, 4, v0")
+        a(f"v_add_u32 v1, {END_}, v1")               # END_ carries the LDS base of X on entry
+        a("v_mov_b32 v8, 0x7fc00000")
+        a("s_load_dwordx4 s[8:11], %[karg], 0x0")    # program records, fitness
+        a(f"s_load_dwordx2 s[{P3_}:{P4_}], %[karg], 0x10")  # work counter
+        a("s_load_dwordx8 s[12:19], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, query, record stride
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"s_or_b32 s17, s17, {BASE}")               # BASE carries the trusted-variable bits (17-30, and 5-7) on entry
+        a(f"v_mov_b32 v10, s{P3_}")
+        a(f"v_mov_b32 v11, s{P4_}")
+        a("s_mul_i32 s14, s14, s15")
+        a(f"s_mul_i32 s14, s14, {G * 1024}")          # s14 = LDS distance from X to y
+        a("v_lshrrev_b32 v13, 4, v0")                 # warm-up offset: 16 lanes per record, 16 bytes per lane
+        a("v_mul_lo_u32 v13, v13, s19")
+        a("v_and_b32 v9, 15, v0")
+        a("v_lshl_add_u32 v13, v9, 4, v13")
+        a(f"s_load_dwordx4 s[{P1_}:{P4_}], %[karg], 0x48")  # static trees per workgroup, first dynamic tree, waves per workgroup
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"s_mul_i32 {CUR}, {CUR}, s{P1_}")          # CUR carries the workgroup id on entry: first tree of its static share
+        a(f"s_add_u32 {END_}, {CUR}, s{P1_}")         # end of the static share
+        a(f"s_mul_i32 {STRIDE}, {STRIDE}, s16")       # STRIDE carries the wave id on entry
+        a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")        # this wave's first static batch
+        a(f"s_mul_i32 {STRIDE}, s{P3_}, s16")         # distance between two batches of one wave
+        a(f"s_mov_b32 {DYN}, s{P2_}")                 # first tree of the dynamic region
+        # one dynamic region and one counter line per XCD: region = XCC_ID & flags[15:12], s18 still holds trees per region
+        a(f"s_getreg_b32 s{P1_}, hwreg(HW_REG_XCC_ID, 0, 4)")
+        a(f"s_bfe_u32 s{P2_}, s17, 0x4000c")
+        a(f"s_and_b32 s{P1_}, s{P1_}, s{P2_}")
+        a(f"s_mul_i32 s{P2_}, s{P1_}, s18")
+        a(f"s_add_u32 {DYN}, {DYN}, s{P2_}")          # first tree of this XCD's region
+        a(f"s_add_u32 s{P2_}, {DYN}, s18")
+        a(f"s_min_u32 s12, s12, s{P2_}")              # s12: end of this XCD's region (the population size is not needed again)
+        a(f"s_lshl_b32 s{P1_}, s{P1_}, 7")            # this XCD's counter: 128 bytes per region
+        a(f"v_add_co_u32 v10, vcc, s{P1_}, v10")
+        a("v_addc_co_u32 v11, vcc, 0, v11, vcc")
+        a(f"s_getpc_b64 s[{T1}:{T2}]")
+        a(f"{lab('pc')}:")
+        a(f"s_add_u32 s{T1}, s{T1}, {lab('hbase')}-{lab('pc')}")
+        a(f"s_addc_u32 s{T2}, s{T2}, 0")
+        a(f"s_mov_b32 {BASE}, s{T1}")                 # 64 KiB aligned: its low half is zero
+        a(f"s_mov_b32 s{sPC + 1}, s{T2}")
+        a(f"{lab('run')}:")
+        if stats:
+            for r in (A_REC, A_WORK, A_TREES, A_DISP):
+                a(f"v_mov_b32 v{r}, 0")
+            a(f"s_memtime s[{T1}:{T2}]")
+            a("s_waitcnt lgkmcnt(0)")
+            a(f"v_mov_b32 v{A_START}, s{T1}")
+        a("s_mov_b32 s18, 1")  # 1 while this wave's part of the static share lasts
+        a(f"s_cmp_lt_u32 {CUR}, {END_}")
+        a(f"s_cbranch_scc0 {lab('batch')}")
+        warm(CUR)
+        # ------------------------------------------------------------------ batch loop
+        a(f"{lab('batch')}:")
+        a("s_cmp_eq_u32 s18, 0")
+        a(f"s_cbranch_scc1 {lab('dyn')}")
+        a(f"s_cmp_lt_u32 {CUR}, {END_}")
+        a(f"s_cbranch_scc0 {lab('to_dyn')}")
+        a(f"s_mov_b32 s{sT0}, {CUR}")
+        a(f"s_sub_u32 s{sNB}, {END_}, s{sT0}")
+        a(f"s_min_u32 s{sNB}, s{sNB}, s16")
+        a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")
+        a(f"s_cmp_lt_u32 {CUR}, {END_}")
+        a(f"s_cbranch_scc0 {lab('last_static')}")
+        warm(CUR)                                      # the records of this wave's NEXT batch
+        a(f"s_branch {lab('have_batch')}")
+        # this was the wave's last static batch: reserve its first dynamic batch now, one batch ahead like every later
+        # one (asked for only when the static share is used up, all waves queue at the counter at the same moment:
+        # ~11 ns per same-address atomic, 45 us for 4096 waves)
+        a(f"{lab('last_static')}:")
+        grab()
+        a("s_mov_b32 s18, 2")
+        a(f"s_branch {lab('have_batch')}")
+        a(f"{lab('to_dyn')}:")
+        a("s_cmp_eq_u32 s18, 2")
+        a("s_mov_b32 s18, 0")
+        a(f"s_cbranch_scc1 {lab('to_dyn_got')}")
+        tick_begin()
+        grab()  # a wave without a static batch (tiny populations)
+        a("s_waitcnt vmcnt(0)")
+        tick_end(A_WORK)
+        a(f"{lab('to_dyn_got')}:")
+        a("s_waitcnt vmcnt(0)")
+        a(f"v_readfirstlane_b32 s{sT0N}, v12")
+        a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
+        a(f"{lab('dyn')}:")
+        a(f"s_mov_b32 s{sT0}, s{sT0N}")
+        a(f"s_cmp_ge_u32 s{sT0}, s12")
+        a(f"s_cbranch_scc1 {lab('exit')}")
+        grab()                                         # the next batch, consumed at the end of this one
+        warm(f"s{sT0}")
+        a(f"s_sub_u32 s{sNB}, s12, s{sT0}")
+        dyn_batch(T1)
+        a(f"s_min_u32 s{sNB}, s{sNB}, s{T1}")
     a(f"{lab('have_batch')}:")
     a(f"s_mov_b32 s{sB}, 0")
     a(f"s_mov_b64 s[{sOK}:{sOK + 1}], 0")
     a("v_mov_b32 v7, 0")
     # ------------------------------------------------------------------ tree loop
     a(f"{lab('tree')}:")
-    a(f"s_add_u32 s{T1}, s{sT0}, s{sB}")
-    a(f"s_mul_hi_u32 s{sREC + 1}, s{T1}, s19")
-    a(f"s_mul_i32 s{sREC}, s{T1}, s19")
-    a(f"s_add_u32 s{sREC}, s{sREC}, s8")
-    a(f"s_addc_u32 s{sREC + 1}, s{sREC + 1}, s9")
+    if fused:
+        rec_addr(sREC, sREC + 1, f"s{sB}", T1)   # slot b of the wave's ring
+    else:
+        a(f"s_add_u32 s{T1}, s{sT0}, s{sB}")
+        rec_addr(sREC, sREC + 1, f"s{T1}", T1)
     tick_begin()
-    for i in range(4):
-        a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+    load_window()
     a(f"{lab('tree_loaded')}:")   # (END of the batch's previous tree arrives here with this record already on its way)
     a("v_mov_b32 v6, 0")
     a(f"s_mov_b32 s{sTILE}, 0")
@@ -374,7 +434,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     tick_end(A_REC)
     if stats:
         a(f"v_add_u32 v{A_TREES}, 1, v{A_TREES}")
-    elif KWARM:
+    elif KWARM and not fused:
         # pull the NEXT tree's record into the scalar cache while this tree runs: four one-line loads whose result nobody
         # reads (the kernarg pointer pair is dead after the prologue and serves as the sink).  A record is 256 bytes
         # (asserted on the host), the next tree of the batch is the next record; the slack behind the last record
@@ -904,8 +964,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
         a(f"s_movrels_b32 s{sA}, s{W + 1}")                  # byte distance to the overflow block
         a(f"s_add_u32 s{sREC}, s{sREC}, s{sA}")
         a(f"s_addc_u32 s{sREC + 1}, s{sREC + 1}, 0")
-        for i in range(4):
-            a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+        load_window()
         # (sREC now points at the overflow block: the tile loop sees that and reloads the first block for the next pass)
         a("s_waitcnt lgkmcnt(0)")
         a(f"s_pack_lh_b32_b16 s{sPC}, s{W}, {BASE}")
@@ -1628,15 +1687,19 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a("global_store_dword v4, v5, s[10:11]")
     a("s_bitcmp1_b32 s17, 16")
     a(f"s_cbranch_scc0 {lab('bail_done')}")
-    a(f"s_getreg_b32 s{T1}, hwreg(HW_REG_XCC_ID, 0, 4)")
-    a(f"s_bfe_u32 s{T2}, s17, 0x4000c")
-    a(f"s_and_b32 s{T1}, s{T1}, s{T2}")
-    a(f"s_lshl_b32 s{T1}, s{T1}, 7")
-    a(f"s_add_u32 s{T1}, s{T1}, 128")                 # this XCD's counter line -> word 0 of the scratch block
-    a(f"v_sub_co_u32 v4, vcc, v10, s{T1}")
-    a("v_subbrev_co_u32 v5, vcc, 0, v11, vcc")
-    a("v_mov_b32 v9, 1")
-    a("global_store_dword v[4:5], v9, off")
+    if fused:
+        a("v_mov_b32 v9, 1")
+        a("global_store_dword v[10:11], v9, off")         # (v[10:11]: word 0 of the scratch block itself)
+    else:
+        a(f"s_getreg_b32 s{T1}, hwreg(HW_REG_XCC_ID, 0, 4)")
+        a(f"s_bfe_u32 s{T2}, s17, 0x4000c")
+        a(f"s_and_b32 s{T1}, s{T1}, s{T2}")
+        a(f"s_lshl_b32 s{T1}, s{T1}, 7")
+        a(f"s_add_u32 s{T1}, s{T1}, 128")                 # this XCD's counter line -> word 0 of the scratch block
+        a(f"v_sub_co_u32 v4, vcc, v10, s{T1}")
+        a("v_subbrev_co_u32 v5, vcc, 0, v11, vcc")
+        a("v_mov_b32 v9, 1")
+        a("global_store_dword v[4:5], v9, off")
     a(f"{lab('bail_done')}:")
     a("s_mov_b64 exec, -1")
     a(f"s_branch {lab('next_tree')}")
@@ -1816,13 +1879,10 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
             a(f"s_add_u32 s{T2}, s{sB}, 1")
             a(f"s_cmp_lt_u32 s{T2}, s{sNB}")
             a(f"s_cbranch_scc0 {lab(f'no_early{fl}')}")
-            a(f"s_add_u32 s{T2}, s{T2}, s{sT0}")
-            a(f"s_mul_hi_u32 s{sREC + 1}, s{T2}, s19")
-            a(f"s_mul_i32 s{sREC}, s{T2}, s19")
-            a(f"s_add_u32 s{sREC}, s{sREC}, s8")
-            a(f"s_addc_u32 s{sREC + 1}, s{sREC + 1}, s9")
-            for i in range(4):
-                a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+            if not fused:
+                a(f"s_add_u32 s{T2}, s{T2}, s{sT0}")
+            rec_addr(sREC, sREC + 1, f"s{T2}", T2)
+            load_window()
             a(f"{lab(f'no_early{fl}')}:")
         a(f"s_and_b32 s{T2}, s17, 0x12")   # a launch without a ragged tile (neither bit 1 nor bit 4) needs none of the following
         a(f"s_cbranch_scc0 {lab(f'end_full{fl}')}")
@@ -1880,17 +1940,16 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_cmp_lt_u32 s{sTILE}, s15")
     a(f"s_cbranch_scc0 {lab('tree_done')}")
     # another pass over the next tile: a two-block program left its overflow block in the window (NEXT moved sREC)
-    a(f"s_add_u32 s{T1}, s{sT0}, s{sB}")
-    a(f"s_mul_hi_u32 s{T2}, s{T1}, s19")
-    a(f"s_mul_i32 s{T1}, s{T1}, s19")
-    a(f"s_add_u32 s{T1}, s{T1}, s8")
-    a(f"s_addc_u32 s{T2}, s{T2}, s9")
+    if fused:
+        rec_addr(T1, T2, f"s{sB}", T1)
+    else:
+        a(f"s_add_u32 s{T1}, s{sT0}, s{sB}")
+        rec_addr(T1, T2, f"s{T1}", T1)
     a(f"s_cmp_eq_u32 s{T1}, s{sREC}")
     a(f"s_cbranch_scc1 {lab('tile')}")
     a(f"s_mov_b32 s{sREC}, s{T1}")
     a(f"s_mov_b32 s{sREC + 1}, s{T2}")
-    for i in range(4):
-        a(f"s_load_dwordx16 s[{W + 16 * i}:{W + 16 * i + 15}], s[{sREC}:{sREC + 1}], {hex(64 * i)}")
+    load_window()
     a("s_waitcnt lgkmcnt(0)")
     a(f"s_branch {lab('tile')}")
     a(f"{lab('tree_done')}:")
@@ -1927,13 +1986,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     tick_begin()
     a("s_waitcnt vmcnt(0)")
     tick_end(A_WORK)
-    a("s_cmp_eq_u32 s18, 0")
-    a(f"s_cbranch_scc0 {lab('no_grab')}")
-    a(f"v_readfirstlane_b32 s{sT0N}, v12")
-    a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
-    a(f"{lab('no_grab')}:")
+    NEXT_BATCH = lab('exit') if fused else lab('batch')
+    if not fused:
+        a("s_cmp_eq_u32 s18, 0")
+        a(f"s_cbranch_scc0 {lab('no_grab')}")
+        a(f"v_readfirstlane_b32 s{sT0N}, v12")
+        a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
+        a(f"{lab('no_grab')}:")
     a(f"s_cmp_eq_u64 s[{sOK}:{sOK + 1}], 0")
-    a(f"s_cbranch_scc1 {lab('batch')}")
+    a(f"s_cbranch_scc1 {NEXT_BATCH}")
     a(f"s_mov_b64 exec, s[{sOK}:{sOK + 1}]")
     # A dataset larger than LDS is run in pieces, one launch per piece: flags bit 2 = add this piece's sums to what the fitness
     # words hold (a word that holds the register kernels' sentinel -- a run-time bail-out in an earlier piece -- keeps it),
@@ -1954,7 +2015,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"s_cbranch_scc1 {lab('fin_mean')}")
     a("global_store_dword v4, v7, s[10:11]")
     a("s_mov_b64 exec, -1")
-    a(f"s_branch {lab('batch')}")
+    a(f"s_branch {NEXT_BATCH}")
     a(f"{lab('fin_mean')}:")
     a("v_cvt_f32_u32 v9, s13")
     d3, d4, d6, d7, d8 = DT
@@ -1971,9 +2032,17 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     a(f"v_div_fixup_f32 v{d3}, v{d3}, v9, v7")
     a(f"global_store_dword v4, v{d3}, s[10:11]")
     a("s_mov_b64 exec, -1")
-    a(f"s_branch {lab('batch')}")
+    a(f"s_branch {NEXT_BATCH}")
 
-    a(f"{lab('exit')}:")
+    if fused:
+        a(f"{lab('exit')}:")
+        a(f"s_getpc_b64 s[{T1}:{T2}]")
+        a(f"{lab('exit_pc')}:")
+        a(f"s_add_u32 s{T1}, s{T1}, {lab('exit_here')}-{lab('exit_pc')}")
+        a(f"s_addc_u32 s{T2}, s{T2}, 0")
+        a(f"s_setpc_b64 s[{T1}:{T2}]")
+    else:
+        a(f"{lab('exit')}:")
     if stats:  # {record wait, work wait, trees, 4 * dispatches, wave ticks, waves} += this wave's counters
         a(f"s_memtime s[{T1}:{T2}]")
         a("s_waitcnt lgkmcnt(0)")
@@ -1991,10 +2060,15 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
                 a(f"v_mov_b32 v12, v{src}")
             a(f"global_atomic_add_x2 v[10:11], v[12:13], off offset:{8 * i}")
         a("s_waitcnt vmcnt(0)")
-    a("s_endpgm")
+    if not fused:
+        a("s_endpgm")
     sect[0] = L
     at = L.index(".p2align 16")
     L[at:at] = tail
+    if fused:
+        # the statement's end -- behind the handler table and its bodies, up to 64 KiB + the bodies away from the batch epilogue,
+        # which therefore comes here through a computed address (a branch reaches 128 KiB, but only just)
+        a(f"{lab('exit_here')}:")
 
     if info is not None:
         info["K"], info["depth"], info["nhandlers"], info["slot"] = K, DEPTH, NHF, SLOT
@@ -2003,13 +2077,26 @@ def gen(K, DEPTH, stats=False, fast=0, info=None):
     body = "\n".join(f'    "{line}\\n\\t"' for line in L)
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV)]
     clob_txt = ", ".join(clob)
-    name = f"K{K}" + ("S" if stats else "") + ("", "F", "H")[fast]
+    name = f"K{K}" + ("S" if stats else "") + ("", "F", "H")[fast] + ("U" if fused else "")
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
-    if K == 8 and not stats and not fast:
+    if K == 8 and not stats and not fast and not fused:
         out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n#define EVOGP_TC_UNARY_MASK {(1 << len(UNARY)) - 1}\n#define EVOGP_TC_HEAVY_REGS {HEAVY_REGS}\n#define EVOGP_TC_DIVIP_REGS {DIVIP_REGS}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
+    if fused:
+        # v12-v17 are not touched (the compiler keeps its own state across the statement there)
+        clob = ['"memory"', '"vcc"', '"scc"', '"m0"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV) if not 13 <= i <= 17]
+        clob_txt = ", ".join(clob)
+        out += f"#define EVOGP_TC_FUSED_TOUCH {1 if TOUCH else 0}\n" if name == "K8U" else ""
+        out += f"#define EVOGP_TC_ASM_{name}(karg_, t0_, nb_, roff_, ldsx_, trust_, taddr_) \\\n  asm volatile( \\\n"
+        out += "\n".join(line + " \\" for line in body.split("\n"))
+        out += f'''
+    : \\
+    : [karg] "s"(karg_), [t0] "s"(t0_), [nb] "s"(nb_), [roff] "s"(roff_), [ldsx] "s"(ldsx_), [trust] "s"(trust_), [taddr] "v"(taddr_) \\
+    : {clob_txt})
+'''
+        return out
     out += f"#define EVOGP_TC_ASM_{name}(karg_, wgid_, ldsx_, wave_, dyn_, pf_, base_) \\\n  asm volatile( \\\n"
     out += "\n".join(line + " \\" for line in body.split("\n"))
     out += f'''
@@ -2035,6 +2122,8 @@ if __name__ == "__main__":
     PKCONST = os.environ.get("EVOGP_TC_GEN_PKCONST", "1") != "0"
     DIVABREAST = os.environ.get("EVOGP_TC_GEN_DIVABREAST", "1") != "0"
     PKARITH = os.environ.get("EVOGP_TC_GEN_PKARITH", "1") != "0"
+    RECGLC = os.environ.get("EVOGP_TC_GEN_RECGLC", "0") == "1"
+    TOUCH = os.environ.get("EVOGP_TC_GEN_TOUCH", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}
@@ -2048,6 +2137,8 @@ if __name__ == "__main__":
                 f.write(gen(K, depth, fast=fast, info=info))
                 table[f"K{K}_{tag}"] = info
             if K == 8:
+                for fast in (0, 1, 2):   # the fused build (one batch per entry, sr_fused_kernel)
+                    f.write(gen(K, depth, fast=fast, fused=True))
                 f.write(gen(K, depth, stats=True))  # cycle-accounting build (its top stack slot holds the counters)
         print("wrote", f"{outdir}/tc_interp_k{K}.inc")
     # per-handler instruction counts of the generated interpreters, read by bench.py (a build artefact like the .inc files)

@@ -288,9 +288,19 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
  *   evogp_hip_set_program_buffer_limit  caps the buffer (default 16 GiB): a call that would need more runs on the register
  *                                       interpreters instead (same results, 3-6x slower); 0 disables the compiled path.
  *   evogp_hip_program_buffer_bytes      bytes currently held on the current device.
- *   evogp_hip_release_workspaces        waits for the current device and frees the buffer; the next fitness call allocates again. */
+ *   evogp_hip_release_workspaces        waits for the current device and frees the buffer (and the rings below); the next
+ *                                       fitness call allocates again.
+ * Round 4: a call whose trees cannot need the general program compiler (single output, gp_len <= 64, a dataset that fits LDS, and
+ * a function mask that says so: evogp_hip_sr_fitness_hinted) runs as ONE kernel whose waves compile the batch of eight trees they
+ * are about to interpret into a RING of records of their own -- no population-sized buffer at all.  A ring is
+ *     bytes = compute units * 16 waves * 2 arrays * 8 records * 256      (16 MiB on a 256-CU device, whatever the population)
+ * and lives in L2; every stream that makes such calls gets one (plus one spare per device, which the first call on a CAPTURING
+ * stream takes: nothing is allocated inside a capture), they are never freed or moved before evogp_hip_release_workspaces, so a
+ * HIP graph that holds such a call stays valid while later calls grow or shrink the population.
+ *   evogp_hip_record_ring_bytes         bytes of rings currently held on the current device. */
 int evogp_hip_set_program_buffer_limit(unsigned long long bytes);
 unsigned long long evogp_hip_program_buffer_bytes(void);
+unsigned long long evogp_hip_record_ring_bytes(void);
 int evogp_hip_release_workspaces(void);
 
 /* Average duration in milliseconds of the most recent `evogp_hip_*` launch sequence that was

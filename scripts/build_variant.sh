@@ -9,7 +9,7 @@ D=$R/build/variant_$suffix
 rm -rf $D; mkdir -p $D/src $D/lib; ln -sfn $R/include $R/build/include
 cp $R/evogp_amd/csrc/*.hip $R/evogp_amd/csrc/*.hpp $D/src/
 (cd $D/src && env "$@" python3 $R/evogp_amd/csrc/gen/gen_tc_asm.py . > /dev/null)
-(cd $D/src && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-inline-asm $EXTRA_HIPFLAGS -I$R/include -c sr_tc.hip -o sr_tc.o)
+(cd $D/src && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-inline-asm -mllvm -amdgpu-atomic-optimizer-strategy=None $EXTRA_HIPFLAGS -I$R/include -c sr_tc.hip -o sr_tc.o)
 objs=$(ls $R/build/obj/*.o | grep -v /sr_tc.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/evogp_amd/lib/libevogp_hip_$suffix.so $objs $D/src/sr_tc.o
 echo "built evogp_amd/lib/libevogp_hip_$suffix.so ($*)"

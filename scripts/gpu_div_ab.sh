@@ -10,7 +10,7 @@ cd $R
   timeout 600 python scripts/dbg/div_range_ab.py run new
   # environment variants of the same library:  AB_ENV="name:VAR=value name2:VAR=value" bash scripts/gpu_div_ab.sh TAG
   for ev in $AB_ENV; do
-    v=${ev%%:*}; kv=${ev#*:}
+    v=${ev%%:*}; kv=${ev#*:}; kv=${kv//,/ }
     env $kv timeout 600 python scripts/dbg/div_range_ab.py run $v
     python scripts/dbg/div_range_ab.py cmp new $v
     echo "cmp new $v rc=$?"

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared_symbols():
         assert hasattr(lib, sym), f"libevogp_hip.so does not export {sym}"
     assert set(_lib.PROTOTYPES) | {"evogp_hip_error_string", "evogp_hip_evaluate_workspace_bytes", "evogp_hip_select_workspace_bytes",
-                                  "evogp_hip_program_buffer_bytes"} == set(declared_symbols())
+                                  "evogp_hip_program_buffer_bytes", "evogp_hip_record_ring_bytes"} == set(declared_symbols())
     assert lib.evogp_hip_abi_version() == _lib.ABI_VERSION
 
 
