@@ -564,17 +564,106 @@ def main():
                 sg5.step(fit5)
                 barrier(); g2 = time.perf_counter()
                 roll_ms.append(max_over_ranks((g1 - g0) * 1e3)); gen5_ms.append(max_over_ranks((g2 - g0) * 1e3))
+            # the engine's share of a step: the prepared forward pass alone (and, for the record, the stack interpreter a forest's FIRST
+            # call runs), each as a captured graph replayed like the rollout's step -- the rest of us_per_step is the environment
+            def replayed_us(fn, reps=300):
+                obs5 = torch.randn(n5, 17, device=device)
+                fn(obs5); fn(obs5)
+                side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+                gf = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(gf, stream=side):
+                        fn(obs5)
+                torch.cuda.current_stream().wait_stream(side)
+                for _ in range(20):
+                    gf.replay()
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps):
+                    gf.replay()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e6
+
+            fwd_us = stack_us = None
+            try:
+                f5 = sg5.forest
+                fwd_us = replayed_us(lambda o: f5.forward(o))
+                vt, tt, st5 = f5.batch_node_value, f5.batch_node_type, f5.batch_subtree_size
+                stack_us = replayed_us(lambda o: torch.ops.evogp_cuda.tree_evaluate(n5, 256, 17, 6, vt, tt, st5, o))
+            except Exception as exc:
+                fwd_us = fwd_us if fwd_us is not None else repr(exc)[:200]
             extras["c5_rollout"] = {
+                "forward_us_per_step": fwd_us, "stack_interpreter_us_per_step": stack_us,
+                "env_us_per_step": (float(np.median(roll_ms[1:])) * 1e3 / c5_steps - fwd_us) if isinstance(fwd_us, float) else None,
                 "workload": f"BASELINE configs[4] shape: policy trees pop {c5_pop} over {world} rank(s) ({n5} per rank), 17 observations, 6 actions, "
                             f"max_tree_len 256, {c5_steps} steps per generation; batched linear stand-in environment (no Brax in this image)",
                 "rollout_ms": float(np.median(roll_ms[1:])), "us_per_step": float(np.median(roll_ms[1:])) * 1e3 / c5_steps,
                 "policy_steps_per_s": c5_pop * c5_steps / (float(np.median(roll_ms[1:])) / 1e3),
                 "generation_ms": float(np.median(gen5_ms[1:])), "first_rollout_ms": roll_ms[0],
                 "what": "rollout = prepare the forest's operation lists + capture one step + 1000 graph replays (max over ranks); generation = "
-                        "rollout + sharded step (fitness all-gather, selection, row exchange, breeding)"}
+                        "rollout + sharded step (fitness all-gather, selection, row exchange, breeding); forward_us_per_step = the prepared forward "
+                        "pass alone (Forest.forward on an unchanged forest, replayed graph), stack_interpreter_us_per_step = tree_evaluate itself "
+                        "(what a forest's first call runs), env_us_per_step = us_per_step - forward: the torch stand-in environment's kernels"}
             del sg5, prob5, pf
         except Exception as exc:
             extras["c5_rollout"] = {"error": repr(exc)[:300]}
+
+    if not args.headline_only and rank == 0:
+        # The reference's own SR script shape (example/uci_sr.py:45-75): max_tree_len 512, max_layer_cnt 9, layer_leaf_prob 0.3, 10 000
+        # constants in [-5, 5], functions + - * / sin cos tan, DefaultMutation(0.1, max_layer_cnt 4), TournamentSelection(20, 0.5, 0.1),
+        # on the 10-variable dataset of the headline (the UCI tables need the network), pop 100 000 x 1024 rows.  Timed at generation 0
+        # (short trees: the generator's depth limits) and after 30 generations of the script's own operators (rows fill up towards
+        # 512 nodes: the long-program paths), each with the stage split, the share of trees the threaded code leaves to the register
+        # kernels and the HBM roofline of SURVEY.md section 8d.
+        try:
+            from evogp_amd.algorithm.selection import TournamentSelection as _TS
+
+            udesc = GenerateDescriptor(max_tree_len=512, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/", "sin", "cos", "tan"],
+                                       max_layer_cnt=9, const_range=[-5, 5], sample_cnt=10000, layer_leaf_prob=0.3)
+            upop = 100_000
+            ualgo = GeneticProgramming(Forest.random_generate(upop, udesc, keys=torch.tensor([42, 0], dtype=torch.uint32, device=device)),
+                                       DefaultCrossover(), DefaultMutation(0.1, udesc.update(max_layer_cnt=4)),
+                                       _TS(tournament_size=20, survivor_rate=0.5, elite_rate=0.1))
+            uneg = torch.full((upop,), float("-inf"), dtype=torch.float32, device=device)
+
+            def uci_point(f):
+                for _ in range(3):
+                    f.SR_fitness(Xd, yd, True, "auto")
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(10):
+                    f.SR_fitness(Xd, yd, True, "auto")
+                torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+                _lib.check(_lib.lib.evogp_hip_debug_profile(2), "profile on")   # stage events; the call stops behind the threaded code
+                words = f.SR_fitness(Xd, yd, True, "auto").view(torch.int32)
+                st = (ctypes.c_float * 3)(); nc = ctypes.c_int(0)
+                _lib.check(_lib.lib.evogp_hip_debug_profile_read(st, ctypes.byref(nc)), "profile read")
+                _lib.check(_lib.lib.evogp_hip_debug_profile(0), "profile off")
+                left = int(((words == 0x7FC0FEED) | (words == 0x7FC0BEEF) | (words == 0x7FC0DEED)).sum())
+                lens = f.batch_subtree_size[:, 0].to(torch.int64)
+                nodes = int(lens.sum())
+                abytes = 6.0 * nodes + 2.0 * upop + 4.0 * DATAPOINTS * (VAR_LEN + 1) + 4.0 * upop
+                return {"call_ms": ms, "tree_evals_per_s": upop * DATAPOINTS / (ms / 1e3), "node_evals_per_s": nodes * DATAPOINTS / (ms / 1e3),
+                        "mean_tree_len": nodes / upop, "max_tree_len": int(lens.max()), "share_longer_than_64": float((lens > 64).float().mean()),
+                        "stage_ms": {"program_compilers": st[0], "interpreter": st[1]},
+                        "share_left_to_register_kernels": left / upop,
+                        "roofline": {"bound": "hbm", "algorithmic_bytes": abytes, "achieved": abytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": abytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS}}
+
+            upoints = {"generation_0": uci_point(ualgo.forest)}
+            ugen = []
+            for g_ in range(30):
+                torch.cuda.synchronize(); g0 = time.perf_counter()
+                f = -ualgo.forest.SR_fitness(Xd, yd, True, "auto")
+                ualgo.step(torch.where(torch.isnan(f), uneg, f))
+                torch.cuda.synchronize(); ugen.append((time.perf_counter() - g0) * 1000)
+            upoints["generation_30"] = uci_point(ualgo.forest)
+            extras["uci_sr_shape"] = {
+                "workload": "example/uci_sr.py:45-75 shape: pop 100k x 1024 rows x 10 variables, max_tree_len 512, max_layer_cnt 9, layer_leaf_prob 0.3, "
+                            "10 000 constants in [-5, 5], + - * / sin cos tan, DefaultCrossover, DefaultMutation(0.1, max_layer_cnt 4), "
+                            "TournamentSelection(20, survivor_rate 0.5, elite_rate 0.1)",
+                "points": upoints, "generation_ms": {"first": ugen[0], "median_gen_10_29": float(np.median(ugen[10:])), "last": ugen[-1]}}
+            del ualgo
+        except Exception as exc:
+            extras["uci_sr_shape"] = {"error": repr(exc)[:300]}
 
     if not args.headline_only and rank == 0:
         # the reference's only published timing: test/vis.ipynb:12-45,171,181 -- XOR-3d, pop 100 000, max_tree_len 128, 8 datapoints,

@@ -97,6 +97,21 @@ struct CounterRing {
 };
 static std::vector<CounterRing> g_ring[64];
 
+__global__ void zero_words_kernel(unsigned *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+hipError_t zero_words_async(void *ptr, size_t nwords, hipStream_t stream) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!capturing) return hipMemsetAsync(ptr, 0, nwords * sizeof(unsigned), stream);
+    size_t blocks = (nwords + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned *)ptr, nwords);
+    return hipGetLastError();
+}
+
 unsigned *acquire_counter(hipStream_t stream, hipError_t *err) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -121,7 +136,7 @@ unsigned *acquire_counter(hipStream_t stream, hipError_t *err) {
         }
         slot = r->base + 4 * (r->next++ % kCounterRing);
     }
-    const hipError_t e = hipMemsetAsync(slot, 0, 4 * sizeof(unsigned), stream);
+    const hipError_t e = zero_words_async(slot, 4, stream);
     if (e != hipSuccess) { *err = e; return nullptr; }
     *err = hipSuccess;
     return slot;
@@ -157,7 +172,7 @@ unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hip
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     if (capturing) {
-        hipError_t e = hipMemsetAsync(s->blocks + kCallScratchWords * use, 0, kCallScratchWords * sizeof(unsigned), stream);
+        hipError_t e = zero_words_async(s->blocks + kCallScratchWords * use, kCallScratchWords, stream);
         if (e != hipSuccess) { *err = e; return nullptr; }
         s->cur = use;
         s->next_clean = false;
@@ -166,7 +181,7 @@ unsigned *acquire_call_scratch(hipStream_t stream, unsigned **zero_for_next, hip
         return s->blocks + kCallScratchWords * use;
     }
     if (!s->next_clean) {
-        hipError_t e = hipMemsetAsync(s->blocks + kCallScratchWords * use, 0, kCallScratchWords * sizeof(unsigned), stream);
+        hipError_t e = zero_words_async(s->blocks + kCallScratchWords * use, kCallScratchWords, stream);
         if (e != hipSuccess) { *err = e; return nullptr; }
     }
     s->cur = use;
@@ -183,6 +198,26 @@ void call_scratch_next_is_clean(hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     for (auto &kv : g_scratch[dev]) if (kv.first == stream) kv.second.next_clean = true;
 }
+
+}  // namespace evogp
+
+// Debugging aid (not declared in the header): both call-scratch blocks of `stream` and the index of the current one, copied to the
+// host after a device synchronisation.  host_words: 2 * 2304 words.
+extern "C" int evogp_hip_debug_call_scratch(void *stream, unsigned *host_words, int *current) {
+    using namespace evogp;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto &kv : g_scratch[dev & 63])
+        if (kv.first == (hipStream_t)stream) {
+            (void)hipDeviceSynchronize();
+            *current = kv.second.cur;
+            return (int)hipMemcpy(host_words, kv.second.blocks, 2 * kCallScratchWords * sizeof(unsigned), hipMemcpyDeviceToHost);
+        }
+    return -1;
+}
+
+namespace evogp {
 
 struct TimerSlot {
     hipEvent_t begin = nullptr, end = nullptr;

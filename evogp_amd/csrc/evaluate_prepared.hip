@@ -171,7 +171,7 @@ extern "C" int evogp_hip_evaluate_prepare(unsigned pop_size, unsigned gp_len, un
     p.count = (int *)((char *)workspace + (size_t)maxrec * pop_size * sizeof(uint4));
     p.info = p.count + pop_size;
     p.pop = (int)pop_size; p.gp_len = (int)gp_len; p.var_len = (int)var_len; p.out_len = (int)out_len; p.maxrec = (int)maxrec;
-    hipError_t e = hipMemsetAsync(p.info, 0, 64, stream);
+    hipError_t e = zero_words_async(p.info, 16, stream);
     if (e != hipSuccess) return (int)e;
     long blocks = ((long)pop_size + 3) / 4;
     const long cap = (long)device_info().num_cus * 16;

@@ -79,7 +79,7 @@ HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top o
 SLOT = 256  # bytes per handler slot
 DIVIP_REGS = 12  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
 DIVIP = ("SS", "SC", "CS")  # division forms with an in-place handler (operands read where they are, temporaries above the stack)
-NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls
+NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1 + 1  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls + swap
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
@@ -95,6 +95,7 @@ DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such 
 EARLYREC = True  # END of a tree's last tile sends for the record of the batch's next tree (EVOGP_TC_GEN_EARLYREC=0: the tree loop does)
 L2WARM = True    # vector loads that pull the next batch's records into L2 (EVOGP_TC_GEN_L2WARM=0: off)
 KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_TC_GEN_KWARM_LINES)
+FUSED_SIZE_OFF, FUSED_LEN_OFF = 96 + 16, 96 + 60   # FusedParams (sr_tc.hip): c.size and c.gp_len behind the 96 bytes of TcParams (static_asserts there)
 TOUCH = True     # fused build: the block's entry touches the rows of the wave's next batch (EVOGP_TC_GEN_TOUCH=0: off)
 RECGLC = False   # fused build: the record loads carry glc (EVOGP_TC_GEN_RECGLC=1) instead of one s_dcache_inv per batch
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
@@ -211,7 +212,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
     for i, form in enumerate(DIVIP):
         hid[f"divip_{form}"] = nh + 14 + i
     hid["end_cls"] = nh + 14 + len(DIVIP)
-    assert NHF == nh + 14 + len(DIVIP) + 1
+    hid["swap"] = nh + 14 + len(DIVIP) + 1
+    assert NHF == nh + 14 + len(DIVIP) + 2
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -303,6 +305,20 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
         a("s_load_dwordx8 s[12:19], %[karg], 0x28")  # pop, D, var_len, tiles, batch, flags, -, -
         a("s_waitcnt lgkmcnt(0)")
         a("s_or_b32 s17, s17, %[trust]")              # the trusted-variable bits (17-30, and 5-7)
+        # the lengths of the NEXT batch's trees (size[t0n + lane][0], lanes below its tree count) for the wave's compiler: on their way
+        # while this batch runs (FUSED_SIZE_OFF / FUSED_LEN_OFF: where the kernel's argument block keeps the size array and gp_len)
+        a(f"s_load_dwordx2 s[{P1_}:{P2_}], %[karg], {hex(FUSED_SIZE_OFF)}")
+        a(f"s_load_dword s{T1}, %[karg], {hex(FUSED_LEN_OFF)}")
+        a(f"s_bfe_u32 s{T2}, %[nb], 0x80008")
+        a("v_add_u32 v4, %[t0n], v0")
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"v_mul_lo_u32 v4, v4, s{T1}")
+        a("v_lshlrev_b32 v4, 1, v4")
+        a(f"s_bfm_b64 exec, s{T2}, 0")
+        a(f"s_cbranch_execz {lab('no_lens')}")
+        a(f"global_load_sshort %[lensn], v4, s[{P1_}:{P2_}]")
+        a(f"{lab('no_lens')}:")
+        a("s_mov_b64 exec, -1")
         a(f"v_mov_b32 v10, s{P3_}")
         a(f"v_mov_b32 v11, s{P4_}")
         a("s_mul_i32 s14, s14, s15")
@@ -316,7 +332,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
         a(f"s_mov_b32 {BASE}, s{T1}")                 # 64 KiB aligned: its low half is zero
         a(f"s_mov_b32 s{sPC + 1}, s{T2}")
         a(f"s_mov_b32 s{sT0}, %[t0]")
-        a(f"s_mov_b32 s{sNB}, %[nb]")
+        a(f"s_and_b32 s{sNB}, %[nb], 0xff")
     else:
         a("v_mbcnt_lo_u32_b32 v0, -1, 0")
         a("v_mbcnt_hi_u32_b32 v0, -1, v0")
@@ -1099,6 +1115,18 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
         for k in range(K):
             a(f"v_mov_b32 v{T + k}, v{P[fl] + k}")
         a(f"s_branch {lab('endcls_body')}")
+        # SWAP: exchange the two top entries of the operand stack.  The general compiler puts it in front of a non-commutative function
+        # whose operands it had evaluated in the other order (the larger subtree first: sr_tc.hip, compile_general's reordering pass)
+        begin("swap", fl)
+        entry()
+        prefetch(P[1 - fl])
+        m0_stack(MODE["SRC0"] | MODE["SRC1"], -2 * K)
+        rows_mov(T, S0 + K)
+        m0_stack(MODE["SRC0"] | MODE["SRC1"] | MODE["DST"], -2 * K)
+        rows_mov(S0 + K, S0)
+        m0_stack(MODE["DST"], -2 * K)
+        rows_mov(S0, T)
+        epilogue()
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # In-place division bodies.  The gather forms above copy the operands into fixed banks because the division's temporaries
@@ -1518,7 +1546,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
             a(f"v_max_f32 v{tx}, v{tx}, |v{rest[0]}|")
         a(f"s_mov_b32 s{T1}, 0x48000000")             # 2^17
         a(f"v_cmp_le_f32 vcc, s{T1}, v{tx}")
-        a(f"s_cbranch_vccnz {lab('bail_far')}")
+        a(f"s_cbranch_vccnz {lab(f'triglib_{uop}')}")   # some row needs the library's Payne-Hanek reduction: the whole function, row by row (below)
         for k in range(K):
             x, res = T + k, Q + k
             a(f"s_mov_b32 s{T1}, 0x3f22f983")         # 2 / pi
@@ -1576,6 +1604,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
                 a(f"v_xor_b32 v{res}, v{tu}, v{tr}")
             # (the library's final "NaN for a non-finite operand" select is not needed: infinities never get past the
             # range test above, and a NaN operand makes every step of the sequence NaN)
+        a(f"{lab(f'trigdone_{uop}')}:")
         a(f"s_mov_b32 m0, s{sDST}")
         for k in range(K):
             a(f"v_mov_b32 v{S0 + k}, v{Q + k}")
@@ -1662,6 +1691,19 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
         for k in range(K):
             a(f"v_mov_b32 v{S0 + k}, v{Q + k}")
         epilogue()
+    # ---- sin / cos / tan of a block that holds an operand of 2^17 or more (or an infinity): the device library's WHOLE function --
+    # both reductions under the exec masks the compiler gave them, gen/ocml_transcribe.py -- row by row like pow, in the registers above
+    # the live operand stack.  (Round 3 handed such a tree to the register kernels at run time: 3 % of an evolved example/uci_sr.py
+    # population after 30 generations, each costing as much as a thousand trees that stay.)  Only a stack that reaches into those
+    # registers still bails out.
+    for uop in ("sin", "cos", "tan"):
+        if uop not in UNARY:
+            continue
+        a(f"{lab(f'triglib_{uop}')}:")
+        a(f"s_cmp_gt_u32 s{sH}, {top - S0}")
+        a(f"s_cbranch_scc1 {lab('bail_far')}")
+        row_loop(f"triglib_{uop}", BODIES[uop], 1, Q)
+        a(f"s_branch {lab(f'trigdone_{uop}')}")
     # The bodies above sit behind the 64-KiB-aligned handler table; the wave's outer loops sit in front of it, up to 64 KiB of
     # padding away.  A branch reaches 128 KiB: the pieces that jump BACK into the outer loops -- the run-time bail-out and
     # everything from the END handlers to the end of the kernel -- are therefore placed in front of the padding (reached from the
@@ -2089,11 +2131,12 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
         clob = ['"memory"', '"vcc"', '"scc"', '"m0"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV) if not 13 <= i <= 17]
         clob_txt = ", ".join(clob)
         out += f"#define EVOGP_TC_FUSED_TOUCH {1 if TOUCH else 0}\n" if name == "K8U" else ""
-        out += f"#define EVOGP_TC_ASM_{name}(karg_, t0_, nb_, roff_, ldsx_, trust_, taddr_) \\\n  asm volatile( \\\n"
+        out += f"#define EVOGP_TC_FUSED_SIZE_OFF {FUSED_SIZE_OFF}\n#define EVOGP_TC_FUSED_LEN_OFF {FUSED_LEN_OFF}\n" if name == "K8U" else ""
+        out += f"#define EVOGP_TC_ASM_{name}(karg_, t0_, nb_, roff_, ldsx_, trust_, taddr_, t0n_, lensn_) \\\n  asm volatile( \\\n"
         out += "\n".join(line + " \\" for line in body.split("\n"))
         out += f'''
-    : \\
-    : [karg] "s"(karg_), [t0] "s"(t0_), [nb] "s"(nb_), [roff] "s"(roff_), [ldsx] "s"(ldsx_), [trust] "s"(trust_), [taddr] "v"(taddr_) \\
+    : [lensn] "=&v"(lensn_) \\
+    : [karg] "s"(karg_), [t0] "s"(t0_), [nb] "s"(nb_), [roff] "s"(roff_), [ldsx] "s"(ldsx_), [trust] "s"(trust_), [taddr] "v"(taddr_), [t0n] "s"(t0n_) \\
     : {clob_txt})
 '''
         return out

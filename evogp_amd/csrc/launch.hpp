@@ -37,6 +37,12 @@ const DeviceInfo &device_info();
 // ordered by the stream.  Returns nullptr and sets *err on failure.
 unsigned *acquire_counter(hipStream_t stream, hipError_t *err);
 
+// Zero `nwords` 32-bit words on `stream`.  Inside a stream capture a small kernel does it: a memset node recorded from hipMemsetAsync
+// was found to write other values than zero when its graph is replayed (ROCm 7.2, gfx950: the call-scratch block of a captured
+// tree_SR_fitness came back holding what looks like another kernel's argument block; scripts/dbg/graph_ring4.py), which left the work
+// counters of every replay but the first dirty.
+hipError_t zero_words_async(void *ptr, size_t nwords, hipStream_t stream);
+
 // integer value of an environment switch, or `def` when it is not set
 int env_int(const char *name, int def);
 

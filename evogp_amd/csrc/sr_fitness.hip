@@ -51,6 +51,7 @@ struct ProfCall {
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static bool g_prof_skip_followups = false;   // evogp_hip_debug_profile(2): the call stops behind the threaded code (marked trees keep their sentinel words)
 static std::vector<ProfCall> g_prof;
 
 // flag word `i` of the call's scratch block, over the chunks the threaded code cut the population into
@@ -518,6 +519,10 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
     }
     if (profiling) (void)hipEventRecord(prof.ev[2], stream);
+    if (profiling && tc_done && g_prof_skip_followups) {   // diagnostics: which trees does the threaded code leave to the register kernels?
+        prof_done(tc_done);
+        return 0;
+    }
     if (tc_done && mo) {  // multi-output trees the threaded code left marked: FULL register build, then the general kernel
         if (p.D >= 128) e = p.var_len <= 16 ? launch_fast<2, 16, 16, true, 8, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<2, 16, 32, true, 8, STORE, false>(p, 1, stream, p.marks + 3);
         else e = p.var_len <= 16 ? launch_fast<1, 32, 16, true, 16, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<1, 32, 32, true, 16, STORE, false>(p, 1, stream, p.marks + 3);
@@ -644,6 +649,7 @@ extern "C" int evogp_hip_debug_profile(int enable) {
     for (auto &c : g_prof) for (auto &ev : c.ev) (void)hipEventDestroy(ev);
     g_prof.clear();
     g_prof_on = enable != 0;
+    g_prof_skip_followups = enable == 2;
     return 0;
 }
 

@@ -346,6 +346,6 @@ extern "C" int evogp_hip_batch_argmax_count(unsigned pop_size, unsigned data_poi
             return (int)launch_deep_recount(p, true, stream);
         }
     }
-    if ((e = hipMemsetAsync(counts, 0, (size_t)pop_size * sizeof(unsigned), stream)) != hipSuccess) return (int)e;
+    if ((e = zero_words_async(counts, (size_t)pop_size, stream)) != hipSuccess) return (int)e;
     return (int)launch_wide<true, 1>(p, stream);
 }

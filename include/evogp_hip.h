@@ -293,7 +293,7 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
  * Round 4: a call whose trees cannot need the general program compiler (single output, gp_len <= 64, a dataset that fits LDS, and
  * a function mask that says so: evogp_hip_sr_fitness_hinted) runs as ONE kernel whose waves compile the batch of eight trees they
  * are about to interpret into a RING of records of their own -- no population-sized buffer at all.  A ring is
- *     bytes = compute units * 16 waves * 2 arrays * 8 records * 256      (16 MiB on a 256-CU device, whatever the population)
+ *     bytes = compute units * 16 waves * 2 arrays * 16 records * 256     (32 MiB on a 256-CU device, whatever the population)
  * and lives in L2; every stream that makes such calls gets one (plus one spare per device, which the first call on a CAPTURING
  * stream takes: nothing is allocated inside a capture), they are never freed or moved before evogp_hip_release_workspaces, so a
  * HIP graph that holds such a call stays valid while later calls grow or shrink the population.
@@ -317,7 +317,9 @@ int evogp_hip_debug_set_stats(unsigned long long *device_counters);
 /* Per-stage timing of evogp_hip_sr_fitness (profiling, no counterpart in the reference).  While enabled, every call records
  * HIP events on its launch stream: before the call, between the program compiler and the interpreter kernel, behind the
  * interpreter, behind the follow-up kernels.  _read waits for the recorded calls and returns the average duration in ms
- * of {compiler, interpreter, follow-ups} over the calls the threaded-code path took; enable(…) also clears the record. */
+ * of {compiler, interpreter, follow-ups} over the calls the threaded-code path took; enable(…) also clears the record.
+ * enable == 2: as 1, and the calls STOP behind the threaded code -- trees it leaves to the register kernels keep their sentinel
+ * words (0x7FC0FEED, 0x7FC0BEEF, 0x7FC0DEED) in the fitness vector, so a script can count them (bench.py). */
 int evogp_hip_debug_profile(int enable);
 int evogp_hip_debug_profile_read(float *stage_ms /* [3] */, int *calls);
 

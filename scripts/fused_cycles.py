@@ -16,7 +16,7 @@ import bench
 dev = torch.device("cuda", 0)
 POP = int(os.environ.get("POP", "1000000"))
 forest, Xd, yd, X, y = bench.sr_inputs(0, POP, dev)
-stats = torch.zeros(8, dtype=torch.int64, device=dev)
+stats = torch.zeros(16, dtype=torch.int64, device=dev)
 for _ in range(3):
     forest.SR_fitness(Xd, yd)
 torch.cuda.synchronize()
@@ -26,11 +26,12 @@ for _ in range(reps):
     forest.SR_fitness(Xd, yd)
 torch.cuda.synchronize()
 _lib.lib.evogp_hip_debug_set_stats(None)
-first, comp, grab, asm, trees, batches, ticks, waves = stats.cpu().tolist()
+first, comp, grab, asm, trees, batches, ticks, waves, cpc, plan = stats.cpu().tolist()[:10]
 if waves == 0:
     print(json.dumps({"error": "no counters: the library was not built with -DEVOGP_FUSED_STATS (or the call did not take the fused kernel)"}))
     sys.exit(0)
 print(json.dumps({"pop": POP, "waves_per_launch": waves / reps, "trees_per_wave": trees / waves, "batches_per_wave": batches / waves,
                   "clocks_per_wave": ticks / waves, "frac_first_nodes": first / ticks, "frac_compile": comp / ticks, "frac_grab_wait": grab / ticks,
                   "frac_asm": asm / ticks, "frac_outside": 1 - (first + comp + grab + asm) / ticks,
+                  "clocks_per_batch": {"args_copy": cpc / batches, "plan_first_pass": plan / batches, "first_nodes_all": first / batches, "asm": asm / batches, "all": ticks / batches},
                   "clocks_per_tree": {"first_nodes": first / trees, "compile": comp / trees, "grab": grab / trees, "asm": asm / trees, "all": ticks / trees}}))

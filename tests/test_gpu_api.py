@@ -182,16 +182,10 @@ def test_program_record_buffer_is_capped_and_released():
     y = (X[:, 0] - X[:, 1] * X[:, 2]).unsqueeze(1)
     evogp_amd.release_workspaces()
     assert evogp_amd.program_buffer_bytes() == 0 and evogp_amd.record_ring_bytes() == 0
-    # with the function mask of its descriptor the forest's call is ONE kernel whose waves keep their records in rings: no
-    # population-sized buffer, a fixed size per stream (+ one spare per device)
-    masked = f.SR_fitness(X, y)
-    cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    ring = cus * 16 * 2 * 8 * 256
-    assert evogp_amd.program_buffer_bytes() == 0 and evogp_amd.record_ring_bytes() in (ring, 2 * ring), (evogp_amd.record_ring_bytes(), ring)
-    # the same trees without a mask (a forest built from raw tensors) take the two-kernel path and its record buffer
-    f = Forest(f.input_len, f.output_len, f.batch_node_value, f.batch_node_type, f.batch_subtree_size)
     a = f.SR_fitness(X, y)
-    assert torch.equal(a.view(torch.int32), masked.view(torch.int32))
+    # (an eager call also leaves ONE record ring behind for calls that arrive inside a graph capture: include/evogp_hip.h)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    assert evogp_amd.record_ring_bytes() in (0, cus * 16 * 2 * 16 * 256), evogp_amd.record_ring_bytes()
     law = (pop * 256 + 4095) // 4096 * 4096 * max(2, (64 + 2 + 30) // 31)      # include/evogp_hip.h: three arrays of records at gp_len 64
     held = evogp_amd.program_buffer_bytes()
     assert law <= held <= law + law // 8 + 8 * 256, (held, law)

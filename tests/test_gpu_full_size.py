@@ -1,0 +1,152 @@
+"""GPU: BASELINE.json's configurations at their FULL sizes, through properties that do not depend on the size plus a sample against
+the oracle (VERDICT r03 "missing" #2 and #3):
+
+  * configs[3] — classifier trees, pop 200 000, 10 outputs, max_tree_len 128, sklearn's digits shape (1797 rows x 64 features:
+    four LDS pieces per fitness pass): the fused arg-max count of the whole population equals that of its two halves, and a
+    2 000-tree sample equals torch's argmax(clip(softmax)) count on the oracle's outputs;
+  * configs[4] — policy trees, pop 50 000, 17 observations, 6 actions, max_tree_len 256, 1000 steps per episode: the rollout of
+    the whole population (prepared forward pass inside a replayed HIP graph) against the oracle's loop on a sample of trees;
+  * the reference's own SR script shape (example/uci_sr.py:45-75): max_tree_len 512, max_layer_cnt 9, 10 000 constants in [-5, 5],
+    functions + - * / sin cos tan, layer_leaf_prob 0.3, pop 100 000 x 1024 rows: a 5 000-tree sample against the oracle, the
+    population against its halves."""
+import numpy as np
+import pytest
+
+from helpers import ARITH, PAPER7, assert_close_classes, c2_dataset, depth2leaf, per_tree_tolerance, roulette_uniform, torch_rule_counts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import gpu_capi
+
+    return gpu_capi
+
+
+def test_configs3_classifier_population_at_full_size(g, oracle):
+    rng = np.random.default_rng(3)
+    pop, L, var_len, out_len, D = 200_000, 128, 64, 10, 1797
+    f = g.generate(pop, L, var_len, out_len, 0.5, 0.5, [7, 0], depth2leaf(6), roulette_uniform(ARITH), [-1.0, 0.0, 1.0])
+    try:
+        from sklearn.datasets import load_digits
+
+        d = load_digits()
+        X, labels = d.data.astype(np.float32), d.target.astype(np.int32)
+    except Exception:  # (the shape is what counts)
+        X, labels = rng.integers(0, 17, (D, var_len)).astype(np.float32), rng.integers(0, out_len, D).astype(np.int32)
+    assert X.shape == (D, var_len)
+    full = g.batch_argmax_count(*f, X, labels, out_len)
+    assert full.min() >= 0 and full.max() <= D
+    h = pop // 2
+    halves = np.concatenate([g.batch_argmax_count(*(a[:h] for a in f), X, labels, out_len),
+                             g.batch_argmax_count(*(a[h:] for a in f), X, labels, out_len)])
+    assert np.array_equal(full, halves), (np.flatnonzero(full != halves)[:5], "the work distribution shows in the counts")
+    pick = np.sort(rng.choice(pop, 2000, replace=False))
+    sub = tuple(a[pick] for a in f)
+    want = torch_rule_counts(oracle.batch_evaluate(*sub, X, out_len), labels)
+    assert np.array_equal(full[pick], want), (np.abs(full[pick] - want).max(), (full[pick] != want).mean())
+    # ... and the same sample as a launch of its own (another number of trees per workgroup, no dynamic tail)
+    assert np.array_equal(g.batch_argmax_count(*sub, X, labels, out_len), want)
+
+
+def test_configs4_policy_rollout_at_full_size(g, oracle):
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.problem import RolloutProblem
+    from evogp_amd.tree import Forest
+
+    rng = np.random.default_rng(4)
+    pop, obs_dim, act_dim, steps = 50_000, 17, 6, 1000
+
+    class Env:   # elementwise (no matrix product): the two sides differ only in the order of two small sums
+        def __init__(self, device=None):
+            self.device, self.obs_dim, self.act_dim = device, obs_dim, act_dim
+            self.x0 = torch.linspace(-1, 1, obs_dim).to(device)
+
+        def reset(self, n):
+            return self.x0[None, :].repeat(n, 1)
+
+        def observe(self, state):
+            return state
+
+        def step(self, state, action):
+            push = torch.cat([action, action, action[:, :obs_dim - 2 * act_dim]], dim=1)
+            nxt = 0.95 * state + 0.1 * push
+            reward = -(nxt * nxt).sum(1) - 0.1 * (action * action).sum(1)
+            return nxt, reward, nxt.abs().amax(1) > 5.0
+
+    cs = np.linspace(-1, 1, 100).astype(np.float32)
+    f = g.generate(pop, 256, obs_dim, act_dim, 0.5, 0.5, [7, 0], depth2leaf(6), roulette_uniform(ARITH), cs)
+    forest = Forest(obs_dim, act_dim, *(torch.from_numpy(a).cuda() for a in f))
+    clamp = lambda a: a.clamp(-1, 1)  # noqa: E731
+    got = RolloutProblem(Env("cuda"), steps, output_transform=clamp, use_graph=True).evaluate(forest).cpu().numpy()
+    assert forest._prepared is not None, "the rollout must run from the operation lists"
+    assert got.shape == (pop,) and np.isfinite(got).all()
+    pick = np.sort(rng.choice(pop, 300, replace=False))
+    sub = tuple(a[pick] for a in f)
+    state = np.tile(np.linspace(-1, 1, obs_dim, dtype=np.float32)[None, :], (len(pick), 1))
+    total = np.zeros(len(pick), np.float32); done = np.zeros(len(pick), bool)
+    for _ in range(steps):
+        with np.errstate(all="ignore"):
+            action = np.clip(oracle.evaluate(*sub, state, act_dim), -1, 1).astype(np.float32)
+            action = np.where(np.isnan(action), np.float32(np.nan), action)
+            push = np.concatenate([action, action, action[:, :obs_dim - 2 * act_dim]], 1)
+            nxt = (np.float32(0.95) * state + np.float32(0.1) * push).astype(np.float32)
+            reward = (-(nxt * nxt).sum(1) - np.float32(0.1) * (action * action).sum(1)).astype(np.float32)
+            now_done = np.abs(nxt).max(1) > 5.0
+            reward = np.nan_to_num(reward, nan=-1e6, posinf=-1e6, neginf=-1e6).astype(np.float32)
+            total = total + np.where(done, np.float32(0), reward)
+            done = done | now_done | ~np.isfinite(nxt).all(1)
+            state = np.where(done[:, None], state, np.nan_to_num(nxt)).astype(np.float32)
+    assert np.allclose(got[pick], total, rtol=5e-4, atol=1e-2), np.abs(got[pick] - total).max()
+    # a sample evaluated as a forest of its own gives the same episodes (per-tree environments: nothing depends on the neighbours)
+    small = Forest(obs_dim, act_dim, *(torch.from_numpy(a).cuda() for a in sub))
+    again = RolloutProblem(Env("cuda"), steps, output_transform=clamp, use_graph=True).evaluate(small).cpu().numpy()
+    assert np.array_equal(again.view(np.uint32), got[pick].view(np.uint32))
+
+
+def uci_sr_forest(g, pop, keys=(42, 0)):
+    """the forest of example/uci_sr.py:45-54 on a 10-variable problem: max_tree_len 512, max_layer_cnt 9, layer_leaf_prob 0.3, seven
+    functions, 10 000 constants drawn from U(-5, 5) (descriptor.py: const_range / sample_cnt)"""
+    d2l = np.array([0.3] * 8 + [1.0] * 2, np.float32)
+    cs = np.random.default_rng(5).uniform(-5, 5, 10_000).astype(np.float32)
+    return g.generate(pop, 512, 10, 1, 0.5, 0.5, list(keys), d2l, roulette_uniform(PAPER7), cs)
+
+
+def test_uci_sr_script_shape_against_the_oracle(g, oracle):
+    rng = np.random.default_rng(6)
+    pop = 100_000
+    f = uci_sr_forest(g, pop)
+    lens = f[2][:, 0]
+    assert lens.max() > 64 and lens.max() <= 511, "the long-row paths are not exercised"
+    X, y = c2_dataset()
+    full = g.sr_fitness(*f, X, y)
+    h = pop // 2
+    halves = np.concatenate([g.sr_fitness(*(a[:h] for a in f), X, y), g.sr_fitness(*(a[h:] for a in f), X, y)])
+    same = (full.view(np.uint32) == halves.view(np.uint32)) | (np.isnan(full) & np.isnan(halves))
+    assert same.all(), (np.flatnonzero(~same)[:5], "the work distribution shows in the fitness words")
+    pick = np.sort(rng.choice(pop, 5000, replace=False))
+    sub = tuple(a[pick] for a in f)
+    # (1) against the register interpreters on the same device (the same math library): the per-row outputs of batch_evaluate, reduced
+    #     in float64, must give the fused fitness to 1e-4 with identical NaN / inf classes -- EVERY tree of the sample
+    pred = g.batch_evaluate(*sub, X, 1)[:, :, 0]
+    with np.errstate(all="ignore"):
+        d = pred - y[:, 0][None, :]
+        ref = (d * d).astype(np.float64).mean(1).astype(np.float32)
+    assert_close_classes(full[pick], ref, 1e-4, what="uci_sr shape: threaded code vs register interpreters")
+    # (2) against the oracle (the host's math library) within every tree's own sensitivity to 3-ulp differences of the library calls.
+    #     tan(tan(x)) next to a pole can move a single row by any amount for a fourth ulp, which the probe of a few seeds does not always
+    #     see: entries beyond their granted tolerance must be rare (1 in 1000), and check (1) holds for them like for all others
+    want, tol, unstable = per_tree_tolerance(oracle, sub, X, y)
+    got = full[pick].astype(np.float64)
+    stable = ~unstable
+    assert unstable.mean() <= 0.1
+    assert np.array_equal(np.isnan(got[stable]), np.isnan(want[stable])) and np.array_equal(np.isinf(got[stable]), np.isinf(want[stable]))
+    fin = stable & np.isfinite(want)
+    beyond = np.abs(got[fin] - want[fin].astype(np.float64)) > tol[fin]
+    assert beyond.mean() <= 1e-3, (int(beyond.sum()), int(fin.sum()))

@@ -473,6 +473,86 @@ def test_sr_fitness_repeated_calls_streams_and_graph_replay(g, oracle, rng):
     assert_close_classes(out.cpu().numpy(), want, RTOL_ARITH, 0.0, "after capture")
 
 
+def test_graph_replay_survives_a_later_call_that_grows_the_record_buffer(g, oracle, rng):
+    """A captured tree_SR_fitness keeps pointing at the engine's record memory.  A later eager call with a population a hundred
+    times as large must not free or overwrite what the graph reads (sr_tc.hip: the buffer a capture used is left to the graphs, the
+    eager call takes a fresh one; a call that cannot get records inside a capture runs on the ring-based kernel): replays before
+    and after the large call, and interleaved with eager calls of the small population, give the oracle's values."""
+    import torch
+
+    import evogp_amd
+
+    rou, d2l = roulette_uniform(ARITH), depth2leaf(6)
+    v, t, s = g.generate(3000, 64, 4, 1, 0.5, 0.3, [15, 16], d2l, rou, CS3)
+    V, T, S = g.generate(300_000, 64, 4, 1, 0.5, 0.3, [17, 18], d2l, rou, CS3)
+    X = rng.standard_normal((1024, 4)).astype(np.float32)
+    y = rng.standard_normal((1024, 1)).astype(np.float32)
+    want = oracle.sr_fitness(v, t, s, X, y)
+    sample = rng.choice(300_000, 2000, replace=False)
+    want_big = oracle.sr_fitness(V[sample], T[sample], S[sample], X, y)
+    small = [g.dev(v, np.float32), g.dev(t, np.int16), g.dev(s, np.int16), g.dev(X, np.float32), g.dev(y, np.float32)]
+    big = [g.dev(V, np.float32), g.dev(T, np.int16), g.dev(S, np.int16), small[3], small[4]]
+
+    def call(args, pop, out, stream):
+        rc = g.L.evogp_hip_sr_fitness(pop, 1024, 64, 4, 1, 1, *[x.data_ptr() for x in args], out.data_ptr(), 0, stream.cuda_stream)
+        assert rc == 0, g.L.evogp_hip_error_string(rc)
+
+    evogp_amd.release_workspaces()
+    main = torch.cuda.current_stream()
+    gout = torch.full((3000,), 777.0, dtype=torch.float32, device=g.DEV)
+    cap = torch.cuda.Stream()
+    cap.wait_stream(main)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap):
+        call(small, 3000, gout, cap)           # warm-up outside the capture (a stream's first call allocates its scratch block)
+        cap.synchronize()
+        with torch.cuda.graph(graph, stream=cap):
+            call(small, 3000, gout, torch.cuda.current_stream())
+    gout.fill_(555.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_close_classes(gout.cpu().numpy(), want, RTOL_ARITH, 0.0, "replay before the large call")
+    bout = torch.full((300_000,), 777.0, dtype=torch.float32, device=g.DEV)
+    call(big, 300_000, bout, main)           # grows the record memory a hundred times
+    gout.fill_(555.0)
+    graph.replay()                          # ... while this one still reads the old
+    eout = torch.full((3000,), 777.0, dtype=torch.float32, device=g.DEV)
+    call(small, 3000, eout, main)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_close_classes(gout.cpu().numpy(), want, RTOL_ARITH, 0.0, "replay after the large call")
+    assert_close_classes(eout.cpu().numpy(), want, RTOL_ARITH, 0.0, "eager call between replays")
+    assert_close_classes(bout.cpu().numpy()[sample], want_big, RTOL_ARITH, 0.0, "the large call")
+    del graph
+    # a capture that needs MORE record memory than exists cannot allocate: it runs on the ring-based kernel (records in L2), whose
+    # ring the eager warm-up left behind
+    evogp_amd.release_workspaces()
+    main = torch.cuda.current_stream()
+    eout = torch.full((3000,), 777.0, dtype=torch.float32, device=g.DEV)
+    call(small, 3000, eout, main)
+    torch.cuda.synchronize()
+    held = evogp_amd.program_buffer_bytes()
+    bout = torch.full((300_000,), 777.0, dtype=torch.float32, device=g.DEV)
+    cap = torch.cuda.Stream()
+    cap.wait_stream(main)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap):
+        call(small, 3000, eout, cap)           # (the stream's scratch block)
+        cap.synchronize()
+        with torch.cuda.graph(graph, stream=cap):
+            call(big, 300_000, bout, torch.cuda.current_stream())
+    assert evogp_amd.program_buffer_bytes() == held, "the capture allocated record memory"
+    for i in range(2):
+        bout.fill_(555.0)
+        graph.replay()
+        call(small, 3000, eout, main)
+        torch.cuda.synchronize()
+        assert_close_classes(bout.cpu().numpy()[sample], want_big, RTOL_ARITH, 0.0, f"large call captured, replay {i}")
+        assert_close_classes(eout.cpu().numpy(), want, RTOL_ARITH, 0.0, "eager call next to it")
+    del graph
+    evogp_amd.release_workspaces()
+
+
 @pytest.mark.parametrize("D", [1, 300])
 def test_sr_fitness_division_modes_on_special_operands(g, oracle, D):
     """Every ordered pair of special operands through `x_i / x_j` in the threaded-code path, in the three division modes
