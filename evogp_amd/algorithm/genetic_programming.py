@@ -57,8 +57,12 @@ class GeneticProgramming:
         if self.enable_pareto_front:
             self.pareto_front.update(fitness, self.forest)
         if self._native_default_ok():
-            return self._native_default_step(fitness)
-        elite_indices, survivor_indices = self.selection(self.forest, fitness)
+            nxt = self._native_default_step(fitness)
+            if nxt is not None:
+                return nxt
+            # (a selection whose lists the fused pass cannot take -- nothing but elites, no parents: the composed operators below)
+        lists = self.__dict__.pop("_replay_lists", None)   # (the selection was already drawn by the fused pass that handed back)
+        elite_indices, survivor_indices = lists if lists is not None else self.selection(self.forest, fitness)
         offspring = self.crossover(forest=self.forest, survivor_indices=survivor_indices,
                                    target_cnt=self.pop_size - elite_indices.shape[0], fitness=fitness)
         offspring = self.mutation(offspring)
@@ -99,8 +103,12 @@ class GeneticProgramming:
         from ..parallel import default_lists
         from .selection import DefaultSelection
 
+        if not fitness.is_cuda or fitness.device != dev:
+            return None   # (a fitness vector on another device: the operators' own torch programs deal with it)
         if type(self.selection) is DefaultSelection:
-            elites, parents = default_lists(fitness.to(torch.float32), *self.selection.counts(pop))
+            if fitness.dtype != torch.float32:
+                return None   # (a cast could merge ties of a float64 fitness: the selection operator ranks what it was given)
+            elites, parents = default_lists(fitness, *self.selection.counts(pop))
         else:
             lists = None
             counter_based = getattr(self.selection, "counter_based", None)
@@ -110,7 +118,12 @@ class GeneticProgramming:
                     self._word_seed = int(torch.randint(0, 2**40, (1,)).item())
                 lists = counter_based(fitness, self._word_seed, getattr(self, "_steps", 0) + 1)
             elites, parents = lists if lists is not None else self.selection(f, fitness)
-            elites, parents = elites.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous()
+            # the same guards DefaultSelection's counts get in _native_default_ok: at least one offspring row, at least one parent, lists
+            # on the forest's device
+            if elites.numel() >= pop or parents.numel() == 0:
+                self._replay_lists = (elites, parents)
+                return None
+            elites, parents = elites.to(device=dev, dtype=torch.int32).contiguous(), parents.to(device=dev, dtype=torch.int32).contiguous()
         n_elite = elites.numel()
         n_new = pop - n_elite
         # no draw at all: the donor kernel and the breeding pass compute the six words of offspring i (and the two generation keys) as

@@ -353,15 +353,18 @@ Tensor select_survivors(const Tensor &fitness, int64_t n_elite, int64_t n_keep) 
     // two workspaces per (device, stream): this call's was zeroed by the previous call's kernel on the same stream
     struct Slot { Tensor ws; int parity = 0; };
     static std::mutex mu;
-    static std::map<std::pair<int, void *>, Slot> slots;
+    // (leaked on purpose: a static container of tensors would be destroyed at process teardown, after the caching allocator)
+    static auto &slots = *new std::map<std::pair<int, void *>, Slot>();
     std::lock_guard<std::mutex> lock(mu);
     Slot &sl = slots[{(int)dev.index(), (void *)stream}];
     if (!sl.ws.defined()) sl.ws = at::zeros({2 * words}, at::TensorOptions().dtype(at::kInt).device(dev));
     int *base = sl.ws.data_ptr<int>();
     int *mine = base + (int64_t)sl.parity * words, *next = base + (int64_t)(1 - sl.parity) * words;
-    sl.parity ^= 1;
-    check_rc(evogp_hip_select_alternating((unsigned)n, (unsigned)n_elite, (unsigned)n_keep, fitness.data_ptr<float>(), order.data_ptr<int>(), mine,
-                                          next, stream), "select_survivors");
+    const int rc = evogp_hip_select_alternating((unsigned)n, (unsigned)n_elite, (unsigned)n_keep, fitness.data_ptr<float>(), order.data_ptr<int>(), mine,
+                                                next, stream);
+    if (rc != EVOGP_OK) sl.ws = Tensor();   // the halves' zero / dirty protocol is unknown after a failed launch: a fresh workspace next time
+    else sl.parity ^= 1;                    // (only a launch that ran has zeroed `next`)
+    check_rc(rc, "select_survivors");
     return order;
 }
 

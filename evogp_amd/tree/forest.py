@@ -103,7 +103,13 @@ class Forest:
 
     def set_compiled_records(self, stamp: int) -> "Forest":
         """remember that the breeding pass compiled exactly these rows (torch.ops.evogp_hip.breed_rows_compiled returned `stamp`):
-        SR_fitness then presents the stamp while the tensors stay untouched, and the engine skips its compiler launch"""
+        SR_fitness then presents the stamp while the tensors stay untouched, and the engine skips its compiler launch.
+
+        "Untouched" is judged by the tensors' data pointers and torch version counters (``_forest_key``).  A write that goes around
+        the counter -- ``tensor.data[...] = x``, a custom op that mutates an input without declaring it -- is NOT seen: the function
+        mask then merely costs a launch (the last follow-up kernel still evaluates every tree), but a stale stamp, with the
+        EVOGP_BREED_COMPILE experiment on, would make the engine evaluate the old programs.  Do not edit a forest through ``.data``;
+        assign the attribute (or index in place) instead."""
         self._records = (int(stamp), self._forest_key()) if stamp else None
         return self
 

@@ -171,7 +171,12 @@ int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, int n_elite,
  * data pointers and version counters).
  * evogp_hip_set_breed_compile: 0 = off (DEFAULT: _compiled then is evogp_hip_breed_lists and returns stamp 0), 1 = one fused
  * kernel, 2 = two-stream pipeline for >= 200 k rows.  Measured on MI355X the compiler's work costs the same time wherever it
- * runs (csrc/sr_tc.hip launch_breed_compiled has the numbers), so nothing is gained yet; environment: EVOGP_BREED_COMPILE. */
+ * runs (csrc/sr_tc.hip launch_breed_compiled has the numbers), so nothing is gained yet; environment: EVOGP_BREED_COMPILE.
+ * Both modes are EXPERIMENTS: mode 2 only takes launches of EVOGP_BREED_COMPILE_PIPE_MIN rows and more (200 000; the variable is read
+ * per call, the mode from the environment once per process), and a suite run with the experiments switched on globally has known
+ * failures (profiles/r03q_pytest_experiments_on.log).  Likewise EVOGP_TC_HINTS=1 (history-driven launch skipping, csrc/sr_tc.hip):
+ * results stay within the 1e-5 contract but are NOT bit-stable from call to call -- the one call that meets stale hints sums a marked
+ * tree in another kernel's order.  Neither is on by default; neither is covered by the bit-reproducibility statements of this header. */
 int evogp_hip_set_breed_compile(int mode);
 int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
                                    const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,

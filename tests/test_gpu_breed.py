@@ -331,6 +331,41 @@ def test_genetic_programming_step_with_tournament_selection_takes_the_fused_path
     assert best[-1] >= best[0] and median[-1] > median[0], (best, median)     # elites keep the best; the tournaments move the population
 
 
+def test_genetic_programming_step_with_lists_the_fused_pass_cannot_take(g):
+    """A user selection may hand back index tensors on the CPU, or a float64 fitness may arrive: the fused step moves the lists to
+    the forest's device, and leaves a fitness vector it would have to cast (ties of a float64 ranking) to the composed operators
+    -- in both cases a valid next generation with the elites copied verbatim."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=3, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5, const_samples=[-1, 0, 1])
+    pop = 3000
+
+    class CpuLists:   # the shape of selection/*.py operators: (elite indices, survivor indices) -- here on the CPU
+        def __call__(self, forest, fitness):
+            order = torch.argsort(fitness, descending=True).cpu()
+            return order[:30], order[:900]
+
+    X = torch.rand(128, 3, device=dev) * 4 - 2
+    y = (X[:, 0] * X[:, 1] - X[:, 2]).unsqueeze(1)
+    for selection, dtype in ((CpuLists(), torch.float32), (DefaultSelection(0.3, elite_rate=0.01), torch.float64)):
+        forest = Forest.random_generate(pop, desc, keys=torch.tensor([5, 6], dtype=torch.uint32, device=dev))
+        algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, desc.update(max_layer_cnt=3)), selection)
+        fit = -forest.SR_fitness(X, y)
+        fit[torch.isnan(fit)] = -torch.inf
+        top = str(forest[int(torch.argmax(fit))])
+        new = algo.step(fit.to(dtype))
+        assert new.pop_size == pop
+        assert top in {str(new[i]) for i in range(30)}
+        sizes = new.batch_subtree_size[:, 0]
+        assert int(sizes.min()) >= 1 and int(sizes.max()) <= 64
+        assert torch.isfinite(new.SR_fitness(X, y)).any()
+
+
 def test_select_survivors_equals_the_sets_of_a_stable_sort(g):
     """csrc/select.hip (exact radix select + compaction in one cooperative launch) against its definition in torch ops
     (evogp_amd.parallel.select_order on the CPU): the n_elite best, then the other survivors, each group by ascending index; ties at
