@@ -199,7 +199,33 @@ void call_scratch_next_is_clean(hipStream_t stream) {
     for (auto &kv : g_scratch[dev]) if (kv.first == stream) kv.second.next_clean = true;
 }
 
+// Calibration reads for the FETCH_SIZE counter (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access
+// pattern"): every lane reads W bytes per load instruction, consecutive lanes consecutive addresses -- W = 2 and 4 are the program
+// compiler's node loads (type / size, value), 16 the wide streaming read the guide calibrated.  scripts/pmc_calibrate.py runs them
+// over a buffer far larger than the Infinity Cache under rocprofv3 --pmc FETCH_SIZE.
+template <int W>
+__global__ __launch_bounds__(256) void calib_read_kernel(const unsigned char *buf, size_t bytes, unsigned *sink) {
+    const size_t n = bytes / W, stride = (size_t)gridDim.x * blockDim.x;
+    unsigned acc = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (W == 2) acc += ((const unsigned short *)buf)[i];
+        else if (W == 4) acc += ((const unsigned *)buf)[i];
+        else { const uint4 v = ((const uint4 *)buf)[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (acc == 0x12345678u) *sink = acc;   // (keeps the loads)
+}
+
 }  // namespace evogp
+
+extern "C" int evogp_hip_debug_calibrate_read(const void *buf, unsigned long long bytes, int width, unsigned *sink, void *stream) {
+    using namespace evogp;
+    const dim3 grid(256 * 16), block(256);
+    if (width == 2) hipLaunchKernelGGL(calib_read_kernel<2>, grid, block, 0, (hipStream_t)stream, (const unsigned char *)buf, (size_t)bytes, sink);
+    else if (width == 4) hipLaunchKernelGGL(calib_read_kernel<4>, grid, block, 0, (hipStream_t)stream, (const unsigned char *)buf, (size_t)bytes, sink);
+    else if (width == 16) hipLaunchKernelGGL(calib_read_kernel<16>, grid, block, 0, (hipStream_t)stream, (const unsigned char *)buf, (size_t)bytes, sink);
+    else return EVOGP_E_BADARG;
+    return (int)hipGetLastError();
+}
 
 // Debugging aid (not declared in the header): both call-scratch blocks of `stream` and the index of the current one, copied to the
 // host after a device synchronisation.  host_words: 2 * 2304 words.

@@ -97,6 +97,7 @@ L2WARM = True    # vector loads that pull the next batch's records into L2 (EVOG
 KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_TC_GEN_KWARM_LINES)
 FUSED_SIZE_OFF, FUSED_LEN_OFF = 96 + 16, 96 + 60   # FusedParams (sr_tc.hip): c.size and c.gp_len behind the 96 bytes of TcParams (static_asserts there)
 TOUCH = True     # fused build: the block's entry touches the rows of the wave's next batch (EVOGP_TC_GEN_TOUCH=0: off)
+TRIGPK = True    # sin / cos / tan over row pairs with packed multiplications and fused multiply-adds (EVOGP_TC_GEN_TRIGPK=0: row by row)
 RECGLC = False   # fused build: the record loads carry glc (EVOGP_TC_GEN_RECGLC=1) instead of one s_dcache_inv per batch
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
 
@@ -1547,63 +1548,152 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
         a(f"s_mov_b32 s{T1}, 0x48000000")             # 2^17
         a(f"v_cmp_le_f32 vcc, s{T1}, v{tx}")
         a(f"s_cbranch_vccnz {lab(f'triglib_{uop}')}")   # some row needs the library's Payne-Hanek reduction: the whole function, row by row (below)
-        for k in range(K):
-            x, res = T + k, Q + k
-            a(f"s_mov_b32 s{T1}, 0x3f22f983")         # 2 / pi
-            a(f"v_mul_f32_e64 v{tn}, |v{x}|, s{T1}")
-            a(f"v_rndne_f32 v{tn}, v{tn}")
-            a(f"s_mov_b32 s{T1}, 0xbfc90fda")         # -pi/2, high part
-            a(f"v_cvt_i32_f32 v{tu}, v{tn}")          # quadrant
-            a(f"v_fma_f32 v{tr}, v{tn}, s{T1}, |v{x}|")
-            a(f"v_fmamk_f32 v{tr}, v{tn}, 0xb3a22168, v{tr}")
-            a(f"v_fmamk_f32 v{tr}, v{tn}, 0xa7c234c4, v{tr}")
-            a(f"v_mul_f32 v{ts2}, v{tr}, v{tr}")
-            if uop in ("sin", "cos"):
-                a(f"v_mov_b32 v{tp}, 0x3c0881c4")
-                a(f"v_fmac_f32 v{tp}, 0xb94c1982, v{ts2}")
-                a(f"v_fmaak_f32 v{tp}, v{ts2}, v{tp}, 0xbe2aaa9d")
-                a(f"v_mul_f32 v{tp}, v{ts2}, v{tp}")
-                a(f"v_fmac_f32 v{tr}, v{tr}, v{tp}")                 # sin(r)
-                a(f"v_mov_b32 v{tq}, 0xbab64f3b")
-                a(f"v_fmac_f32 v{tq}, 0x37d75334, v{ts2}")
-                a(f"v_fmaak_f32 v{tq}, v{ts2}, v{tq}, 0x3d2aabf7")
-                a(f"v_fmaak_f32 v{tq}, v{ts2}, v{tq}, 0xbf000004")
-                a(f"v_fma_f32 v{tq}, v{ts2}, v{tq}, 1.0")            # cos(r)
-                a(f"v_and_b32 v{tp}, 1, v{tu}")
-                a(f"v_lshlrev_b32 v{tu}, 30, v{tu}")
-                a(f"v_cmp_eq_u32 vcc, 0, v{tp}")
-                a(f"v_and_b32 v{tu}, 0x80000000, v{tu}")             # sign from bit 1 of the quadrant
-                if uop == "sin":
-                    a(f"v_and_b32 v{tp}, 0x80000000, v{x}")          # sin is odd: the sign of x
-                    a(f"v_cndmask_b32 v{tq}, v{tq}, v{tr}, vcc")     # even quadrant: sin(r), odd: cos(r)
-                    a(f"v_xor_b32 v{tu}, v{tp}, v{tu}")
-                    a(f"v_xor_b32 v{res}, v{tu}, v{tq}")
+        if TRIGPK and K >= 2:
+            # Row PAIRS through packed instructions: the reduction, the polynomials and tan's correction steps are multiplications and
+            # fused multiply-adds -- v_pk_mul_f32 / v_pk_fma_f32 do two rows for the issue slot of one (the same IEEE operations as the
+            # library's v_fma / v_fmac / v_fmaak / v_fmamk, so the same bits); a constant comes from one SGPR for both halves
+            # (op_sel_hi 0; packed instructions take no literal), an addend constant that meets an SGPR factor is two moves.  Rounding,
+            # conversion, reciprocals and the quadrant logic stay per row.  39 / 35 / 42 instead of 50 / 46 / 54 vector instructions
+            # per row pair of sin / cos / tan.
+            A, B, C, D = 4, 18, 20, 22
+
+            def pk_c(ins, dst, s0, s1, s2, cpos, const, neg=""):
+                """packed instruction with the constant `const` at source position cpos (1 or 2)"""
+                a(f"s_mov_b32 s{T1}, {const}")
+                ops = [f"v[{s0}:{s0 + 1}]" if s0 is not None else None, f"v[{s1}:{s1 + 1}]" if s1 is not None else None,
+                       f"v[{s2}:{s2 + 1}]" if s2 is not None else None]
+                ops[cpos] = f"s[{T1}:{T2}]"
+                ops = [o for o in ops if o is not None]
+                sel = ["1"] * len(ops)
+                sel[cpos] = "0"
+                a(f"{ins} v[{dst}:{dst + 1}], {', '.join(ops)} op_sel_hi:[{','.join(sel)}]{neg}")
+
+            for k in range(0, K, 2):
+                X, E = T + k, Q + k
+                for j in (0, 1):
+                    a(f"v_and_b32 v{A + j}, 0x7fffffff, v{X + j}")
+                pk_c("v_pk_mul_f32", B, A, None, None, 1, "0x3f22f983")           # |x| * 2 / pi
+                for j in (0, 1):
+                    a(f"v_rndne_f32 v{B + j}, v{B + j}")
+                for j in (0, 1):
+                    a(f"v_cvt_i32_f32 v{C + j}, v{B + j}")                          # quadrant
+                pk_c("v_pk_fma_f32", A, B, None, A, 1, "0xbfc90fda")              # r = n * (-pi/2, three parts) + |x|
+                pk_c("v_pk_fma_f32", A, B, None, A, 1, "0xb3a22168")
+                pk_c("v_pk_fma_f32", A, B, None, A, 1, "0xa7c234c4")
+                a(f"v_pk_mul_f32 v[{B}:{B + 1}], v[{A}:{A + 1}], v[{A}:{A + 1}]")    # s2 = r * r
+                if uop in ("sin", "cos"):
+                    for j in (0, 1):
+                        a(f"v_mov_b32 v{D + j}, 0x3c0881c4")
+                    pk_c("v_pk_fma_f32", D, B, None, D, 1, "0xb94c1982")
+                    pk_c("v_pk_fma_f32", D, B, D, None, 2, "0xbe2aaa9d")
+                    a(f"v_pk_mul_f32 v[{D}:{D + 1}], v[{B}:{B + 1}], v[{D}:{D + 1}]")
+                    a(f"v_pk_fma_f32 v[{A}:{A + 1}], v[{A}:{A + 1}], v[{D}:{D + 1}], v[{A}:{A + 1}]")   # sin(r)
+                    for j in (0, 1):
+                        a(f"v_mov_b32 v{E + j}, 0xbab64f3b")
+                    pk_c("v_pk_fma_f32", E, B, None, E, 1, "0x37d75334")
+                    pk_c("v_pk_fma_f32", E, B, E, None, 2, "0x3d2aabf7")
+                    pk_c("v_pk_fma_f32", E, B, E, None, 2, "0xbf000004")
+                    pk_c("v_pk_fma_f32", E, B, E, None, 2, "0x3f800000")          # cos(r)
+                    for j in (0, 1):
+                        tr_, tq_, tu_, x_ = A + j, E + j, C + j, X + j
+                        a(f"v_and_b32 v9, 1, v{tu_}")
+                        a(f"v_lshlrev_b32 v{tu_}, 30, v{tu_}")
+                        a("v_cmp_eq_u32 vcc, 0, v9")
+                        a(f"v_and_b32 v{tu_}, 0x80000000, v{tu_}")               # sign from bit 1 of the quadrant
+                        if uop == "sin":
+                            a(f"v_and_b32 v9, 0x80000000, v{x_}")                # sin is odd: the sign of x
+                            a(f"v_cndmask_b32 v{tq_}, v{tq_}, v{tr_}, vcc")      # even quadrant: sin(r), odd: cos(r)
+                            a(f"v_xor_b32 v{tu_}, v9, v{tu_}")
+                            a(f"v_xor_b32 v{tq_}, v{tu_}, v{tq_}")
+                        else:
+                            a(f"v_cndmask_b32_e64 v{tq_}, -v{tr_}, v{tq_}, vcc")  # even quadrant: cos(r), odd: -sin(r)
+                            a(f"v_xor_b32 v{tq_}, v{tu_}, v{tq_}")
                 else:
-                    a(f"v_cndmask_b32_e64 v{tq}, -v{tr}, v{tq}, vcc")  # even quadrant: cos(r), odd: -sin(r)
-                    a(f"v_xor_b32 v{res}, v{tu}, v{tq}")
-            else:
-                a(f"v_mov_b32 v{tp}, 0xbf039337")
-                a(f"v_fmac_f32 v{tp}, 0x3c971480, v{ts2}")
-                a(f"v_fmaak_f32 v{tp}, v{ts2}, v{tp}, 0x3f93f425")
-                a(f"v_rcp_f32 v{tp}, v{tp}")
-                a(f"v_mov_b32 v{tq}, 0x3ec54587")
-                a(f"v_fmac_f32 v{tq}, 0xbc8cedd3, v{ts2}")
-                a(f"v_and_b32 v{tu}, 1, v{tu}")
-                a(f"v_mul_f32 v{tp}, v{tq}, v{tp}")
-                a(f"v_mul_f32 v{ts2}, v{ts2}, v{tp}")                # z
-                a(f"v_fma_f32 v{tp}, v{ts2}, v{tr}, v{tr}")          # t = tan(r)
-                a(f"v_rcp_f32 v{tq}, v{tp}")
-                a(f"v_sub_f32 v{tn}, v{tp}, v{tr}")
-                a(f"v_fma_f32 v{tr}, v{ts2}, v{tr}, -v{tn}")
-                a(f"v_cmp_eq_u32 vcc, 0, v{tu}")
-                a(f"v_fma_f32 v{ts2}, v{tp}, -v{tq}, 1.0")
-                a(f"v_fma_f32 v{tr}, v{tr}, -v{tq}, v{ts2}")
-                a(f"v_fma_f32 v{tr}, v{tr}, -v{tq}, -v{tq}")         # -cot(r)
-                a(f"v_cndmask_b32 v{tr}, v{tr}, v{tp}, vcc")
-                a(f"v_and_b32 v{tu}, 0x80000000, v{x}")              # tan is odd
-                a(f"v_xor_b32 v{res}, v{tu}, v{tr}")
-            # (the library's final "NaN for a non-finite operand" select is not needed: infinities never get past the
-            # range test above, and a NaN operand makes every step of the sequence NaN)
+                    for j in (0, 1):
+                        a(f"v_mov_b32 v{D + j}, 0xbf039337")
+                    pk_c("v_pk_fma_f32", D, B, None, D, 1, "0x3c971480")
+                    pk_c("v_pk_fma_f32", D, B, D, None, 2, "0x3f93f425")
+                    for j in (0, 1):
+                        a(f"v_rcp_f32 v{D + j}, v{D + j}")
+                    for j in (0, 1):
+                        a(f"v_mov_b32 v{E + j}, 0x3ec54587")
+                    pk_c("v_pk_fma_f32", E, B, None, E, 1, "0xbc8cedd3")
+                    for j in (0, 1):
+                        a(f"v_and_b32 v{C + j}, 1, v{C + j}")
+                    a(f"v_pk_mul_f32 v[{D}:{D + 1}], v[{E}:{E + 1}], v[{D}:{D + 1}]")
+                    a(f"v_pk_mul_f32 v[{B}:{B + 1}], v[{B}:{B + 1}], v[{D}:{D + 1}]")                    # z
+                    a(f"v_pk_fma_f32 v[{D}:{D + 1}], v[{B}:{B + 1}], v[{A}:{A + 1}], v[{A}:{A + 1}]")   # t = tan(r)
+                    for j in (0, 1):
+                        a(f"v_rcp_f32 v{E + j}, v{D + j}")
+                    for j in (0, 1):
+                        a(f"v_sub_f32 v9, v{D + j}, v{A + j}")
+                        a(f"v_fma_f32 v{A + j}, v{B + j}, v{A + j}, -v9")
+                    pk_c("v_pk_fma_f32", B, D, E, None, 2, "0x3f800000", " neg_lo:[0,1,0] neg_hi:[0,1,0]")
+                    a(f"v_pk_fma_f32 v[{A}:{A + 1}], v[{A}:{A + 1}], v[{E}:{E + 1}], v[{B}:{B + 1}] neg_lo:[0,1,0] neg_hi:[0,1,0]")
+                    a(f"v_pk_fma_f32 v[{A}:{A + 1}], v[{A}:{A + 1}], v[{E}:{E + 1}], v[{E}:{E + 1}] neg_lo:[0,1,1] neg_hi:[0,1,1]")   # -cot(r)
+                    for j in (0, 1):
+                        a(f"v_cmp_eq_u32 vcc, 0, v{C + j}")
+                        a(f"v_and_b32 v9, 0x80000000, v{X + j}")                 # tan is odd
+                        a(f"v_cndmask_b32 v{A + j}, v{A + j}, v{D + j}, vcc")
+                        a(f"v_xor_b32 v{E + j}, v9, v{A + j}")
+        else:
+            for k in range(K):
+                x, res = T + k, Q + k
+                a(f"s_mov_b32 s{T1}, 0x3f22f983")         # 2 / pi
+                a(f"v_mul_f32_e64 v{tn}, |v{x}|, s{T1}")
+                a(f"v_rndne_f32 v{tn}, v{tn}")
+                a(f"s_mov_b32 s{T1}, 0xbfc90fda")         # -pi/2, high part
+                a(f"v_cvt_i32_f32 v{tu}, v{tn}")          # quadrant
+                a(f"v_fma_f32 v{tr}, v{tn}, s{T1}, |v{x}|")
+                a(f"v_fmamk_f32 v{tr}, v{tn}, 0xb3a22168, v{tr}")
+                a(f"v_fmamk_f32 v{tr}, v{tn}, 0xa7c234c4, v{tr}")
+                a(f"v_mul_f32 v{ts2}, v{tr}, v{tr}")
+                if uop in ("sin", "cos"):
+                    a(f"v_mov_b32 v{tp}, 0x3c0881c4")
+                    a(f"v_fmac_f32 v{tp}, 0xb94c1982, v{ts2}")
+                    a(f"v_fmaak_f32 v{tp}, v{ts2}, v{tp}, 0xbe2aaa9d")
+                    a(f"v_mul_f32 v{tp}, v{ts2}, v{tp}")
+                    a(f"v_fmac_f32 v{tr}, v{tr}, v{tp}")                 # sin(r)
+                    a(f"v_mov_b32 v{tq}, 0xbab64f3b")
+                    a(f"v_fmac_f32 v{tq}, 0x37d75334, v{ts2}")
+                    a(f"v_fmaak_f32 v{tq}, v{ts2}, v{tq}, 0x3d2aabf7")
+                    a(f"v_fmaak_f32 v{tq}, v{ts2}, v{tq}, 0xbf000004")
+                    a(f"v_fma_f32 v{tq}, v{ts2}, v{tq}, 1.0")            # cos(r)
+                    a(f"v_and_b32 v{tp}, 1, v{tu}")
+                    a(f"v_lshlrev_b32 v{tu}, 30, v{tu}")
+                    a(f"v_cmp_eq_u32 vcc, 0, v{tp}")
+                    a(f"v_and_b32 v{tu}, 0x80000000, v{tu}")             # sign from bit 1 of the quadrant
+                    if uop == "sin":
+                        a(f"v_and_b32 v{tp}, 0x80000000, v{x}")          # sin is odd: the sign of x
+                        a(f"v_cndmask_b32 v{tq}, v{tq}, v{tr}, vcc")     # even quadrant: sin(r), odd: cos(r)
+                        a(f"v_xor_b32 v{tu}, v{tp}, v{tu}")
+                        a(f"v_xor_b32 v{res}, v{tu}, v{tq}")
+                    else:
+                        a(f"v_cndmask_b32_e64 v{tq}, -v{tr}, v{tq}, vcc")  # even quadrant: cos(r), odd: -sin(r)
+                        a(f"v_xor_b32 v{res}, v{tu}, v{tq}")
+                else:
+                    a(f"v_mov_b32 v{tp}, 0xbf039337")
+                    a(f"v_fmac_f32 v{tp}, 0x3c971480, v{ts2}")
+                    a(f"v_fmaak_f32 v{tp}, v{ts2}, v{tp}, 0x3f93f425")
+                    a(f"v_rcp_f32 v{tp}, v{tp}")
+                    a(f"v_mov_b32 v{tq}, 0x3ec54587")
+                    a(f"v_fmac_f32 v{tq}, 0xbc8cedd3, v{ts2}")
+                    a(f"v_and_b32 v{tu}, 1, v{tu}")
+                    a(f"v_mul_f32 v{tp}, v{tq}, v{tp}")
+                    a(f"v_mul_f32 v{ts2}, v{ts2}, v{tp}")                # z
+                    a(f"v_fma_f32 v{tp}, v{ts2}, v{tr}, v{tr}")          # t = tan(r)
+                    a(f"v_rcp_f32 v{tq}, v{tp}")
+                    a(f"v_sub_f32 v{tn}, v{tp}, v{tr}")
+                    a(f"v_fma_f32 v{tr}, v{ts2}, v{tr}, -v{tn}")
+                    a(f"v_cmp_eq_u32 vcc, 0, v{tu}")
+                    a(f"v_fma_f32 v{ts2}, v{tp}, -v{tq}, 1.0")
+                    a(f"v_fma_f32 v{tr}, v{tr}, -v{tq}, v{ts2}")
+                    a(f"v_fma_f32 v{tr}, v{tr}, -v{tq}, -v{tq}")         # -cot(r)
+                    a(f"v_cndmask_b32 v{tr}, v{tr}, v{tp}, vcc")
+                    a(f"v_and_b32 v{tu}, 0x80000000, v{x}")              # tan is odd
+                    a(f"v_xor_b32 v{res}, v{tu}, v{tr}")
+                # (the library's final "NaN for a non-finite operand" select is not needed: infinities never get past the
+                # range test above, and a NaN operand makes every step of the sequence NaN)
         a(f"{lab(f'trigdone_{uop}')}:")
         a(f"s_mov_b32 m0, s{sDST}")
         for k in range(K):
@@ -2167,6 +2257,7 @@ if __name__ == "__main__":
     PKARITH = os.environ.get("EVOGP_TC_GEN_PKARITH", "1") != "0"
     RECGLC = os.environ.get("EVOGP_TC_GEN_RECGLC", "0") == "1"
     TOUCH = os.environ.get("EVOGP_TC_GEN_TOUCH", "1") != "0"
+    TRIGPK = os.environ.get("EVOGP_TC_GEN_TRIGPK", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}

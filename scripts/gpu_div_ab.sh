@@ -7,21 +7,21 @@ TAG=${1:-divab}
 mkdir -p $OUT
 cd $R
 {
-  timeout 600 python scripts/dbg/div_range_ab.py run new
+  timeout 600 python ${AB_SCRIPT:-scripts/dbg/div_range_ab.py} run new
   # environment variants of the same library:  AB_ENV="name:VAR=value name2:VAR=value" bash scripts/gpu_div_ab.sh TAG
   for ev in $AB_ENV; do
     v=${ev%%:*}; kv=${ev#*:}; kv=${kv//,/ }
-    env $kv timeout 600 python scripts/dbg/div_range_ab.py run $v
-    python scripts/dbg/div_range_ab.py cmp new $v
+    env $kv timeout 600 python ${AB_SCRIPT:-scripts/dbg/div_range_ab.py} run $v
+    python ${AB_SCRIPT:-scripts/dbg/div_range_ab.py} cmp new $v
     echo "cmp new $v rc=$?"
   done
   cp evogp_amd/lib/libevogp_hip.so /tmp/keep.so
   for alt in $(ls evogp_amd/lib/libevogp_hip_*.so 2>/dev/null); do
     v=$(basename $alt .so); v=${v#libevogp_hip_}
     cp $alt evogp_amd/lib/libevogp_hip.so
-    timeout 600 python scripts/dbg/div_range_ab.py run $v
+    timeout 600 python ${AB_SCRIPT:-scripts/dbg/div_range_ab.py} run $v
     cp /tmp/keep.so evogp_amd/lib/libevogp_hip.so
-    python scripts/dbg/div_range_ab.py cmp new $v
+    python ${AB_SCRIPT:-scripts/dbg/div_range_ab.py} cmp new $v
     echo "cmp new $v rc=$?"
   done
 } > $OUT/${TAG}_divab.log 2>&1
