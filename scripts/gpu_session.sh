@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-2 GPU session: usage  gpurun --timeout N -- 'bash scripts/gpu_r02.sh TAG step [step ...]'
-# steps: smoke tests bench prof pmc extra:<script.py> ...   Everything lands in gpurun_out/TAG_*.
+# A GPU session in steps: usage  gpurun --timeout N -- 'bash scripts/gpu_session.sh TAG step [step ...]'
+# steps: smoke tests bench prof pmc calib extra:<script.py> ...   Everything lands in gpurun_out/TAG_*.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
-TAG=${1:-r02}; shift
+TAG=${1:-session}; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
@@ -44,6 +44,16 @@ pmc)
   cd $R
   python scripts/pmc_json.py $OUT/${TAG}_05_pmc1.md $OUT/${TAG}_05_pmc2.md $OUT/${TAG}_05_pmc3.md $OUT/${TAG}_05_pmc1.log > $OUT/${TAG}_05_pmc_latest.json 2> $OUT/${TAG}_05_pmc_json.err
   cat $OUT/${TAG}_05_pmc3.md | cut -c1-200 ;;
+calib)      # known-byte-count reads: what does FETCH_SIZE report for 2-, 4- and 16-byte-per-lane loads?
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/calib_$TAG -o pmc -- python $R/scripts/pmc_calibrate.py > $OUT/${TAG}_06_calib.log 2>&1
+  python $R/scripts/rocpd_summary.py $(find $OUT/calib_$TAG -name "*.db" | head -1) 2>&1 | grep -i "counter\|---\|calib_read" > $OUT/${TAG}_06_calib.md
+  rm -rf $OUT/calib_$TAG; cd $R
+  cat $OUT/${TAG}_06_calib.md | cut -c1-200 ;;
+pytest:*)    # pytest:<file or node id> [-k expr]
+  s=${step#pytest:}; n=$(basename ${s%% *} .py)
+  timeout 1800 python -m pytest $s -m gpu -q -x > $OUT/${TAG}_01_pytest_$n.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_01_pytest_$n.log
+  tail -12 $OUT/${TAG}_01_pytest_$n.log | cut -c1-300 ;;
 extra:*)
   s=${step#extra:}; n=$(basename ${s%% *} .py)
   timeout 900 python $s > $OUT/${TAG}_10_$n.log 2>&1; echo "rc=$?" >> $OUT/${TAG}_10_$n.log; tail -25 $OUT/${TAG}_10_$n.log | cut -c1-300 ;;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the three PMC passes of scripts/gpu_r02.sh (FETCH_SIZE | WRITE_SIZE | SQ counters; bench.py --headline-only, so
+"""Turn the three PMC passes of scripts/gpu_session.sh (FETCH_SIZE | WRITE_SIZE | SQ counters; bench.py --headline-only, so
 every launch of the fitness kernels has the headline's shape) into profiles/pmc_latest.json.  The record carries the hash
 of the kernel sources and the trees per launch: bench.py quotes `traffic` only when both match what it runs.
 
@@ -67,12 +67,17 @@ def main():
         out["correction"] = ("counter values are KB (x 1024); FETCH_SIZE doubled (gfx950 tallies 128-byte requests of 16 B/lane coalesced reads at 64 B; "
                              f"calibration on this kernel: records = pop x 256 B = {pop * 256} B, raw FETCH_SIZE = {f:.0f} B); WRITE_SIZE as reported")
     if comp and "FETCH_SIZE" in t.get(comp, {}) and "WRITE_SIZE" in t[comp] and "sr_tc_kernel_hbm_bytes_per_launch" in out:
-        # the whole fitness call: + the program compiler (its reads are 2- and 4-byte node loads: FETCH_SIZE as reported) -- it reads
-        # the forest and writes the records the interpreter then reads
+        # the whole fitness call: + the program compiler, which reads the forest (2- and 4-byte loads per lane) and writes the records the
+        # interpreter then reads.  Its FETCH_SIZE is doubled too: calibrated in round 4 with reads of a known byte count in exactly these
+        # widths (scripts/pmc_calibrate.py, profiles/r04P_06_calib.md: 2, 4 and 16 bytes per lane over 2 GiB all report 1.0486e6 KB,
+        # exactly one half)
         cf, cw = t[comp]["FETCH_SIZE"][1] * 1024, t[comp]["WRITE_SIZE"][1] * 1024
         out["tc_compile_kernel_fetch_bytes_raw"] = cf
         out["tc_compile_kernel_write_bytes_raw"] = cw
-        out["call_hbm_bytes"] = out["sr_tc_kernel_hbm_bytes_per_launch"] + cf + cw
+        out["tc_compile_kernel_hbm_bytes_per_launch"] = 2 * cf + cw
+        out["call_hbm_bytes"] = out["sr_tc_kernel_hbm_bytes_per_launch"] + 2 * cf + cw
+        out["correction"] += ("; the compiler's FETCH_SIZE doubled as well (calibrated: 2-, 4- and 16-byte-per-lane reads of 2 GiB each report exactly "
+                              "half, profiles/r04P_06_calib.md)")
     if interp and "SQ_WAVE_CYCLES" in t[interp]:
         c = {k: v[1] * inst for k, v in t[interp].items()}
         wc = c["SQ_WAVE_CYCLES"]
