@@ -1,7 +1,7 @@
 // breed_group.hpp — the four-rows-per-wave breeding pass (breed.hip) as a body with a hook behind every chunk of 64 rows, so
 // that a second translation unit can instantiate it with work of its own on the rows just written: sr_tc.hip compiles them
 // into the program records of the NEXT fitness call while the rows are in the cache and the breeding pass — bound by memory
-// latency — leaves the vector unit idle.
+// latency — leaves the vector unit idle (docs/DESIGN_history_r01_r03.md section 3.5a).
 #pragma once
 #include "replace_row.hpp"
 #include <hip/hip_runtime.h>

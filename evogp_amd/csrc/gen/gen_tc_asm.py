@@ -2,7 +2,7 @@
 """Generate tc_interp_k<K>.inc: the threaded-code SR-fitness interpreter for gfx950.
 
 Why it looks the way it does — measured on MI355X (scripts/ubench/*.hip, profiles/*ubench*.log; PMC counters in profiles/;
-DESIGN.md section 3.1 has the numbers):
+DESIGN.md section 3.1 and docs/DESIGN_history_r01_r03.md have the numbers):
 
   * a tree interpreter on this chip ends up bound by VALU issue (the division's dependent operations above all) once the
     per-instruction overheads are gone: a computed jump costs a wave ~50 clocks, a v_readlane 8-12 VALU clocks, one
@@ -2263,7 +2263,7 @@ if __name__ == "__main__":
     table = {}
     # (K = 16 -- tiles of 1024 rows, 248 VGPRs, two waves per SIMD, half the dispatches and scalar instructions per row --
     # generates and runs, fitness words identical, but is 7 % SLOWER at 1 M trees, with the division's row pairs abreast or not:
-    # profiles/r03M_div_range_ab.log; DESIGN.md section 3.1d.  Not built.)
+    # profiles/r03M_div_range_ab.log; docs/DESIGN_history_r01_r03.md section 3.1d.  Not built.)
     for K, depth in ((8, 9), (4, 15), (1, 44)):
         with open(f"{outdir}/tc_interp_k{K}.inc", "w") as f:
             for fast, tag in ((0, "ieee"), (1, "fast"), (2, "short")):  # division: IEEE / no range scaling / one correction

@@ -290,6 +290,8 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
  * reused by every later call on that device and invisible to the caller's allocator.  Size law:
  *     bytes = ceil(pop_size * 256 / 4096) * 4096 * max(2, ceil((gp_len + 2) / 31))    (+ 1/8 slack when it grows)
  * i.e. 768 MB for 1 M trees of gp_len 64 (three arrays of records; two up to gp_len 60), 8.7 GB for 1 M trees of gp_len 1024.
+ * A single-output forest of gp_len <= 64 whose function mask (evogp_hip_sr_fitness_hinted) holds no unary function has programs of at
+ * most 32 words: ONE array, 256 MB at 1 M trees (round 4).
  *   evogp_hip_set_program_buffer_limit  caps the buffer (default 16 GiB): a call that would need more runs on the register
  *                                       interpreters instead (same results, 3-6x slower); 0 disables the compiled path.
  *   evogp_hip_program_buffer_bytes      bytes currently held on the current device.
@@ -347,7 +349,7 @@ const char *evogp_hip_error_string(int code);
  *                   div_faithful.hip), where it is the neighbouring float.  Fitness vectors of 200 k trees x 1024 rows
  *                   were bit-identical to the IEEE mode (scripts/div_modes.py).  A block of 64 lanes x K rows whose operands
  *                   all lie in [2^-46, 2^46] -- where the range scaling does nothing -- runs the same four operations
- *                   without it (same quotients, bit for bit).
+ *                   without it (same quotients, bit for bit; docs/DESIGN_history_r01_r03.md section 3.1d).
  *   EVOGP_DIV_IEEE  every quotient is the correctly rounded IEEE-754 quotient, as the CPU oracle computes it (+45 % time).
  *   EVOGP_DIV_FAST  as SHORT, but a block with an operand outside [2^-46, 2^46] takes rows without range scaling:
  *                   |b| > 2^126 gives 0 and |a/b| >= 2^128 gives NaN instead of inf (-2 % time against SHORT).

@@ -186,9 +186,15 @@ def test_program_record_buffer_is_capped_and_released():
     # (an eager call also leaves ONE record ring behind for calls that arrive inside a graph capture: include/evogp_hip.h)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     assert evogp_amd.record_ring_bytes() in (0, cus * 16 * 2 * 16 * 256), evogp_amd.record_ring_bytes()
-    law = (pop * 256 + 4095) // 4096 * 4096 * max(2, (64 + 2 + 30) // 31)      # include/evogp_hip.h: three arrays of records at gp_len 64
+    array = (pop * 256 + 4095) // 4096 * 4096
+    law = array                       # include/evogp_hip.h: ONE array of records for a forest whose function mask holds no unary function
     held = evogp_amd.program_buffer_bytes()
     assert law <= held <= law + law // 8 + 8 * 256, (held, law)
+    # the same trees without a mask (a forest built from raw tensors): programs may have up to 64 words, three arrays at gp_len 64
+    plain = Forest(f.input_len, f.output_len, f.batch_node_value, f.batch_node_type, f.batch_subtree_size)
+    assert torch.equal(plain.SR_fitness(X, y).view(torch.int32), a.view(torch.int32))
+    law3 = array * max(2, (64 + 2 + 30) // 31)
+    assert law3 <= evogp_amd.program_buffer_bytes() <= law3 + law3 // 8 + 8 * 256, (evogp_amd.program_buffer_bytes(), law3)
     evogp_amd.release_workspaces()
     assert evogp_amd.program_buffer_bytes() == 0 and evogp_amd.record_ring_bytes() == 0
     try:

@@ -217,7 +217,7 @@ def test_forest_function_mask_follows_the_trees():
 
 
 def test_interpreter_generator_switches_still_generate():
-    """gen/gen_tc_asm.py is the source of the interpreter; its A/B switches (scripts/build_variant.sh) must keep
+    """gen/gen_tc_asm.py is the source of the interpreter; its A/B switches (docs/DESIGN_history_r01_r03.md section 3.1d, scripts/build_variant.sh) must keep
     producing a program for every build (K = 8, 4, 1; the three division modes), with the per-handler instruction counts bench.py
     reads.  (Assembling is the build's job: a handler that outgrows its 256-byte slot fails there.)"""
     import importlib.util
