@@ -137,7 +137,8 @@ def test_uci_sr_script_shape_against_the_oracle(g, oracle):
     pred = g.batch_evaluate(*sub, X, 1)[:, :, 0]
     with np.errstate(all="ignore"):
         d = pred - y[:, 0][None, :]
-        ref = (d * d).astype(np.float64).mean(1).astype(np.float32)
+        tot = (d * d).astype(np.float64).sum(1)
+        ref = np.where(tot > np.finfo(np.float32).max, np.inf, tot / X.shape[0]).astype(np.float32)
     assert_close_classes(full[pick], ref, 1e-4, what="uci_sr shape: threaded code vs register interpreters")
     # (2) against the oracle (the host's math library) within every tree's own sensitivity to 3-ulp differences of the library calls.
     #     tan(tan(x)) next to a pole can move a single row by any amount for a fourth ulp, which the probe of a few seeds does not always
@@ -150,3 +151,61 @@ def test_uci_sr_script_shape_against_the_oracle(g, oracle):
     fin = stable & np.isfinite(want)
     beyond = np.abs(got[fin] - want[fin].astype(np.float64)) > tol[fin]
     assert beyond.mean() <= 1e-3, (int(beyond.sum()), int(fin.sum()))
+
+
+def test_evolved_uci_sr_population_stays_in_the_threaded_code(g, oracle):
+    """30 generations of example/uci_sr.py's own operators (DefaultCrossover, DefaultMutation(0.1, max_layer_cnt 4), TournamentSelection(20,
+    0.5, 0.1)) on a population of 6 000 trees with max_tree_len 512: the rows fill up, 40 % of the trees need more operand-stack entries
+    than the interpreter has in its own evaluation order, some evaluate sin / cos / tan of 2^17 and more.  Round 3 left half of such a
+    population to the scratch-stack register kernel (172 ms per call at 100 k trees); now (compile_general's reordering pass, the
+    library's whole trigonometric functions inside the threaded code) at most 1 % may be left, and every fitness word must be what the
+    register interpreters return for the tree (batch_evaluate: the same math library, reduced in float64) -- and the oracle's within the
+    trees' own sensitivity for all but 1 in 200."""
+    import ctypes
+
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd import _lib
+    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, GeneticProgramming
+    from evogp_amd.algorithm.selection import TournamentSelection
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(11)
+    pop = 6000
+    desc = GenerateDescriptor(max_tree_len=512, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/", "sin", "cos", "tan"],
+                              max_layer_cnt=9, const_range=[-5, 5], sample_cnt=10000, layer_leaf_prob=0.3)
+    X, y = c2_dataset()
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    algo = GeneticProgramming(Forest.random_generate(pop, desc, keys=torch.tensor([42, 0], dtype=torch.uint32, device=dev)),
+                              DefaultCrossover(), DefaultMutation(0.1, desc.update(max_layer_cnt=4)), TournamentSelection(20, 0.5, 0.1))
+    neg = torch.full((pop,), float("-inf"), device=dev)
+    for _ in range(30):
+        fit = -algo.forest.SR_fitness(Xd, yd)
+        algo.step(torch.where(torch.isnan(fit), neg, fit))
+    f = algo.forest
+    trees = (f.batch_node_value.cpu().numpy(), f.batch_node_type.cpu().numpy(), f.batch_subtree_size.cpu().numpy())
+    lens = trees[2][:, 0]
+    assert lens.mean() > 100 and lens.max() > 400, (lens.mean(), lens.max(), "the population did not grow: not the evolved case")
+    _lib.check(_lib.lib.evogp_hip_debug_profile(2), "profile")          # the call stops behind the threaded code: marked trees keep their sentinel
+    words = f.SR_fitness(Xd, yd).view(torch.int32)
+    _lib.check(_lib.lib.evogp_hip_debug_profile(0), "profile")
+    left = ((words == 0x7FC0FEED) | (words == 0x7FC0BEEF) | (words == 0x7FC0DEED)).float().mean().item()
+    assert left <= 0.01, f"{left:.3f} of the evolved trees were left to the register kernels"
+    got = g.sr_fitness(*trees, X, y)
+    assert np.array_equal(got.view(np.uint32), f.SR_fitness(Xd, yd).cpu().numpy().view(np.uint32)) or np.allclose(
+        np.nan_to_num(got, nan=-1.0, posinf=-2.0), np.nan_to_num(f.SR_fitness(Xd, yd).cpu().numpy(), nan=-1.0, posinf=-2.0), rtol=1e-6)
+    pred = g.batch_evaluate(*trees, X, 1)[:, :, 0]
+    with np.errstate(all="ignore"):
+        d = pred - y[:, 0][None, :]
+        tot = (d * d).astype(np.float64).sum(1)                  # squares in fp32 (same overflow), sum in fp64 ...
+        ref = np.where(tot > np.finfo(np.float32).max, np.inf, tot / X.shape[0]).astype(np.float32)   # ... which overflows where the kernel's fp32 sum does
+    assert_close_classes(got, ref, 1e-4, what="evolved uci_sr population: threaded code vs register interpreters")
+    pick = np.sort(np.random.default_rng(1).choice(pop, 1500, replace=False))
+    sub = tuple(a[pick] for a in trees)
+    want, tol, unstable = per_tree_tolerance(oracle, sub, X, y)
+    stable = ~unstable
+    fin = stable & np.isfinite(want) & np.isfinite(got[pick])
+    beyond = np.abs(got[pick][fin].astype(np.float64) - want[fin].astype(np.float64)) > tol[fin]
+    assert beyond.mean() <= 5e-3, (int(beyond.sum()), int(fin.sum()))
