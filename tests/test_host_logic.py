@@ -227,7 +227,8 @@ def test_interpreter_generator_switches_still_generate():
     spec = importlib.util.spec_from_file_location("gen_tc_asm_under_test", path)
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
-    defaults = {k: getattr(g, k) for k in ("DIVRANGE", "TRUST", "PKCONST", "PKARITH", "DIVABREAST", "DIVFIX", "EARLYREC", "L2WARM", "KWARM")}
+    defaults = {k: getattr(g, k) for k in ("DIVRANGE", "TRUST", "PKCONST", "PKARITH", "DIVABREAST", "DIVFIX", "EARLYREC", "L2WARM", "KWARM", "TRIGPK",
+                                           "TOUCH", "RECGLC")}
     try:
         for flip in [None] + list(defaults):
             for k, v in defaults.items():
@@ -242,8 +243,13 @@ def test_interpreter_generator_switches_still_generate():
                     h = info["handlers"]
                     assert set(("end", "mul_SS", "divip_SS", "div_VV", "push_c")) <= set(h)
                     assert all(v["valu_clk"] >= v["valu"] for v in h.values())
-                    packed = "v_pk_fma_f32" in text
-                    assert packed == (g.DIVRANGE and fast in (1, 2) and K >= 2), (flip, K, fast)
+                    packed = "v_pk_fma_f32" in text   # the range-tested division rows and (round 4) the sin / cos / tan rows over row pairs
+                    assert packed == ((g.DIVRANGE and fast in (1, 2) and K >= 2) or (g.TRIGPK and K >= 2)), (flip, K, fast)
+                    assert "swap" in h and "Ltc_triglib_sin" in text
+                    if K == 8:   # the build that runs ONE batch per entry and returns (sr_fused_kernel)
+                        fused = g.gen(K, depth, fast=fast, fused=True)
+                        assert "s_endpgm" not in fused and "Ltc_exit_here" in fused and "%[t0n]" in fused
+                        assert ("glc" in fused) == g.RECGLC and ("%[taddr]" in fused.split("asm volatile")[1].split(": [lensn]")[0]) == g.TOUCH
     finally:
         for k, v in defaults.items():
             setattr(g, k, v)
