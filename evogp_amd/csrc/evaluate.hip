@@ -261,6 +261,9 @@ hipError_t launch_eval_marked_general(unsigned pop, unsigned gp_len, unsigned va
     return out_len > 1 ? launch_eval_general<true>(p, 1, stream) : launch_eval_general<false>(p, 1, stream);
 }
 
+hipError_t launch_eval_direct(unsigned pop, unsigned gp_len, unsigned var_len, unsigned out_len, const float *value, const int16_t *type,
+                              const int16_t *size, const float *vars, float *results, hipStream_t stream);
+
 } // namespace evogp
 
 using namespace evogp;
@@ -275,6 +278,11 @@ extern "C" int evogp_hip_evaluate(unsigned pop_size, unsigned gp_len, unsigned v
     hipStream_t stream = (hipStream_t)stream_;
     EvalParams p{value, type, size, variables, results, (int)pop_size, (int)gp_len, (int)var_len, (int)out_len};
     const bool mo = out_len > 1;
+    // multi-output trees: every OUT node at once, one wave per tree (evaluate_prepared.hip eval_direct_kernel; EVOGP_EVAL_DIRECT=0: the
+    // lane-per-tree stack interpreter below)
+    static const bool direct = [] { const char *e = getenv("EVOGP_EVAL_DIRECT"); return !e || atoi(e) != 0; }();
+    if (mo && direct && var_len <= 64 && out_len <= 64)
+        return (int)launch_eval_direct(pop_size, gp_len, var_len, out_len, value, type, size, variables, results, stream);
     if (var_len > 64 || out_len > 32)  // the transposed input rows / accumulators would not fit the wave's LDS budget
         return (int)(mo ? launch_eval_general<true>(p, 0, stream) : launch_eval_general<false>(p, 0, stream));
     return (int)(mo ? launch_eval_lane<true>(p, stream) : launch_eval_lane<false>(p, stream));

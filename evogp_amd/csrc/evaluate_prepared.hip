@@ -146,6 +146,112 @@ __global__ __launch_bounds__(64) void eval_prepared_kernel(PreparedParams p) {
 hipError_t launch_eval_marked_general(unsigned pop, unsigned gp_len, unsigned var_len, unsigned out_len, const float *value,
                                       const int16_t *type, const int16_t *size, const float *vars, float *results, hipStream_t stream);
 
+// ---- the same reading of a multi-output tree WITHOUT a prepared list: tree_evaluate itself (round 4) -------------------------------
+// evogp_hip_evaluate on multi-output trees used to run the stack interpreter of evaluate.hip: one lane per tree, bound by the serial
+// life of the longest tree of a wave -- 39 us for the 50 000 policy trees of BASELINE configs[4], where the prepared pass takes 12
+// but costs 85 us to prepare.  eval_direct_kernel does what eval_prepare_kernel does -- one wave per tree, one node per lane, OUT nodes
+// find their leaf operands through the subtree sizes -- but with the tree in REGISTERS (cross-lane permutes instead of scattered
+// global gathers), evaluates every OUT node at once (lane = node; the tree's input row sits in the lanes of one register) and adds
+// the values to their outputs in execution order (higher node index first, forward.cu:239-240).  Same operations in the same order
+// as the stack interpreter and the prepared pass: the same bits.  Trees of more than 64 nodes, with node types outside the five
+// classes or with subtree sizes that do not describe them are marked for the stack interpreter (launched behind this kernel).
+__global__ __launch_bounds__(256) void eval_direct_kernel(PreparedParams q, const float *value, const int16_t *type, const int16_t *size, int gp_len) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    auto bperm = [](int v, int i) -> int { return __builtin_amdgcn_ds_bpermute(i << 2, v); };
+    const int width = gp_len < 64 ? gp_len : 64;
+    // (the loads of the next tree are issued before this one is evaluated)
+    int n_len = 0, n_ty = T_CONST, n_sz = 1;
+    float n_val = 0.0f, n_var = 0.0f;
+    auto fetch = [&](int t) {
+        n_len = 0; n_ty = T_CONST; n_sz = 1; n_val = 0.0f; n_var = 0.0f;
+        if (t < q.pop) {
+            const size_t row = (size_t)t * gp_len;
+            n_len = (int)size[row];
+            if (lane < width) { n_ty = (int)type[row + lane]; n_val = value[row + lane]; n_sz = (int)size[row + lane]; }
+            if (lane < q.var_len) n_var = q.vars[(size_t)t * q.var_len + lane];
+        }
+    };
+    fetch(wave);
+    for (int t = wave; t < q.pop; t += nwaves) {
+        int len = uni(n_len);
+        const int rty = n_ty, rsz = n_sz;
+        const float rval = n_val, xrow = n_var;
+        fetch(t + nwaves);
+        float *res = q.results + (size_t)t * q.out_len;
+        len = len < 0 ? 0 : (len > gp_len ? gp_len : len);
+        if (len > 64) {   // (rows of up to 1024 nodes exist; the stack interpreter takes them)
+            if (lane == 0) res[0] = bits2f(kSentinelDeepEvalP);
+            continue;
+        }
+        const bool in = lane < len;
+        const int ty = in ? rty : (int)T_CONST, sz = in ? rsz : 1;
+        const float val = in ? rval : 0.0f;
+        const int cls = ty & T_MASK;
+        const int arity = cls <= T_CONST ? 0 : (cls <= T_TFUNC ? cls - 1 : 3);  // any other type takes the ternary path (forward.cu:213-224)
+        bool fallback = __any(in && cls > T_TFUNC) != 0;
+        const int delta = in ? 1 - arity : 0;
+        const int incl = wave_scan_incl(delta);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        const bool bad = len <= 0 || __any(in && tot - (incl - delta) < 1) != 0 || tot != 1;
+        const Decoded d = decode_node(ty, val, true, q.var_len, q.out_len);
+        // the operands: the rightmost leaf of every child subtree (what the subtree passes upward); kind and size travel in one word
+        const int ts = cls | (sz << 8);
+        int ci = lane + 1, sum = 1;
+        bool ok = true;
+        float opnd[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {   // (every lane runs the permutes)
+            const int sc = bperm(ts, ci) >> 8;
+            const int leaf = ci + sc - 1;
+            const int lt = bperm(ts, leaf) & 0xFF;
+            const float lv = bits2f((uint32_t)bperm((int)f2bits(val), leaf));
+            int v = (int)lv;
+            v = v < 0 ? 0 : (v >= q.var_len ? q.var_len - 1 : v);
+            const float xv = bits2f((uint32_t)bperm((int)f2bits(xrow), v));
+            if (in && a < arity && ok) {
+                if (ci >= len || sc < 1 || ci + sc > len || lt > T_CONST) ok = false;
+                else { opnd[a] = lt == T_CONST ? lv : xv; sum += sc; ci += sc; }
+            }
+        }
+        if (__any(in && (!ok || sz != sum))) fallback = true;
+        if (bad || fallback) {   // malformed: a NaN row (the reference asserts); beyond this kernel: the stack interpreter's mark in the first word
+            for (int o = lane; o < q.out_len; o += 64) res[o] = (!bad && o == 0) ? bits2f(kSentinelDeepEvalP) : __builtin_nanf("");
+            continue;
+        }
+        const bool adds = in && arity > 0 && d.pay != kNoOut && d.op != H_UN_ZERO && d.op != H_BIN_ZERO;  // unknown ids add 0
+        float r = 0.0f;
+        if (adds) r = prepared_apply(d.op, opnd[0], opnd[1], opnd[2]);
+        // outs[o] = the sum of its OUT nodes' values in execution order; lane o collects output o
+        float mine = 0.0f;
+        for (int o = 0; o < q.out_len; ++o) {
+            unsigned long long m = __ballot(adds && d.pay == (uint32_t)o);
+            float acc = 0.0f;
+            while (m) {
+                const int hi = 63 - __builtin_clzll(m);
+                m &= ~(1ull << hi);
+                acc += bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(r), hi));
+            }
+            if (lane == o) mine = acc;
+        }
+        if (lane < q.out_len) res[lane] = mine;
+    }
+}
+
+// tree_evaluate for multi-output trees of at most 64 variables and 64 outputs: the direct kernel, then the stack interpreter for what it marked
+hipError_t launch_eval_direct(unsigned pop, unsigned gp_len, unsigned var_len, unsigned out_len, const float *value, const int16_t *type,
+                              const int16_t *size, const float *vars, float *results, hipStream_t stream) {
+    PreparedParams q{nullptr, nullptr, vars, results, (int)pop, (int)var_len, (int)out_len};
+    long blocks = ((long)pop + 3) / 4;
+    const long cap = (long)device_info().num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(eval_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q, value, type, size, (int)gp_len);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_eval_marked_general(pop, gp_len, var_len, out_len, value, type, size, vars, results, stream);
+}
+
 } // namespace evogp
 
 using namespace evogp;
