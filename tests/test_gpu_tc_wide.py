@@ -89,6 +89,56 @@ def test_evolved_long_trees_after_crossover(g, oracle, rng):
     check(g, oracle, f1, X, y, "crossover products, L=128", max_skipped=0.01)
 
 
+# ---- the program compilers: one tree per pass, several trees per pass in batches of 8 ... 64 ------------------------------
+@pytest.mark.parametrize("masked,L,unary", [(False, 64, [NEG, ABS, SQRT, INV]), (True, 64, []), (True, 33, []), (False, 20, [NEG, ABS, SQRT, INV]),
+                                             (False, 64, [SIN, COS, TAN, EXP, LOG, NEG])])
+def test_every_program_compiler_gives_the_same_fitness_words(g, oracle, rng, masked, L, unary):
+    """tc_compile_packed_kernel (several trees per pass, largest first) against tc_compile_kernel (one tree per pass), fitness WORDS:
+    a population whose size is no multiple of any batch, rows without a tree, a wrong subtree size, the generator's "no function"
+    node (unary, id 29: generate.cu:77-84) over trees of every kind, a function the mask does not announce.  `masked`: the forest
+    carries its function mask, so the arithmetic-only instantiation runs (and compiles the id-29 nodes itself).  Function sets that are
+    IEEE-exact on both sides are also held against the oracle."""
+    import torch
+
+    from evogp_amd import _lib
+    from evogp_amd.tree import Forest
+
+    pop, V = 20011, 6
+    funcs = [ADD, SUB, MUL, DIV] + unary
+    v, t, s = oracle.generate(pop, L, V, 1, 0.0, 0.5, [L, 5 + masked], depth2leaf(6 if L > 40 else 5 if L > 30 else 4), roulette_uniform(funcs), CS)
+    v, t, s = v.copy(), t.copy(), s.copy()
+    s[17, 0] = 0; s[18, 0] = -3; s[40000 % pop, 0] = 0          # rows without a tree: NaN
+    r = int(np.nonzero(s[:, 0] >= 5)[0][0]); s[r, 1] += 1        # a subtree size that does not add up: the register kernels
+    wrapped = 0
+    for r in np.nonzero(s[:, 0] < L - 2)[0][100:160]:            # "no function" over the whole tree (some twice), leaves included
+        for _ in range(1 + (r & 1)):
+            n = int(s[r, 0])
+            v[r, 1:n + 1] = v[r, :n].copy(); t[r, 1:n + 1] = t[r, :n].copy(); s[r, 1:n + 1] = s[r, :n].copy()
+            v[r, 0] = 29.0; t[r, 0] = 2; s[r, 0] = n + 1
+            wrapped += 1
+    r = int(np.nonzero((s[:, 0] >= 3) & (t[:, 0] == 3))[0][7]); v[r, 0] = float(MAX)   # not in the mask / a generic stub
+    assert wrapped >= 60
+    X = rng.uniform(-3, 3, (300, V)).astype(np.float32); y = rng.uniform(-3, 3, (300, 1)).astype(np.float32)
+    mask = sum(1 << f for f in funcs) if masked else 0
+    forest = Forest(V, 1, torch.from_numpy(v).to(g.DEV), torch.from_numpy(t).to(g.DEV), torch.from_numpy(s).to(g.DEV), func_mask=mask)
+    Xd, yd = torch.from_numpy(X).to(g.DEV), torch.from_numpy(y).to(g.DEV)
+    words = {}
+    try:
+        for batch in (0, 8, 16, 32, 64, -1):
+            assert _lib.lib.evogp_hip_debug_compile_batch(batch) == 0
+            words[batch] = forest.SR_fitness(Xd, yd).cpu().numpy().view(np.uint32).copy()
+    finally:
+        _lib.lib.evogp_hip_debug_compile_batch(-1)
+    for batch, w in words.items():
+        diff = np.nonzero(w != words[0])[0]
+        assert len(diff) == 0, f"batch {batch}: {len(diff)} fitness words differ from the one-tree compiler's, first tree {diff[:5]}"
+    got = words[-1].view(np.float32)
+    assert np.isnan(got[[17, 18, 40000 % pop]]).all()
+    if SIN not in unary:   # (the library functions are judged against the oracle elsewhere, with their own envelope)
+        keep = np.ones(pop, bool); keep[[17, 18, 40000 % pop]] = False   # (a row without a tree is NaN here; the reference reads what lies there)
+        assert_close_classes(got[keep], oracle.sr_fitness(v, t, s, X, y, True)[keep], RTOL, what=f"packed compilers, masked={masked}")
+
+
 def _leaning_forest(rng, pop, L, var_len, funcs, right_funcs, lean_left=True, max_levels=60):
     """trees that lean to one side: level k is f_k(level k - 1, small) (lean_left) or f_k(small, level k - 1), `small` a function of two
     leaves.  In the interpreter's order -- the LAST operand first -- a left-leaning tree keeps one value per level on the operand
