@@ -20,6 +20,7 @@ sys.argv = [sys.argv[0]]
 import bench
 
 dev = torch.device("cuda", 0)
+torch.manual_seed(int(os.environ.get("SEED", "42")))   # (the algorithm draws its word seed from torch's CPU generator: the trajectory)
 GENS = int(os.environ.get("GENS", "30"))
 POP = int(os.environ.get("POP", "100000"))
 _, Xd, yd, X, y = bench.sr_inputs(0, 1000, dev)
@@ -80,6 +81,19 @@ for g in range(GENS + 1):
               f"{(d[:, 0] > 9).mean():.3f} (max {d[:, 0].max()}), larger-first {(d[:, 1] > 9).mean():.3f} (max {d[:, 1].max()}); "
               f"left among height <= 9: {left[pick][d[:, 0] <= 9].mean() if (d[:, 0] <= 9).any() else float('nan'):.3f}, among height > 9: "
               f"{left[pick][d[:, 0] > 9].mean() if (d[:, 0] > 9).any() else float('nan'):.3f}; len>64 {np.mean(lens > 64):.3f}")
+        w = words.cpu().numpy().view(np.uint32)
+        kinds = {name: int((w == code).sum()) for name, code in (("heavy (compile time)", 0x7FC0FEED), ("general", 0x7FC0BEEF), ("run time", 0x7FC0DEED))}
+        alllen = sz[:, 0]
+        vals = f.batch_node_value.cpu().numpy()
+        trig = ((ty == 2) & (np.arange(ty.shape[1])[None, :] < alllen[:, None])).sum(1)
+        buckets = [(1, 64), (65, 128), (129, 256), (257, 384), (385, 512)]
+        print("   sentinels:", kinds, "| left share by length:", {f"{a}-{b}": (round(float(left[(alllen >= a) & (alllen <= b)].mean()), 3), int(((alllen >= a) & (alllen <= b)).sum()))
+                                                               for a, b in buckets if ((alllen >= a) & (alllen <= b)).any()},
+              f"| unary nodes per tree: left {trig[left].mean() if left.any() else 0:.1f}, taken {trig[~left].mean():.1f}")
+        if g == GENS and os.environ.get("DUMP") and left.any():   # some of the trees that were left, for a look at them on the host
+            rows = np.nonzero(left)[0][:200]
+            np.savez_compressed(os.path.join(ROOT, "gpurun_out", "uci_left.npz"), ty=f.batch_node_type.cpu().numpy()[rows], va=vals[rows], sz=sz[rows],
+                                words=w[rows])
     if g < GENS:
         fit = -algo.forest.SR_fitness(Xd, yd)
         algo.step(torch.where(torch.isnan(fit), neg, fit))

@@ -189,6 +189,51 @@ def test_leaning_trees_deeper_than_the_register_stack_are_reordered(g, oracle, r
         assert h["swap"] == 0, "a right-leaning tree runs in the interpreter's own order"
 
 
+def test_trig_high_on_the_stack_with_huge_operands_is_reordered_instead_of_bailing_out(g, oracle, rng):
+    """sin / cos / tan of operands of 2^17 and more run the device library's whole function in the registers above the operand stack
+    (gen_tc_asm.py triglib_*); a stack of seven and more entries reaches into them and the tree bails out at RUN time to the register
+    kernels (an evolved example/uci_sr.py population: up to 8 % of its trees, more than half of the call's time).  In a forest of long
+    rows the compilers reorder such a tree -- larger subtree first -- although its stack would fit: the trig node then runs low.
+    Trees f_k(.. f_1(trig(x0 * 3e5), small_1) .., small_k), k = 6 .. 8 (natural height 7 .. 9), bare (at most 36 nodes: the one-chunk
+    compiler hands them on) and under 20 right-leaning levels (116 nodes: the staged compiler directly)."""
+    import torch
+
+    from evogp_amd import _lib
+    from evogp_amd.tree import Forest
+
+    L, V, pop = 256, 4, 900
+    v = np.zeros((pop, L), np.float32); t = np.zeros((pop, L), np.int16); s = np.zeros((pop, L), np.int16)
+    for r in range(pop):
+        k, wrap = 6 + r % 3, 20 * ((r // 3) % 2)
+        small = lambda: [(3, float(rng.choice([ADD, SUB, MUL])), 3), (0, float(rng.integers(0, V)), 1), (0, float(rng.integers(0, V)), 1)]
+        nodes = [(2, float([SIN, COS, TAN][r % 3]), 4), (3, float(MUL), 3), (0, 0.0, 1), (1, 3e5, 1)]
+        for _ in range(k):      # left-leaning: the trig node's level runs LAST in the interpreter's order, on top of k values
+            nodes = [(3, float(rng.choice([ADD, SUB, MUL])), len(nodes) + 4)] + nodes + small()
+        for _ in range(wrap):   # right-leaning: adds nodes, no height
+            nodes = [(3, float(rng.choice([ADD, SUB])), len(nodes) + 4)] + small() + nodes
+        assert len(nodes) == 4 + 4 * (k + wrap)
+        for i, (ty, val, sz) in enumerate(nodes):
+            t[r, i], v[r, i], s[r, i] = ty, val, sz
+        assert oracle.validate_tree(t[r], s[r]) == 0
+    X = rng.uniform(-3, 3, (1024, V)).astype(np.float32); y = rng.uniform(-3, 3, (1024, 1)).astype(np.float32)
+    forest = Forest(V, 1, torch.from_numpy(v).to(g.DEV), torch.from_numpy(t).to(g.DEV), torch.from_numpy(s).to(g.DEV))
+    Xd, yd = torch.from_numpy(X).to(g.DEV), torch.from_numpy(y).to(g.DEV)
+    _lib.check(_lib.lib.evogp_hip_debug_profile(2), "profile")          # the call stops behind the threaded code: marked trees keep their sentinel
+    try:
+        words = forest.SR_fitness(Xd, yd).view(torch.int32).cpu().numpy()
+    finally:
+        _lib.check(_lib.lib.evogp_hip_debug_profile(0), "profile")
+    left = (words == 0x7FC0FEED) | (words == 0x7FC0BEEF) | (words == 0x7FC0DEED)
+    assert not left.any(), f"{int(left.sum())} of {pop} trees were left to the register kernels (bare: {int(left[(np.arange(pop) // 3) % 2 == 0].sum())})"
+    got = g.sr_fitness(v, t, s, X, y)
+    be = g.batch_evaluate(v, t, s, X, 1).astype(np.float64)             # the register kernels call the same library
+    with np.errstate(all="ignore"):
+        ref = ((be - y[None, :, :].astype(np.float64)) ** 2).sum(2).mean(1)
+    ok = np.isfinite(ref) & (np.abs(ref) < 1e30)
+    assert ok.mean() > 0.5
+    assert np.allclose(got[ok], ref[ok], rtol=2e-5, atol=1e-30), "threaded code vs the register kernels on the same trees"
+
+
 # ---- the functions behind the generic stubs -------------------------------------------------------------------------------
 @pytest.mark.parametrize("funcs", [[LDIV, ADD, MUL], [MAX, MIN, ADD, SUB], [LT, GT, LE, GE, ADD, MUL], [IF, ADD, SUB, LT], [LINV, INV, ADD, MUL],
                                    EXACT_WIDE], ids=["ldiv", "maxmin", "cmp", "if", "linv", "all-exact"])
