@@ -103,12 +103,16 @@ struct PreparedParams {
     int pop, var_len, out_len;
 };
 
-__device__ inline float prepared_apply(uint32_t op, float a, float b, float c) {
+// (the library functions stay behind a call: inlined, their registers and code would weigh on every caller's arithmetic path)
+__device__ __attribute__((noinline)) float prepared_apply_other(uint32_t op, float a, float b) {
+    if (op >= H_UN) return op_unary<false>(op, a);
+    return op_binary_other<false>(op, a, b);
+}
+__device__ __attribute__((always_inline)) inline float prepared_apply(uint32_t op, float a, float b, float c) {
     if (op >= H_ADD && op <= H_DIV)
         return op == H_ADD ? a + b : op == H_SUB ? a - b : op == H_MUL ? a * b : (b == 0.0f ? __builtin_nanf("") : a / b);  // forward.cu:177-187
     if (op == H_IF) return a > 0.0f ? b : c;
-    if (op >= H_UN) return op_unary<false>(op, a);
-    return op_binary_other<false>(op, a, b);
+    return prepared_apply_other(op, a, b);
 }
 
 __global__ __launch_bounds__(64) void eval_prepared_kernel(PreparedParams p) {
@@ -161,21 +165,23 @@ __global__ __launch_bounds__(256) void eval_direct_kernel(PreparedParams q, cons
     const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
     auto bperm = [](int v, int i) -> int { return __builtin_amdgcn_ds_bpermute(i << 2, v); };
     const int width = gp_len < 64 ? gp_len : 64;
-    // (the loads of the next tree are issued before this one is evaluated)
-    int n_len = 0, n_ty = T_CONST, n_sz = 1;
+    // (the loads of the next tree are issued before this one is evaluated.  Nothing may touch a loaded value before the tree's turn:
+    // the length used to be a load of its own, converted at once -- and the wait for that conversion, loads completing in order,
+    // was a wait for ALL of the next tree's loads in front of the current tree's work: 26 us at the C5 shape instead of 11.  The
+    // length is the subtree size of node 0, lane 0's word.)
+    int n_ty = T_CONST, n_sz = 0;
     float n_val = 0.0f, n_var = 0.0f;
     auto fetch = [&](int t) {
-        n_len = 0; n_ty = T_CONST; n_sz = 1; n_val = 0.0f; n_var = 0.0f;
+        n_ty = T_CONST; n_sz = 0; n_val = 0.0f; n_var = 0.0f;
         if (t < q.pop) {
             const size_t row = (size_t)t * gp_len;
-            n_len = (int)size[row];
             if (lane < width) { n_ty = (int)type[row + lane]; n_val = value[row + lane]; n_sz = (int)size[row + lane]; }
             if (lane < q.var_len) n_var = q.vars[(size_t)t * q.var_len + lane];
         }
     };
     fetch(wave);
     for (int t = wave; t < q.pop; t += nwaves) {
-        int len = uni(n_len);
+        int len = __builtin_amdgcn_readfirstlane(n_sz);
         const int rty = n_ty, rsz = n_sz;
         const float rval = n_val, xrow = n_var;
         fetch(t + nwaves);
@@ -201,8 +207,10 @@ __global__ __launch_bounds__(256) void eval_direct_kernel(PreparedParams q, cons
         int ci = lane + 1, sum = 1;
         bool ok = true;
         float opnd[3] = {0.0f, 0.0f, 0.0f};
+        const int max_arity = __builtin_amdgcn_ballot_w64(in && arity > 2) != 0ull ? 3 : __builtin_amdgcn_ballot_w64(in && arity > 1) != 0ull ? 2 : 1;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {   // (every lane runs the permutes)
+        for (int a = 0; a < 3; ++a) {   // (every lane runs the permutes -- of the operands some node of the tree has)
+            if (a >= max_arity) break;
             const int sc = bperm(ts, ci) >> 8;
             const int leaf = ci + sc - 1;
             const int lt = bperm(ts, leaf) & 0xFF;
@@ -239,6 +247,11 @@ __global__ __launch_bounds__(256) void eval_direct_kernel(PreparedParams q, cons
     }
 }
 
+// (Several trees per pass -- the packed program compiler's scheme, sr_tc.hip -- was built for this kernel in round 4 and taken out
+// again: 29.7 us against 27.6 at the C5 shape, 19 against 9 at 12 500 trees.  A pass of this kernel is a chain of dependent
+// cross-lane steps, ~3 us whatever it holds; sharing passes saves instructions but makes the serial parts -- the plan of a pass, the
+// ordered sums of all its trees' OUT nodes -- longer, and at these sizes the chip is not short of issue slots.  Nodes staged in LDS
+// with every load of a batch requested up front made no difference either: it is not memory latency.)
 // tree_evaluate for multi-output trees of at most 64 variables and 64 outputs: the direct kernel, then the stack interpreter for what it marked
 hipError_t launch_eval_direct(unsigned pop, unsigned gp_len, unsigned var_len, unsigned out_len, const float *value, const int16_t *type,
                               const int16_t *size, const float *vars, float *results, hipStream_t stream) {

@@ -97,7 +97,17 @@ assert L_.evogp_hip_generate(pe, Le, 17, 6, 100, 0.5, 0.5, keys.data_ptr(), d2l6
 obs = torch.randn(pe, 17, device=g.DEV); res = torch.empty(pe, 6, device=g.DEV)
 def evaluate():
     assert L_.evogp_hip_evaluate(pe, Le, 17, 6, ev.data_ptr(), et.data_ptr(), es.data_ptr(), obs.data_ptr(), res.data_ptr(), S()) == 0
-us = timed(evaluate, 50)
+us_eager = timed(evaluate, 50)
+# the same call recorded into a HIP graph, 20 calls per replay: the device's time per call (the eager figure is bound by this script's
+# own ctypes call: ~20 us of Python per call, more than the two kernels take)
+gs = torch.cuda.Stream()
+with torch.cuda.stream(gs):
+    evaluate(); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=gs):
+        for _ in range(20): evaluate()
+us = timed(gr.replay, 20) / 20
+row("tree_evaluate (C5 shape), eager calls from Python", us_eager, 6.0 * es[:, 0].to(torch.int64).sum().item() + 2.0 * pe + 4.0 * pe * 23, f"pop {pe}, L {Le}, in 17, out 6, one policy step; bound by the caller")
 row("tree_evaluate (C5 shape)", us, 6.0 * es[:, 0].to(torch.int64).sum().item() + 2.0 * pe + 4.0 * pe * 23, f"pop {pe}, L {Le}, in 17, out 6, one policy step")
 
 # batch_evaluate at the classifier shape (C4, reduced pop): pop 20k, L 128, in 64, out 10, D 1797

@@ -146,6 +146,31 @@ def test_evaluate_arith_bit_exact(g, oracle, rng, out_len):
     assert np.array_equal(fbits(g.evaluate(*forest, X, out_len)), fbits(oracle.evaluate(*forest, X, out_len)))
 
 
+@pytest.mark.parametrize("pop,L,out_len,var_len,mlc", [(5003, 128, 6, 17, 7), (777, 64, 64, 64, 6), (20001, 64, 3, 5, 6), (9, 16, 2, 3, 3), (1001, 256, 10, 30, 5)])
+def test_evaluate_multi_output_trees_share_the_passes_of_a_wave(g, oracle, rng, pop, L, out_len, var_len, mlc):
+    """tree_evaluate on multi-output trees: several trees per wave pass (evaluate_prepared.hip eval_direct_packed_kernel) -- populations
+    that are no multiple of the batch, as many outputs as accumulator slots (one tree per pass), rows of more than 64 nodes (the
+    stack interpreter takes those trees), rows without a tree, a truncated tree and a subtree size that does not add up."""
+    forest = oracle.generate(pop, L, var_len, out_len, 0.5, 0.5, [pop % 97, L], depth2leaf(mlc), roulette_uniform(ARITH), CS3)
+    v, t, s = (a.copy() for a in forest)
+    bad = []
+    if pop > 100:
+        s[5, 0] = 0; s[pop - 1, 0] = -2; bad += [5, pop - 1]                       # no tree: NaN row
+        t[6, :3] = [3, 0, 0]; s[6, :3] = [3, 1, 1]; v[6, 0] = 1; s[6, 0] = 2; bad.append(6)   # truncated: stack underflow -> NaN row
+        for r in np.flatnonzero(s[:, 0] > 7)[:3]:                                 # sizes that do not describe the tree: the stack interpreter
+            if r not in bad:
+                s[r, 1] += 1
+    X = rng.normal(0, 1, (pop, var_len)).astype(np.float32)
+    got = g.evaluate(v, t, s, X, out_len)
+    want = oracle.evaluate(v, t, s, X, out_len)
+    ok = np.ones(pop, bool); ok[bad] = False   # (malformed trees: NaN here, undefined in the reference)
+    assert np.array_equal(fbits(got[ok]), fbits(want[ok]))
+    if bad:
+        assert np.isnan(got[bad]).all()
+    if L > 64 and mlc > 6:
+        assert (s[:, 0] > 64).sum() > 10, "no tree beyond 64 nodes: the case is not covered"
+
+
 def test_evaluate_each_function_alone(g, oracle, rng):
     """One function at a time (plus + to build trees): tolerances per family."""
     for f in range(29):
