@@ -31,6 +31,16 @@ for gen in range(gens):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
     if gen % 5 == 0 or gen == gens - 1:
         print(f"gen {gen:3d}  mean len {float(sizes.mean()):5.1f}  fitness launch {e0.elapsed_time(e1):.3f} ms  generation {dt:.3f} ms  best {float(f.max()):.5g}", flush=True)
+# the share of the evolved population the threaded code leaves to the register kernels (the call stops behind it: sentinels stay)
+import ctypes
+from evogp_amd import _lib
+_lib.check(_lib.lib.evogp_hip_debug_profile(2), "profile")
+words = old.SR_fitness(X, y).view(torch.int32)
+st = (ctypes.c_float * 3)(); nc = ctypes.c_int(0)
+_lib.check(_lib.lib.evogp_hip_debug_profile_read(st, ctypes.byref(nc)), "profile read")
+_lib.check(_lib.lib.evogp_hip_debug_profile(0), "profile")
+left = ((words == 0x7FC0FEED) | (words == 0x7FC0BEEF) | (words == 0x7FC0DEED)).float().mean().item()
+print(f"last population: {left:.4%} of the trees left to the register kernels; compilers {st[0] * 1e3:.0f} us, interpreter {st[1] * 1e3:.0f} us")
 best = int(torch.argmax(f))
 out = old[best:best + 1].batch_forward(X)[0, :, 0]
 print("best tree:", old[best], " fitness", float(fit[best]), " recomputed", float(((out - y[:, 0]) ** 2).mean()))
