@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # EVOGP_HIP_LIB: alternative build of the same engine (A/B benchmarking of compiler flags only)
 LIB_PATH = os.environ.get("EVOGP_HIP_LIB") or os.path.join(_HERE, "lib", "libevogp_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp = C.c_void_p
 _u = C.c_uint

@@ -36,7 +36,8 @@ def main():
         if raw.startswith("{") and '"metric"' in raw:
             line = json.loads(raw)
     interp = next((k for k in t if "sr_tc_kernel<8, false, 2>" in k), None)
-    comp = next((k for k in t if "tc_compile" in k), None)
+    # the program compiler of the headline: the packed kernel (round 4), else the one-tree kernel -- never the general compiler's launch
+    comp = next((k for k in t if "tc_compile_packed_kernel" in k), None) or next((k for k in t if "tc_compile_kernel" in k), None)
     out = {
         "what": "rocprofv3 --kernel-trace --pmc, one counter set per pass (FETCH_SIZE | WRITE_SIZE | SQ_*), command: python bench.py "
                 "--steps 4 --warmup 1 --headline-only; per-dispatch averages (scripts/rocpd_summary.py)",
