@@ -619,10 +619,10 @@ def main():
         try:
             from evogp_amd.algorithm.selection import TournamentSelection as _TS
 
+            torch.manual_seed(42)   # (the constants of the descriptor and the word seed of GeneticProgramming come from torch's generators: the trajectory)
             udesc = GenerateDescriptor(max_tree_len=512, input_len=VAR_LEN, output_len=1, using_funcs=["+", "-", "*", "/", "sin", "cos", "tan"],
                                        max_layer_cnt=9, const_range=[-5, 5], sample_cnt=10000, layer_leaf_prob=0.3)
             upop = 100_000
-            torch.manual_seed(42)   # (the trajectory: GeneticProgramming draws its word seed from torch's CPU generator)
             ualgo = GeneticProgramming(Forest.random_generate(upop, udesc, keys=torch.tensor([42, 0], dtype=torch.uint32, device=device)),
                                        DefaultCrossover(), DefaultMutation(0.1, udesc.update(max_layer_cnt=4)),
                                        _TS(tournament_size=20, survivor_rate=0.5, elite_rate=0.1))

@@ -91,7 +91,8 @@ def test_evolved_long_trees_after_crossover(g, oracle, rng):
 
 # ---- the program compilers: one tree per pass, several trees per pass in batches of 8 ... 64 ------------------------------
 @pytest.mark.parametrize("masked,L,unary", [(False, 64, [NEG, ABS, SQRT, INV]), (True, 64, []), (True, 33, []), (False, 20, [NEG, ABS, SQRT, INV]),
-                                             (False, 64, [SIN, COS, TAN, EXP, LOG, NEG])])
+                                             (False, 64, [SIN, COS, TAN, EXP, LOG, NEG]), (False, 128, [NEG, ABS, SQRT, INV]), (True, 200, []),
+                                             (False, 256, [SIN, COS, TAN, NEG])])
 def test_every_program_compiler_gives_the_same_fitness_words(g, oracle, rng, masked, L, unary):
     """tc_compile_packed_kernel (several trees per pass, largest first) against tc_compile_kernel (one tree per pass), fitness WORDS:
     a population whose size is no multiple of any batch, rows without a tree, a wrong subtree size, the generator's "no function"
@@ -105,11 +106,13 @@ def test_every_program_compiler_gives_the_same_fitness_words(g, oracle, rng, mas
 
     pop, V = 20011, 6
     funcs = [ADD, SUB, MUL, DIV] + unary
-    v, t, s = oracle.generate(pop, L, V, 1, 0.0, 0.5, [L, 5 + masked], depth2leaf(6 if L > 40 else 5 if L > 30 else 4), roulette_uniform(funcs), CS)
+    v, t, s = oracle.generate(pop, L, V, 1, 0.0, 0.5, [L, 5 + masked], depth2leaf(7 if L > 64 else 6 if L > 40 else 5 if L > 30 else 4), roulette_uniform(funcs), CS)
     v, t, s = v.copy(), t.copy(), s.copy()
     s[17, 0] = 0; s[18, 0] = -3; s[40000 % pop, 0] = 0          # rows without a tree: NaN
     r = int(np.nonzero(s[:, 0] >= 5)[0][0]); s[r, 1] += 1        # a subtree size that does not add up: the register kernels
     wrapped = 0
+    if L > 64:
+        assert (s[:, 0] > 64).sum() > 5, "no tree beyond 64 nodes: the long-row case is not covered"
     for r in np.nonzero(s[:, 0] < L - 2)[0][100:160]:            # "no function" over the whole tree (some twice), leaves included
         for _ in range(1 + (r & 1)):
             n = int(s[r, 0])
