@@ -330,8 +330,8 @@ int evogp_hip_debug_set_stats(unsigned long long *device_counters);
 int evogp_hip_debug_profile(int enable);
 int evogp_hip_debug_profile_read(float *stage_ms /* [3] */, int *calls);
 
-/* Which program compiler evogp_hip_sr_fitness uses for rows of at most 64 nodes (tests and A/B measurements; no counterpart in the
- * reference): -1 = the packed compiler with the batch size chosen by the population (DEFAULT), 0 = the older one-tree-per-pass
+/* Which program compiler evogp_hip_sr_fitness uses for single-output trees of at most 64 nodes (tests and A/B measurements; no
+ * counterpart in the reference): -1 = the packed compiler with the batch size chosen by the population (DEFAULT), 0 = the older one-tree-per-pass
  * compiler, 8 / 16 / 32 / 64 = the packed compiler with that many trees per wave.  The fitness words do not depend on the choice
  * (tests/test_gpu_tc_wide.py compares them bit for bit).  The environment variable EVOGP_TC_PACKED sets the same before the first call. */
 int evogp_hip_debug_compile_batch(int trees);
