@@ -370,7 +370,7 @@ const char *evogp_hip_error_string(int code);
 int evogp_hip_set_sr_division(int mode);
 int evogp_hip_get_sr_division(void);
 
-/* ABI version of this header: bumped when a signature changes. */
+/* ABI version of this header (3): bumped when a signature changes or an entry point is added. */
 int evogp_hip_abi_version(void);
 
 #ifdef __cplusplus
