@@ -58,6 +58,10 @@ def test_error_strings_and_argument_errors_without_gpu():
     assert _lib.lib.evogp_hip_breed_lists(10, 10, 8, 1, 30, *([None] * 6), 0, *([None] * 7), 0, 10, None) == -2      # null pointers (more parents than trees is legal)
     # the engine-owned program-record buffer: nothing held before the first fitness call; the cap is a plain setter
     assert _lib.lib.evogp_hip_set_program_buffer_limit(1 << 34) == 0
+    # which program compiler a fitness call uses (tests, A/B): -1 packed with the batch by population, 0 one tree per pass, up to 64
+    assert _lib.lib.evogp_hip_debug_compile_batch(65) == -1 and _lib.lib.evogp_hip_debug_compile_batch(-2) == -1
+    assert _lib.lib.evogp_hip_debug_compile_batch(0) == 0 and _lib.lib.evogp_hip_debug_compile_batch(32) == 0
+    assert _lib.lib.evogp_hip_debug_compile_batch(-1) == 0
 
 
 def test_ops_are_registered_with_reference_schemas():
