@@ -253,3 +253,38 @@ def test_interpreter_generator_switches_still_generate():
     finally:
         for k, v in defaults.items():
             setattr(g, k, v)
+
+
+def test_packed_compiler_plan_shares_out_more_trees_per_pass_than_consecutive_packing():
+    """DESIGN.md section 3.1's figures for tc_compile_packed_kernel's plan, restated on the host: a wave takes 32 consecutive trees,
+    orders them by length / 8 (stable) and fills a pass with the largest tree that is left, then the largest that still fits the 64
+    lanes -- 2.15 trees per pass on the headline forest's lengths, against 1.76 for consecutive trees and a bound of 64 / mean."""
+    from oracle.pyoracle import Oracle, depth2leaf, roulette_uniform
+
+    lens = Oracle("port").generate(32000, 64, 10, 1, 0.5, 0.5, [42, 0], depth2leaf(6), roulette_uniform([1, 2, 3, 4]), [-1, 0, 1])[2][:, 0].astype(int)
+
+    def consecutive(batch):
+        passes, used = 1, 0
+        for n in batch:
+            if used + n > 64:
+                passes, used = passes + 1, 0
+            used += n
+        return passes
+
+    def largest_first(batch):
+        left = sorted(batch, key=lambda n: -(n >> 3))   # (python's sort is stable, like the kernel's radix rounds)
+        passes = 0
+        while left:
+            passes, used, i = passes + 1, 0, 0
+            while i < len(left):
+                if used + left[i] <= 64:
+                    used += left.pop(i)
+                else:
+                    i += 1
+        return passes
+
+    batches = [list(lens[i:i + 32]) for i in range(0, len(lens), 32)]
+    per_pass_consecutive = len(lens) / sum(consecutive(b) for b in batches)
+    per_pass_planned = len(lens) / sum(largest_first(b) for b in batches)
+    assert 1.70 < per_pass_consecutive < 1.82, per_pass_consecutive
+    assert 2.10 < per_pass_planned < 64 / lens.mean(), (per_pass_planned, 64 / lens.mean())
