@@ -288,3 +288,24 @@ def test_packed_compiler_plan_shares_out_more_trees_per_pass_than_consecutive_pa
     per_pass_planned = len(lens) / sum(largest_first(b) for b in batches)
     assert 1.70 < per_pass_consecutive < 1.82, per_pass_consecutive
     assert 2.10 < per_pass_planned < 64 / lens.mean(), (per_pass_planned, 64 / lens.mean())
+
+
+def test_pmc_json_takes_the_headline_compilers_counters_not_the_general_compilers(tmp_path):
+    """scripts/pmc_json.py on the round's own PMC tables: the program compiler's traffic must come from the packed kernel's rows (a
+    substring match once picked tc_compile_general_kernel's four empty launches: 11 KB instead of 640 MB in `call_hbm_bytes`)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    tables = [os.path.join(prof, f"r04Z_05_pmc{i}.md") for i in (1, 2, 3)]
+    if not all(os.path.exists(t) for t in tables):
+        pytest.skip("no PMC tables of this round in profiles/")
+    line = tmp_path / "bench.log"
+    line.write_text(json.dumps({"metric": "tree_evals_per_s", "config": {"pop_per_gpu": 1000000}}) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_json.py"), *tables, str(line)], capture_output=True, text=True, check=True).stdout
+    d = json.loads(out)
+    assert "tc_compile_packed_kernel" in d["kernels"]["tc_compile_kernel"]["rocprof_name"]
+    assert d["tc_compile_kernel_hbm_bytes_per_launch"] > 3e8 and d["sr_tc_kernel_hbm_bytes_per_launch"] > 2e8
+    assert abs(d["call_hbm_bytes"] - d["tc_compile_kernel_hbm_bytes_per_launch"] - d["sr_tc_kernel_hbm_bytes_per_launch"]) < 1.0
