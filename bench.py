@@ -206,11 +206,27 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "gloo" if share_gpu else "nccl"
-        if share_gpu:
+        backend = os.environ.get("EVOGP_BENCH_BACKEND", "gloo" if share_gpu else "nccl")
+        if backend == "gloo":
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=device)
+            # nccl = RCCL.  The headline step has no data-path collective (barriers and two scalar reductions around the timed region),
+            # so a node whose RCCL does not come up still gets measured: the ranks fall back to gloo for those, and the line says so.
+            try:
+                dist.init_process_group("nccl", device_id=device)
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world, f"all_reduce over {world} ranks gave {probe.item()}"
+            except Exception as exc:   # noqa: BLE001 -- whatever RCCL raises
+                print(f"[bench] rank {rank}: RCCL did not come up ({exc!r:.300}); barriers and reductions go over gloo", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+                store = f"/tmp/evogp_bench_store_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.environ.get('MASTER_PORT', '0')}"
+                dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+                backend = "gloo (RCCL initialisation failed)"
         world = dist.get_world_size()
 
     import evogp_amd  # noqa: F401
