@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # EVOGP_HIP_LIB: alternative build of the same engine (A/B benchmarking of compiler flags only)
 LIB_PATH = os.environ.get("EVOGP_HIP_LIB") or os.path.join(_HERE, "lib", "libevogp_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = C.c_void_p
 _u = C.c_uint
@@ -31,11 +31,9 @@ PROTOTYPES = {
     "evogp_hip_breed_default_rows": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_breed_default_table": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evogp_hip_breed_lists": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "evogp_hip_breed_lists_compiled": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "evogp_hip_generate_masked_hashed": [_u, _u, _u, _u, _u, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_longlong, C.c_longlong, _u, _vp],
-    "evogp_hip_breed_lists_hashed": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, C.c_longlong, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
-    "evogp_hip_sr_fitness_stamped": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_ulonglong, _vp],
-    "evogp_hip_sr_fitness_hinted": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, C.c_ulonglong, _u, _vp],
+    "evogp_hip_breed_lists_hashed": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_longlong, C.c_longlong, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "evogp_hip_sr_fitness_hinted": [_u, _u, _u, _u, _u, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _u, _vp],
     "evogp_hip_batch_evaluate": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_batch_argmax_count": [_u, _u, _u, _u, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_evaluate_prepare": [_u, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_size_t, _vp],
@@ -45,7 +43,6 @@ PROTOTYPES = {
     "evogp_hip_select_alternating": [_u, _u, _u, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_tournament_select": [_u, _u, _u, C.c_longlong, C.c_longlong, _vp, _vp, _vp],
     "evogp_hip_set_program_buffer_limit": [C.c_ulonglong],
-    "evogp_hip_set_breed_compile": [_i],
     "evogp_hip_release_workspaces": [],
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],

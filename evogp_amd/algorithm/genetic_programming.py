@@ -139,8 +139,7 @@ class GeneticProgramming:
         donors = torch.ops.evogp_hip.tree_generate_masked_hashed(
             n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob,
             d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, self._word_seed, self._steps, below)
-        # (the pass also compiles the rows it builds for the next tree_SR_fitness call when that experiment is on: csrc/sr_tc.hip)
-        nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elites, parents, self._word_seed, self._steps,
-                                                                  below, *donors, 0, pop)
-        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns, func_mask=Forest.join_masks(f.func_mask, d.func_mask)).set_compiled_records(stamp)
+        nv, nt, ns = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elites, parents, self._word_seed, self._steps,
+                                                           below, *donors, 0, pop)
+        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns, func_mask=Forest.join_masks(f.func_mask, d.func_mask))
         return self.forest

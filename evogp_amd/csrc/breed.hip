@@ -149,6 +149,12 @@ __global__ __launch_bounds__(kRepBlock) void breed_group_kernel(BreedParams a) {
 
 using namespace evogp;
 
+static int breed_impl(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value, const int16_t *type,
+                      const int16_t *size, const int *elite_rows, const int *parent_rows, const int *rnd, int hashed,
+                      unsigned long long hash_base, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
+                      const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res, int *decisions, int row_begin,
+                      int row_count, evogp_stream_t stream_);
+
 extern "C" int evogp_hip_breed_default(int pop_size, int gp_len, int n_elite, int n_surv, const float *value,
                                        const int16_t *type, const int16_t *size, const int *order, const int *rnd,
                                        unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
@@ -190,45 +196,27 @@ extern "C" int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, i
                                      const int *rnd, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
                                      const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
                                      int *decisions, int row_begin, int row_count, evogp_stream_t stream_) {
-    return evogp_hip_breed_lists_compiled(pop_size, table_rows, gp_len, n_elite, n_surv, value, type, size, elite_rows, parent_rows, rnd,
-                                          mutate_below, donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions,
-                                          row_begin, row_count, nullptr, stream_);
-}
-
-static int breed_impl(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value, const int16_t *type,
-                      const int16_t *size, const int *elite_rows, const int *parent_rows, const int *rnd, int hashed,
-                      unsigned long long hash_base, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
-                      const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res, int *decisions, int row_begin,
-                      int row_count, unsigned long long *records_stamp, evogp_stream_t stream_);
-
-extern "C" int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
-                                              const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
-                                              const int *rnd, unsigned mutate_below, const float *donor_value,
-                                              const int16_t *donor_type, const int16_t *donor_size, float *value_res,
-                                              int16_t *type_res, int16_t *size_res, int *decisions, int row_begin, int row_count,
-                                              unsigned long long *records_stamp, evogp_stream_t stream_) {
     return breed_impl(pop_size, table_rows, gp_len, n_elite, n_surv, value, type, size, elite_rows, parent_rows, rnd, 0, 0ull, mutate_below,
-                      donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions, row_begin, row_count, records_stamp, stream_);
+                      donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions, row_begin, row_count, stream_);
 }
+
 
 extern "C" int evogp_hip_breed_lists_hashed(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
                                             const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
                                             long long seed, long long generation, unsigned mutate_below, const float *donor_value,
                                             const int16_t *donor_type, const int16_t *donor_size, float *value_res, int16_t *type_res,
-                                            int16_t *size_res, int *decisions, int row_begin, int row_count,
-                                            unsigned long long *records_stamp, evogp_stream_t stream_) {
+                                            int16_t *size_res, int *decisions, int row_begin, int row_count, evogp_stream_t stream_) {
     return breed_impl(pop_size, table_rows, gp_len, n_elite, n_surv, value, type, size, elite_rows, parent_rows, nullptr, 1,
                       counter_base(seed, generation), mutate_below, donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions,
-                      row_begin, row_count, records_stamp, stream_);
+                      row_begin, row_count, stream_);
 }
 
 static int breed_impl(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value, const int16_t *type,
                       const int16_t *size, const int *elite_rows, const int *parent_rows, const int *rnd, int hashed,
                       unsigned long long hash_base, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
                       const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res, int *decisions, int row_begin,
-                      int row_count, unsigned long long *records_stamp, evogp_stream_t stream_) {
+                      int row_count, evogp_stream_t stream_) {
     const int *order = elite_rows;
-    if (records_stamp) *records_stamp = 0ull;
     // n_surv may exceed pop_size: a selection that draws with replacement may name more parents than there are trees
     if (pop_size <= 0 || table_rows <= 0 || gp_len <= 0 || gp_len > kMaxStack || n_elite < 0 || n_elite > pop_size || n_surv <= 0)
         return EVOGP_E_BADARG;
@@ -257,11 +245,6 @@ static int breed_impl(int pop_size, int table_rows, int gp_len, int n_elite, int
     const size_t lds_groups = (size_t)(kRepBlock / kGroupLanes) * gp_len * 8;
     if (groups_on && gp_len % 4 == 0 && lds_groups <= 48 * 1024 && (uintptr_t)value_res % 16 == 0 && (uintptr_t)type_res % 8 == 0 &&
         (uintptr_t)size_res % 8 == 0) {
-        if (records_stamp) {   // the same pass, compiling its rows for the next fitness call where that is possible (sr_tc.hip)
-            const hipError_t ce = launch_breed_compiled(a, (unsigned)blocks, lds_groups, (hipStream_t)stream_, records_stamp);
-            if (ce != hipSuccess) return (int)ce;
-            if (*records_stamp != 0ull) return EVOGP_OK;
-        }
         hipLaunchKernelGGL(breed_group_kernel, dim3((unsigned)blocks), dim3(kRepBlock), lds_groups, (hipStream_t)stream_, a);
         return (int)hipGetLastError();
     }

@@ -1,7 +1,6 @@
-// breed_group.hpp — the four-rows-per-wave breeding pass (breed.hip) as a body with a hook behind every chunk of 64 rows, so
-// that a second translation unit can instantiate it with work of its own on the rows just written: sr_tc.hip compiles them
-// into the program records of the NEXT fitness call while the rows are in the cache and the breeding pass — bound by memory
-// latency — leaves the vector unit idle (docs/DESIGN_history_r01_r03.md section 3.5a).
+// breed_group.hpp — the four-rows-per-wave breeding pass (breed.hip) as a body with a hook behind every chunk of 64 rows.
+// (Rounds 3-4 instantiated it a second time with a hook that compiled the rows just written into the program records of the
+// next fitness call; measured, nothing gained, removed in round 5: docs/DESIGN_history_r01_r03.md section 3.5a.)
 #pragma once
 #include "replace_row.hpp"
 #include <hip/hip_runtime.h>
@@ -28,10 +27,6 @@ struct BreedParams {
 };
 
 constexpr int kBreedUnit = kRepBlock / 64;   // chunks a workgroup can decide at once: one per wave
-
-// sr_tc.hip: the same pass as a kernel that also compiles the rows it builds into the program records of the next fitness call
-// (*stamp != 0: launched, the stamp names the records; *stamp == 0: not possible now, nothing was launched)
-hipError_t launch_breed_compiled(const BreedParams &a, unsigned blocks, size_t lds, hipStream_t stream, unsigned long long *stamp);
 
 struct NoBreedHook {
     __device__ inline void chunk_done(const BreedParams &, int, int) const {}

@@ -291,15 +291,10 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
     const int lane = threadIdx.x & 63;
     // only_marked 1: behind the register kernels, the trees they marked too deep; 2: behind the threaded code alone (more
     // variables than the register kernels take), every tree it left marked
-    // 3: the ONLY follow-up behind the threaded code when the launch hints skipped the general compiler and / or the FULL register
-    // build: every tree that still carries a sentinel (too deep, heavy / run-time bail-out, left for the general compiler); it also
-    // reports the call's marks for the hints of later calls
-    // 4: like 3, but the FULL register build ran in front (it has taken the heavy marks): too deep, or left for a general compiler
-    // that was not launched
-    if (only_marked >= 3 && p.marks) {
-        const bool heavy = marks_pending(p, 0), general = marks_pending(p, 4);
-        if (p.hint_words && blockIdx.x == 0 && lane == 0) { p.hint_words[0] = heavy ? 1u : 0u; p.hint_words[1] = general ? 1u : 0u; }
-        if ((!heavy || only_marked == 4) && !general && uni((int)p.marks[1]) == 0) return;
+    // 4: behind the threaded code and the FULL register build (which has taken the heavy marks) when the caller's function mask kept
+    // the general compiler from being launched: too deep, or carrying that compiler's sentinel after all (a mask that promised too much)
+    if (only_marked == 4 && p.marks) {
+        if (!marks_pending(p, 4) && uni((int)p.marks[1]) == 0) return;
     }
     if (only_marked == 1 && p.marks && uni((int)p.marks[1]) == 0) return;  // no tree needs the general path
     if (only_marked == 2 && p.marks && !marks_pending(p, 0) && uni((int)p.marks[1]) == 0) return;
@@ -360,7 +355,7 @@ __global__ __launch_bounds__(64) void sr_general_kernel(SrParams p, int only_mar
         if (t < c1) {
             const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
             const uint32_t w = f2bits(*mark);
-            hit = w == kSentinelDeep || (only_marked >= 2 && w == kSentinelHeavy) || (only_marked >= 3 && w == kSentinelGeneral);
+            hit = w == kSentinelDeep || (only_marked >= 2 && w == kSentinelHeavy) || (only_marked == 4 && w == kSentinelGeneral);
         }
         unsigned long long m = __ballot(hit);
         while (m) {
@@ -432,7 +427,7 @@ static std::mutex g_chain_mu;  // one for both instantiations of run_population:
 template <bool STORE>
 static int run_population(const SrParams &p_in, hipStream_t stream) {
     SrParams p = p_in;
-    p.hint_general = 1; p.hint_heavy = 1; p.hint_words = nullptr;   // launch everything unless the hints below say otherwise
+    p.hint_general = 1;   // the general compiler is launched unless the function mask below says that nothing can be left for it
     // The scratch block handed out below was zeroed by the previous call's first kernel ON THE SAME STREAM; two host
     // threads feeding one stream must therefore not interleave their acquire + launch sequences.
     std::lock_guard<std::mutex> chain_lock(g_chain_mu);
@@ -483,16 +478,12 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         std::lock_guard<std::mutex> pl(g_prof_mu);
         g_prof.push_back(prof);
     };
-    if (!STORE && asm_depth == 3 && !mo && !profiling) {   // (per-stage profiling keeps the full launch sequence)
-        const TcHints h = tc_hints();
-        p.hint_general = h.general ? 1 : 0; p.hint_heavy = h.heavy ? 1 : 0; p.hint_words = h.device_words;
-    }
     if (!STORE && asm_depth == 3 && !mo && !profiling && p.func_mask != 0u && p.gp_len <= 64) {
         // The caller knows the forest's function set.  Nothing but + - * / and the unary functions with handlers of their own:
         // no tree can be left for the general compiler (rows of at most 64 nodes), so that launch is not made.  The last follow-up
         // kernel (mode 4: behind the FULL build) also takes a tree that carries the general compiler's sentinel after all, so a mask
         // that promises too much costs speed, never a result.  Decided by the mask alone: the same forest always takes the same
-        // kernels (unlike the history-driven hints above).  5 launches -> 4 on the headline's function set.
+        // kernels.  5 launches -> 4 on the headline's function set.
         constexpr unsigned kOwnHandlers = (1u << F_ADD) | (1u << F_SUB) | (1u << F_MUL) | (1u << F_DIV) | (1u << F_SIN) | (1u << F_COS) | (1u << F_TAN) |
                                           (1u << F_LOG) | (1u << F_LOOSE_LOG) | (1u << F_EXP) | (1u << F_INV) | (1u << F_NEG) | (1u << F_ABS) |
                                           (1u << F_SQRT) | (1u << F_LOOSE_SQRT);
@@ -526,8 +517,6 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
     if (tc_done && mo) {  // multi-output trees the threaded code left marked: FULL register build, then the general kernel
         if (p.D >= 128) e = p.var_len <= 16 ? launch_fast<2, 16, 16, true, 8, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<2, 16, 32, true, 8, STORE, false>(p, 1, stream, p.marks + 3);
         else e = p.var_len <= 16 ? launch_fast<1, 32, 16, true, 16, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<1, 32, 32, true, 16, STORE, false>(p, 1, stream, p.marks + 3);
-    } else if (tc_done && !p.hint_heavy) {
-        e = hipSuccess;   // no heavy marks for a while: whatever this call marks is taken by the scratch-stack kernel below (mode 3)
     } else if (tc_done) {
         if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
         else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
@@ -547,14 +536,14 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         e = p.var_len <= 16 ? launch_pair<1, 32, 16, true, 16, STORE>(p, stream) : launch_pair<1, 32, 32, true, 16, STORE>(p, stream);
     }
     if (e != hipSuccess) return (int)e;
-    e = launch_general<STORE>(p, tc_done && !mo && (p.hint_words || !p.hint_general || !p.hint_heavy) ? (p.hint_heavy ? 4 : 3) : 1, stream);
+    e = launch_general<STORE>(p, tc_done && !mo && !p.hint_general ? 4 : 1, stream);
     static const bool dbg_marks = getenv("EVOGP_DEBUG_MARKS") != nullptr;   // diagnostics: the call's flag words (synchronises)
     if (dbg_marks && p.marks) {
         unsigned h[8] = {};
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, p.marks, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[evogp] sr_fitness pop %d: marks %u %u %u %u %u %u %u %u, hints general %d heavy %d, chunks %d\n", p.pop, h[0], h[1], h[2], h[3], h[4],
-                h[5], h[6], h[7], p.hint_general, p.hint_heavy, p.mark_chunks);
+        fprintf(stderr, "[evogp] sr_fitness pop %d: marks %u %u %u %u %u %u %u %u, general compiler %d, chunks %d\n", p.pop, h[0], h[1], h[2], h[3], h[4],
+                h[5], h[6], h[7], p.hint_general, p.mark_chunks);
     }
     prof_done(tc_done);
     return (int)e;
@@ -569,7 +558,7 @@ hipError_t run_argmax_count_threaded(const SrParams &p_in, const int *labels, un
     static const int asm_depth = env_int("EVOGP_SR_ASM", EVOGP_SR_DEFAULT_ASM);
     if (asm_depth != 3) return hipSuccess;
     SrParams p = p_in;
-    p.hint_general = 1; p.hint_heavy = 1; p.hint_words = nullptr;
+    p.hint_general = 1;
     std::lock_guard<std::mutex> chain_lock(g_chain_mu);   // (the call-scratch chain of run_population)
     hipError_t e;
     p.marks = acquire_call_scratch(stream, &p.zero_next, &e);
@@ -589,24 +578,14 @@ extern "C" int evogp_hip_sr_fitness(unsigned pop_size, unsigned data_points, uns
                                     unsigned out_len, int use_mse, const float *value, const int16_t *type,
                                     const int16_t *size, const float *variables, const float *labels,
                                     float *fitnesses, unsigned kernel_type, evogp_stream_t stream_) {
-    return evogp_hip_sr_fitness_stamped(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels,
-                                        fitnesses, kernel_type, 0ull, stream_);
-}
-
-extern "C" int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len,
-                                            unsigned out_len, int use_mse, const float *value, const int16_t *type,
-                                            const int16_t *size, const float *variables, const float *labels,
-                                            float *fitnesses, unsigned kernel_type, unsigned long long records_stamp,
-                                            evogp_stream_t stream_) {
     return evogp_hip_sr_fitness_hinted(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels,
-                                       fitnesses, kernel_type, records_stamp, 0u, stream_);
+                                       fitnesses, kernel_type, 0u, stream_);
 }
 
 extern "C" int evogp_hip_sr_fitness_hinted(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len,
                                            unsigned out_len, int use_mse, const float *value, const int16_t *type,
                                            const int16_t *size, const float *variables, const float *labels,
-                                           float *fitnesses, unsigned kernel_type, unsigned long long records_stamp,
-                                           unsigned function_mask, evogp_stream_t stream_) {
+                                           float *fitnesses, unsigned kernel_type, unsigned function_mask, evogp_stream_t stream_) {
     // argument contract of torch_wrapper.cu:250-254
     if (pop_size == 0 || data_points == 0 || gp_len == 0 || gp_len > (unsigned)kMaxStack || var_len == 0 || out_len == 0)
         return EVOGP_E_BADARG;
@@ -617,7 +596,6 @@ extern "C" int evogp_hip_sr_fitness_hinted(unsigned pop_size, unsigned data_poin
     p.value = value; p.type = type; p.size = size; p.X = variables; p.y = labels; p.fitness = fitnesses;
     p.pop = (int)pop_size; p.D = (int)data_points; p.gp_len = (int)gp_len; p.var_len = (int)var_len;
     p.out_len = (int)out_len; p.use_mse = use_mse ? 1 : 0;
-    p.stamp = records_stamp;
     p.func_mask = function_mask;
     return run_population<false>(p, (hipStream_t)stream_);
 }

@@ -32,16 +32,11 @@ struct SrParams {
     unsigned *zero_next; // four words the first kernel of the chain zeroes for the next call on this stream (or nullptr)
     int mark_chunks;     // the threaded code ran the population in this many chunks: chunk c's flags are marks[c * kCallScratchChunkWords + i]
     hipEvent_t prof_mid; // profiling (evogp_hip_debug_profile): recorded between the compiler and the interpreter launch, or nullptr
-    // Launch hints (sr_tc.hip tc_hints): what recent calls on this device found.  They only decide which of the kernels that
-    // would leave at once are launched at all; whatever a skipped kernel would have handled is evaluated by the last follow-up
-    // kernel (sr_general_kernel, mode 3), so results never depend on them.
-    int hint_general;         // != 0: launch the general compiler (trees the one-chunk compiler marks for it occurred recently)
-    int hint_heavy;           // != 0: launch the FULL register build for marked trees (such marks occurred recently)
-    unsigned *hint_words;     // host-mapped words the last follow-up kernel reports this call's marks into (or nullptr)
+    int hint_general;         // != 0: launch the general compiler behind the packed one.  0 only where the caller's function mask (below) says
+                              // that no tree can be left for it; a tree that carries its sentinel after all is evaluated by the last follow-up kernel
     unsigned func_mask;       // bit f: function id f (defs.h:10-57) may occur in the forest; 0 = unknown.  A caller that knows the
                               // forest's function set (evogp_amd.tree.Forest tracks it from the descriptors its trees came from) lets
                               // the call skip launches that such a forest cannot need -- decided by the mask, never by history
-    unsigned long long stamp; // != 0: the caller believes the program records of the breeding pass with this stamp belong to this population
     unsigned *marks; // [0] != 0: some tree carries kSentinelHeavy, [1] != 0: some tree carries kSentinelDeep,
                      // [2]: how many of the mark_sample sampled trees were marked heavy (may be nullptr)
 };
@@ -50,10 +45,6 @@ struct SrParams {
 // assembly core.  Returns hipSuccess and sets *handled when it took the launch (trees it could not take are
 // marked kSentinelHeavy / NaN in p.fitness for the follow-up kernels); *handled == false means "not eligible".
 hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled, int *mark_sample, int *mark_chunks);
-
-// What recent fitness calls on the current device found (see SrParams::hint_*): one call per fitness call.
-struct TcHints { bool heavy, general; unsigned *device_words; };
-TcHints tc_hints();
 
 // Classification epilogue on the threaded code (sr_fitness.hip: it shares the call-scratch chain with the fitness calls):
 // counts[t] = rows whose arg-max output equals labels[row]; trees the path cannot take come back with kDeepCountBit set and

@@ -196,7 +196,7 @@ Tensor tree_evaluate(int64_t pop_size, int64_t gp_len, int64_t var_len, int64_t 
 
 Tensor sr_fitness_impl(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
                        const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
-                       int64_t kernel_type, int64_t records_stamp, int64_t func_mask = 0) {
+                       int64_t kernel_type, int64_t func_mask = 0) {
     check_sizes(pop_size, gp_len);
     TORCH_CHECK(var_len > 0, "var_len must be larger than 0, but got ", var_len);
     TORCH_CHECK(out_len > 0, "out_len must be larger than 0, but got ", out_len);
@@ -212,7 +212,7 @@ Tensor sr_fitness_impl(int64_t pop_size, int64_t data_points, int64_t gp_len, in
     const int rc = evogp_hip_sr_fitness_hinted((unsigned)pop_size, (unsigned)data_points, (unsigned)gp_len, (unsigned)var_len, (unsigned)out_len,
                                                use_mse ? 1 : 0, value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(),
                                                variables.data_ptr<float>(), labels.data_ptr<float>(), fitness.data_ptr<float>(),
-                                               (unsigned)kernel_type, (unsigned long long)records_stamp, (unsigned)func_mask, current_stream(dev));
+                                               (unsigned)kernel_type, (unsigned)func_mask, current_stream(dev));
     check_rc(rc, "tree_SR_fitness");
     return fitness;
 }
@@ -220,16 +220,14 @@ Tensor sr_fitness_impl(int64_t pop_size, int64_t data_points, int64_t gp_len, in
 Tensor tree_SR_fitness(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
                        const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
                        int64_t kernel_type) {
-    return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type, 0);
+    return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type);
 }
 
-// tree_SR_fitness for a caller that knows more about the forest: the stamp of the records the breeding pass compiled ahead for
-// exactly these rows (0: none) and the set of functions that can occur in it (0: unknown) -- include/evogp_hip.h
-Tensor tree_SR_fitness_stamped(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
-                               const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
-                               int64_t kernel_type, int64_t records_stamp, int64_t func_mask) {
-    return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type,
-                           records_stamp, func_mask);
+// tree_SR_fitness for a caller that knows the set of functions that can occur in the forest (0: unknown) -- include/evogp_hip.h
+Tensor tree_SR_fitness_masked(int64_t pop_size, int64_t data_points, int64_t gp_len, int64_t var_len, int64_t out_len, bool use_mse,
+                              const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &variables, const Tensor &labels,
+                              int64_t kernel_type, int64_t func_mask) {
+    return sr_fitness_impl(pop_size, data_points, gp_len, var_len, out_len, use_mse, value, type, size, variables, labels, kernel_type, func_mask);
 }
 
 // ---- extra ops (no counterpart in the reference) ------------------------------------------------------------------------
@@ -453,8 +451,7 @@ Tensor3 breed_default_rows(int64_t pop_size, int64_t gp_len, int64_t n_elite, in
 // the survivor indices of a tournament selection do); n_elite / n_surv are the lists' lengths.
 Tensor3 breed_rows_impl(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
                         const Tensor &parent_rows, const Tensor *rnd_or_null, int64_t seed, int64_t generation, int64_t mutate_below,
-                        const Tensor &donor_value, const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin, int64_t row_count,
-                        unsigned long long *records_stamp) {
+                        const Tensor &donor_value, const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
     check_sizes(pop_size, gp_len);
     TORCH_CHECK(row_begin >= 0 && row_count > 0 && row_begin + row_count <= pop_size, "row range out of the population");
     TORCH_CHECK(mutate_below >= 0 && mutate_below < (1LL << 32), "mutate_below must fit in 32 bits");
@@ -477,18 +474,18 @@ Tensor3 breed_rows_impl(int64_t pop_size, int64_t gp_len, const Tensor &value, c
     c10::DeviceGuard guard(dev);
     Tensor3 out = empty_forest(row_count, gp_len, dev);
     const int rc = rnd_or_null
-        ? evogp_hip_breed_lists_compiled(
+        ? evogp_hip_breed_lists(
               (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),
               size.data_ptr<int16_t>(), n_elite > 0 ? elite_rows.data_ptr<int>() : nullptr, parent_rows.data_ptr<int>(), rnd_or_null->data_ptr<int>(),
               (unsigned)mutate_below, donor_value.data_ptr<float>() - skip * gp_len, donor_type.data_ptr<int16_t>() - skip * gp_len,
               donor_size.data_ptr<int16_t>() - skip * gp_len, std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
-              std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, records_stamp, current_stream(dev))
+              std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, current_stream(dev))
         : evogp_hip_breed_lists_hashed(
               (int)pop_size, (int)table_rows, (int)gp_len, (int)n_elite, (int)n_surv, value.data_ptr<float>(), type.data_ptr<int16_t>(),
               size.data_ptr<int16_t>(), n_elite > 0 ? elite_rows.data_ptr<int>() : nullptr, parent_rows.data_ptr<int>(), seed, generation,
               (unsigned)mutate_below, donor_value.data_ptr<float>() - skip * gp_len, donor_type.data_ptr<int16_t>() - skip * gp_len,
               donor_size.data_ptr<int16_t>() - skip * gp_len, std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
-              std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, records_stamp, current_stream(dev));
+              std::get<2>(out).data_ptr<int16_t>(), nullptr, (int)row_begin, (int)row_count, current_stream(dev));
     check_rc(rc, "breed_rows");
     return out;
 }
@@ -497,32 +494,15 @@ Tensor3 breed_rows(int64_t pop_size, int64_t gp_len, const Tensor &value, const 
                    const Tensor &parent_rows, const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value, const Tensor &donor_type,
                    const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
     return breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, &rnd, 0, 0, mutate_below, donor_value, donor_type, donor_size,
-                           row_begin, row_count, nullptr);
+                           row_begin, row_count);
 }
 
-// breed_rows that also compiles the rows it builds into the program records of the next tree_SR_fitness call where the engine
-// can (include/evogp_hip.h evogp_hip_breed_lists_compiled); the int is the records' stamp (0: not compiled) for
-// tree_SR_fitness_stamped
-std::tuple<Tensor, Tensor, Tensor, int64_t> breed_rows_compiled(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type,
-                                                                const Tensor &size, const Tensor &elite_rows, const Tensor &parent_rows,
-                                                                const Tensor &rnd, int64_t mutate_below, const Tensor &donor_value,
-                                                                const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin,
-                                                                int64_t row_count) {
-    unsigned long long stamp = 0;
-    Tensor3 out = breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, &rnd, 0, 0, mutate_below, donor_value, donor_type,
-                                  donor_size, row_begin, row_count, &stamp);
-    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), (int64_t)stamp};
-}
-
-// breed_rows_compiled with the six words of every offspring computed in the kernel from (seed, generation) instead of read from `rnd`
-std::tuple<Tensor, Tensor, Tensor, int64_t> breed_rows_hashed(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type,
-                                                              const Tensor &size, const Tensor &elite_rows, const Tensor &parent_rows, int64_t seed,
-                                                              int64_t generation, int64_t mutate_below, const Tensor &donor_value,
-                                                              const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
-    unsigned long long stamp = 0;
-    Tensor3 out = breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, nullptr, seed, generation, mutate_below, donor_value,
-                                  donor_type, donor_size, row_begin, row_count, &stamp);
-    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), (int64_t)stamp};
+// breed_rows with the six words of every offspring computed in the kernel from (seed, generation) instead of read from `rnd`
+Tensor3 breed_rows_hashed(int64_t pop_size, int64_t gp_len, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &elite_rows,
+                          const Tensor &parent_rows, int64_t seed, int64_t generation, int64_t mutate_below, const Tensor &donor_value,
+                          const Tensor &donor_type, const Tensor &donor_size, int64_t row_begin, int64_t row_count) {
+    return breed_rows_impl(pop_size, gp_len, value, type, size, elite_rows, parent_rows, nullptr, seed, generation, mutate_below, donor_value,
+                           donor_type, donor_size, row_begin, row_count);
 }
 
 }  // namespace
@@ -571,17 +551,14 @@ TORCH_LIBRARY(evogp_hip, m) {
     m.def("breed_rows(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows, Tensor parent_rows,"
           " Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin, int row_count)"
           " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
-    m.def("breed_rows_compiled(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows,"
-          " Tensor parent_rows, Tensor rnd, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin,"
-          " int row_count) -> (Tensor value, Tensor node_type, Tensor subtree_size, int records_stamp)");
     m.def("breed_rows_hashed(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows, Tensor parent_rows,"
           " int seed, int generation, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin, int row_count)"
-          " -> (Tensor value, Tensor node_type, Tensor subtree_size, int records_stamp)");
+          " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
     m.def("tree_generate_masked_hashed(int pop_size, int gp_len, int var_len, int out_len, int const_samples_len, float out_prob, float const_prob,"
           " Tensor depth2leaf_probs, Tensor roulette_funcs, Tensor const_samples, int tree_index_offset, int seed, int generation, int active_below)"
           " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
-    m.def("tree_SR_fitness_stamped(int pop_size, int data_points, int gp_len, int var_len, int out_len, bool use_mse, Tensor value,"
-          " Tensor node_type, Tensor subtree_size, Tensor variables, Tensor labels, int kernel_type, int records_stamp, int func_mask) -> Tensor");
+    m.def("tree_SR_fitness_masked(int pop_size, int data_points, int gp_len, int var_len, int out_len, bool use_mse, Tensor value,"
+          " Tensor node_type, Tensor subtree_size, Tensor variables, Tensor labels, int kernel_type, int func_mask) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(evogp_hip, CompositeExplicitAutograd, m) { m.impl("random_words", &random_words); }  // no tensor argument to dispatch on
@@ -596,10 +573,9 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("breed_default", &breed_default);
     m.impl("breed_default_rows", &breed_default_rows);
     m.impl("breed_rows", &breed_rows);
-    m.impl("breed_rows_compiled", &breed_rows_compiled);
     m.impl("breed_rows_hashed", &breed_rows_hashed);
     m.impl("tree_generate_masked_hashed", &tree_generate_masked_hashed);
-    m.impl("tree_SR_fitness_stamped", &tree_SR_fitness_stamped);
+    m.impl("tree_SR_fitness_masked", &tree_SR_fitness_masked);
     m.impl("select_survivors", &select_survivors);
     m.impl("tournament_select", &tournament_select);
 }

@@ -318,9 +318,9 @@ class ShardedGeneticProgramming:
             donors = (torch.empty((rows, L), dtype=torch.float32, device=dev), torch.empty((rows, L), dtype=torch.int16, device=dev),
                       torch.empty((rows, L), dtype=torch.int16, device=dev))
         value, ntype, size = full._tensors()
-        nv, nt, ns, stamp = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elite_rows, parent_rows, self.seed, self.generation,
+        nv, nt, ns = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elite_rows, parent_rows, self.seed, self.generation,
                                                                   below, *donors, lo, rows)
-        return Forest(full.input_len, full.output_len, nv, nt, ns, func_mask=Forest.join_masks(full.func_mask, d.func_mask)).set_compiled_records(stamp)
+        return Forest(full.input_len, full.output_len, nv, nt, ns, func_mask=Forest.join_masks(full.func_mask, d.func_mask))
 
     def slice_torch(self, table: Forest, elite_rows: torch.Tensor, parent_rows: torch.Tensor, pop: int, lo: int, hi: int) -> Forest:
         """The same slice composed from the reference's operators (any device): genetic_programming.py:110-122."""

@@ -101,18 +101,6 @@ class Forest:
         size[:, 0] = 1
         return Forest(input_len, output_len, value, ntype, size)
 
-    def set_compiled_records(self, stamp: int) -> "Forest":
-        """remember that the breeding pass compiled exactly these rows (torch.ops.evogp_hip.breed_rows_compiled returned `stamp`):
-        SR_fitness then presents the stamp while the tensors stay untouched, and the engine skips its compiler launch.
-
-        "Untouched" is judged by the tensors' data pointers and torch version counters (``_forest_key``).  A write that goes around
-        the counter -- ``tensor.data[...] = x``, a custom op that mutates an input without declaring it -- is NOT seen: the function
-        mask then merely costs a launch (the last follow-up kernel still evaluates every tree), but a stale stamp, with the
-        EVOGP_BREED_COMPILE experiment on, would make the engine evaluate the old programs.  Do not edit a forest through ``.data``;
-        assign the attribute (or index in place) instead."""
-        self._records = (int(stamp), self._forest_key()) if stamp else None
-        return self
-
     def _tensors(self):
         return (self.batch_node_value.contiguous(), self.batch_node_type.contiguous(),
                 self.batch_subtree_size.contiguous())
@@ -182,18 +170,12 @@ class Forest:
         assert labels.shape == (n, self.output_len), (
             f"outputs shape should be ({n}, {self.output_len}), but got {labels.shape}")
         assert execute_mode in _SR_MODES, f"execute_mode should be one of {list(_SR_MODES)}, but got {execute_mode}"
-        # rows the breeding pass compiled ahead of this call (set_compiled_records): present the stamp as long as the three
-        # tensors are the ones that pass returned, unmodified (identity + version counters); the engine checks the rest
-        rec = getattr(self, "_records", None)
-        if rec is not None and rec[1] != self._forest_key():
-            rec = self._records = None
         mask = self.func_mask
-        if inputs.is_cuda and (rec is not None or mask):
-            # what this object knows beyond the tensors: the stamp of records compiled ahead, the function set of the trees
-            return torch.ops.evogp_hip.tree_SR_fitness_stamped(self.pop_size, n, self.max_tree_len, self.input_len, self.output_len, use_MSE,
-                                                               *self._tensors(), inputs.contiguous().to(torch.float32),
-                                                               labels.contiguous().to(torch.float32), _SR_MODES[execute_mode],
-                                                               rec[0] if rec is not None else 0, mask)
+        if inputs.is_cuda and mask:
+            # what this object knows beyond the tensors: the function set of the trees (the descriptors they came from)
+            return torch.ops.evogp_hip.tree_SR_fitness_masked(self.pop_size, n, self.max_tree_len, self.input_len, self.output_len, use_MSE,
+                                                              *self._tensors(), inputs.contiguous().to(torch.float32),
+                                                              labels.contiguous().to(torch.float32), _SR_MODES[execute_mode], mask)
         return torch.ops.evogp_cuda.tree_SR_fitness(self.pop_size, n, self.max_tree_len, self.input_len,
                                                     self.output_len, use_MSE, *self._tensors(),
                                                     inputs.contiguous().to(torch.float32),

@@ -157,38 +157,7 @@ int evogp_hip_breed_lists(int pop_size, int table_rows, int gp_len, int n_elite,
                           const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
                           int *decisions, int row_begin, int row_count, evogp_stream_t stream);
 
-/* Program records written AHEAD of the fitness call (no counterpart in the reference).  evogp_hip_sr_fitness spends a fifth of
- * its time compiling the trees into the program records its interpreter reads; the breeding pass has the rows it builds in
- * the cache and its vector unit idle.  evogp_hip_breed_lists_compiled is evogp_hip_breed_lists that also compiles rows
- * [row_begin, row_begin + row_count) — record k = row row_begin + k — for the dataset geometry of the device's most recent
- * single-output evogp_hip_sr_fitness call, and returns a STAMP naming those records (0: not possible now — no such call yet,
- * gp_len > 64, the record buffer too small — then it is exactly evogp_hip_breed_lists).  evogp_hip_sr_fitness_stamped is
- * evogp_hip_sr_fitness for a caller that presents the stamp it got for EXACTLY the rows it now passes (same row_count trees,
- * unmodified since): if the engine's records still carry that stamp, the population size matches and the dataset geometry is
- * the one they were compiled for, the compiler launch is skipped; in every other case (stamp 0, another forest evaluated in
- * between, another dataset shape, another division mode ...) the call compiles as usual.  Results are identical either way.
- * The caller vouches only for "these are the rows that pass built, unmodified" (evogp_amd/tree/forest.py checks the tensors'
- * data pointers and version counters).
- * evogp_hip_set_breed_compile: 0 = off (DEFAULT: _compiled then is evogp_hip_breed_lists and returns stamp 0), 1 = one fused
- * kernel, 2 = two-stream pipeline for >= 200 k rows.  Measured on MI355X the compiler's work costs the same time wherever it
- * runs (csrc/sr_tc.hip launch_breed_compiled has the numbers), so nothing is gained yet; environment: EVOGP_BREED_COMPILE.
- * Both modes are EXPERIMENTS: mode 2 only takes launches of EVOGP_BREED_COMPILE_PIPE_MIN rows and more (200 000; the variable is read
- * per call, the mode from the environment once per process), and a suite run with the experiments switched on globally has known
- * failures (profiles/r03q_pytest_experiments_on.log).  Likewise EVOGP_TC_HINTS=1 (history-driven launch skipping, csrc/sr_tc.hip):
- * results stay within the 1e-5 contract but are NOT bit-stable from call to call -- the one call that meets stale hints sums a marked
- * tree in another kernel's order.  Neither is on by default; neither is covered by the bit-reproducibility statements of this header. */
-int evogp_hip_set_breed_compile(int mode);
-int evogp_hip_breed_lists_compiled(int pop_size, int table_rows, int gp_len, int n_elite, int n_surv, const float *value,
-                                   const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
-                                   const int *rnd, unsigned mutate_below, const float *donor_value, const int16_t *donor_type,
-                                   const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
-                                   int *decisions, int row_begin, int row_count, unsigned long long *records_stamp,
-                                   evogp_stream_t stream);
-int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len, unsigned out_len,
-                                 int use_mse, const float *value, const int16_t *type, const int16_t *size,
-                                 const float *variables, const float *labels, float *fitnesses, unsigned kernel_type,
-                                 unsigned long long records_stamp, evogp_stream_t stream);
-/* ... and for a caller that also knows which functions can occur in the forest: bit f of function_mask = function id f
+/* evogp_hip_sr_fitness for a caller that knows which functions can occur in the forest: bit f of function_mask = function id f
  * (defs.h:10-57) may occur, 0 = unknown.  A fitness call is up to five launches of which three usually find nothing to do; a
  * forest of + - * / and the unary functions of at most 64 nodes per tree cannot leave a tree for the general compiler, so that
  * launch need not be made (5 -> 4 launches: 5-11 us per call).  Whatever a tree carries that the mask did not promise is still
@@ -198,13 +167,16 @@ int evogp_hip_sr_fitness_stamped(unsigned pop_size, unsigned data_points, unsign
 int evogp_hip_sr_fitness_hinted(unsigned pop_size, unsigned data_points, unsigned gp_len, unsigned var_len, unsigned out_len,
                                 int use_mse, const float *value, const int16_t *type, const int16_t *size,
                                 const float *variables, const float *labels, float *fitnesses, unsigned kernel_type,
-                                unsigned long long records_stamp, unsigned function_mask, evogp_stream_t stream);
+                                unsigned function_mask, evogp_stream_t stream);
+/* (Rounds 3-4 also shipped two opt-in experiments -- program records compiled ahead by the breeding pass under a stamp protocol
+ * (evogp_hip_breed_lists_compiled, evogp_hip_sr_fitness_stamped, evogp_hip_set_breed_compile) and history-driven launch skipping
+ * (EVOGP_TC_HINTS) -- that gained nothing measurable and, switched on globally, failed tests.  Round 5 removed both: ABI version 4.) */
 
 /* The same two passes with their random words computed in the kernels (no counterpart in the reference): word k of offspring i is
  * hash(seed, generation, k, i) -- exactly the numbers evogp_hip_random_words writes -- so no array of words is drawn, written and read
  * (one launch and 24 B per offspring less per generation), and the two generation keys are words (7, 0) and (7, 1) modulo 10^6.
  * evogp_hip_generate_masked_hashed generates the trees n whose word (4, n + tree_index_offset) is below active_below;
- * evogp_hip_breed_lists_hashed is evogp_hip_breed_lists_compiled without `rnd`.  Results equal those of the array forms fed with
+ * evogp_hip_breed_lists_hashed is evogp_hip_breed_lists without `rnd`.  Results equal those of the array forms fed with
  * evogp_hip_random_words(seed, generation, ...) bit for bit (tests/test_gpu_breed.py). */
 int evogp_hip_generate_masked_hashed(unsigned pop_size, unsigned gp_len, unsigned var_len, unsigned out_len,
                                      unsigned const_samples_len, float out_prob, float const_prob, const float *depth2leaf_probs,
@@ -215,8 +187,7 @@ int evogp_hip_breed_lists_hashed(int pop_size, int table_rows, int gp_len, int n
                                  const int16_t *type, const int16_t *size, const int *elite_rows, const int *parent_rows,
                                  long long seed, long long generation, unsigned mutate_below, const float *donor_value,
                                  const int16_t *donor_type, const int16_t *donor_size, float *value_res, int16_t *type_res,
-                                 int16_t *size_res, int *decisions, int row_begin, int row_count,
-                                 unsigned long long *records_stamp, evogp_stream_t stream);
+                                 int16_t *size_res, int *decisions, int row_begin, int row_count, evogp_stream_t stream);
 
 /* Counter-based random words for the breeding pass of a sharded run (no counterpart in the reference, which draws with
  * torch's generator): out[k][i] for k < rows, i in [lo, hi) = hash(seed, generation, k, i) mapped to [0, 2^31 - 1), the value
@@ -370,7 +341,7 @@ const char *evogp_hip_error_string(int code);
 int evogp_hip_set_sr_division(int mode);
 int evogp_hip_get_sr_division(void);
 
-/* ABI version of this header (3): bumped when a signature changes or an entry point is added. */
+/* ABI version of this header (4): bumped when a signature changes or an entry point is added. */
 int evogp_hip_abi_version(void);
 
 #ifdef __cplusplus

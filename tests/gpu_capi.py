@@ -70,13 +70,18 @@ def evaluate(value, type_, size, X, out_len):
     return res.cpu().numpy()
 
 
-def sr_fitness(value, type_, size, X, y, use_mse=True, kernel_type=0):
+def sr_fitness(value, type_, size, X, y, use_mse=True, kernel_type=0, func_mask=0):
+    """func_mask != 0: evogp_hip_sr_fitness_hinted with that function-set mask (what evogp_amd.tree.Forest.SR_fitness and bench.py call)"""
     pop, gp_len = value.shape
     a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32), dev(y, np.float32)]
     D, var_len = a[3].shape
     fit = torch.full((pop,), 12345.0, dtype=torch.float32, device=DEV)
-    rc = L.evogp_hip_sr_fitness(pop, D, gp_len, var_len, a[4].shape[1], int(use_mse), *[x.data_ptr() for x in a],
-                                fit.data_ptr(), kernel_type, _stream())
+    if func_mask:
+        rc = L.evogp_hip_sr_fitness_hinted(pop, D, gp_len, var_len, a[4].shape[1], int(use_mse), *[x.data_ptr() for x in a],
+                                           fit.data_ptr(), kernel_type, func_mask, _stream())
+    else:
+        rc = L.evogp_hip_sr_fitness(pop, D, gp_len, var_len, a[4].shape[1], int(use_mse), *[x.data_ptr() for x in a],
+                                    fit.data_ptr(), kernel_type, _stream())
     assert rc == 0, L.evogp_hip_error_string(rc)
     torch.cuda.synchronize()
     return fit.cpu().numpy()

@@ -450,93 +450,6 @@ def test_native_random_words_equal_the_python_definition(g):
     assert abs(float(random_words(5, 5, 6, 0, 200_000, "cpu").float().mean()) / 2**31 - 0.5) < 0.005
 
 
-@pytest.fixture(params=[1, 2], ids=["fused", "pipe"])
-def compile_ahead(request, monkeypatch):
-    """the breeding pass compiles ahead (off by default: it does not pay yet, csrc/sr_tc.hip launch_breed_compiled); mode 2 pipelines
-    from 200 k rows on -- lowered here"""
-    import evogp_amd
-    from evogp_amd import _lib
-
-    monkeypatch.setenv("EVOGP_BREED_COMPILE_PIPE_MIN", "1000")     # read once per process, at the first mode-2 launch
-    _lib.check(_lib.lib.evogp_hip_set_breed_compile(request.param), "set_breed_compile")
-    yield request.param
-    _lib.check(_lib.lib.evogp_hip_set_breed_compile(0), "set_breed_compile")
-
-
-@pytest.mark.parametrize("funcs,D", [(["+", "-", "*", "/"], 1024), (["+", "-", "*", "/", "sin", "neg", "pow", "max"], 300), (["+", "*", "/"], 40)])
-def test_breeding_pass_compiles_ahead_and_stale_stamps_recompile(g, compile_ahead, funcs, D):
-    """the breeding pass compiles the rows it builds into the program records of the next tree_SR_fitness call
-    (csrc/sr_tc.hip breed_compile_group_kernel); a forest that presents the records' stamp skips the compiler launch.  The
-    fitness words must be those of an ordinary call, bit for bit — for compiled programs, for trees the compiler leaves to the
-    register kernels (pow) or to the general compiler (max), for every way a stamp can go stale."""
-    import torch
-
-    import evogp_amd  # noqa: F401
-    from evogp_amd.algorithm import DefaultCrossover, DefaultMutation, DefaultSelection, GeneticProgramming
-    from evogp_amd.tree import Forest, GenerateDescriptor
-
-    dev = torch.device("cuda", 0)
-    desc = GenerateDescriptor(max_tree_len=64, input_len=5, output_len=1, using_funcs=funcs, max_layer_cnt=5, const_samples=[-1.0, 0.5, 2.0])
-    pop = 20_000
-    gen = torch.Generator().manual_seed(D)
-    X = (torch.rand(D, 5, generator=gen) * 4 - 2).to(dev)
-    y = (X[:, 0] * X[:, 1] - X[:, 2]).unsqueeze(1).contiguous()
-
-    def plain(forest):   # the same rows as a forest nobody compiled ahead
-        return Forest(forest.input_len, forest.output_len, forest.batch_node_value.clone(), forest.batch_node_type.clone(),
-                      forest.batch_subtree_size.clone())
-
-    def same(a, b, what):
-        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), what
-
-    algo = GeneticProgramming(Forest.random_generate(pop, desc, keys=torch.tensor([3, 9], dtype=torch.uint32, device=dev)),
-                              DefaultCrossover(), DefaultMutation(0.3, desc.update(max_layer_cnt=3)), DefaultSelection(0.3, elite_rate=0.01))
-    assert getattr(algo.forest, "_records", None) is None
-    for generation in range(4):
-        fit = -algo.forest.SR_fitness(X, y)
-        algo.step(torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit))
-        f = algo.forest
-        assert f._records is not None and f._records[0] > 0, "the breeding pass did not compile its rows"
-        want = plain(f).SR_fitness(X, y)                       # ordinary call (this also overwrites the engine's records ...)
-        # ... so the stamp is stale now: the call below must notice and compile
-        same(f.SR_fitness(X, y), want, f"generation {generation}: stale stamp (another forest was evaluated in between)")
-    # a fresh stamp that is honoured: breed, then evaluate the bred forest FIRST
-    fit = -algo.forest.SR_fitness(X, y)
-    algo.step(torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit))
-    f = algo.forest
-    evogp_amd._lib.check(evogp_amd._lib.lib.evogp_hip_debug_profile(1), "profile on")
-    ahead = f.SR_fitness(X, y)
-    import ctypes
-    st = (ctypes.c_float * 3)(); nc = ctypes.c_int(0)
-    evogp_amd._lib.lib.evogp_hip_debug_profile_read(st, ctypes.byref(nc)); evogp_amd._lib.lib.evogp_hip_debug_profile(0)
-    same(ahead, plain(f).SR_fitness(X, y), "records compiled ahead vs an ordinary call")
-    print(f"compiled ahead: compiler stage {st[0] * 1e3:.1f} us, interpreter {st[1] * 1e3:.1f} us")
-    # another dataset shape: the records were compiled for the old geometry -> recompiled
-    fit = -algo.forest.SR_fitness(X, y)
-    algo.step(torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit))
-    f = algo.forest
-    X2 = torch.cat([X, X[: max(1, D // 3)] * 0.5]); y2 = torch.cat([y, y[: max(1, D // 3)]])
-    same(f.SR_fitness(X2, y2), plain(f).SR_fitness(X2, y2), "another dataset shape")
-    # an in-place edit of the forest: the version counter moves, the stamp is dropped
-    fit = -algo.forest.SR_fitness(X, y)
-    algo.step(torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit))
-    f = algo.forest
-    f.batch_node_value[:, 0].mul_(1.0)          # no change of value, but an in-place write
-    keep = f._records
-    f.batch_node_type[5, 0] = 1; f.batch_node_value[5, 0] = 42.0; f.batch_subtree_size[5, 0] = 1    # tree 5 is now the constant 42
-    got = f.SR_fitness(X, y)
-    assert f._records is None and keep is not None
-    same(got, plain(f).SR_fitness(X, y), "edited in place")
-    assert abs(float(got[5]) - float(((42.0 - y[:, 0]) ** 2).mean())) < 1e-3 * float(got[5])
-    # a stamp presented for rows of another population size is ignored by the engine
-    half = Forest(f.input_len, f.output_len, f.batch_node_value[: pop // 2].contiguous(), f.batch_node_type[: pop // 2].contiguous(),
-                  f.batch_subtree_size[: pop // 2].contiguous())
-    fit = -algo.forest.SR_fitness(X, y)
-    algo.step(torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit))
-    half.set_compiled_records(algo.forest._records[0])
-    same(half.SR_fitness(X, y), plain(half).SR_fitness(X, y), "stamp of another population size")
-
-
 def test_hashed_words_equal_the_array_forms(g, oracle):
     """evogp_hip_generate_masked_hashed / evogp_hip_breed_lists_hashed compute the counter-based words in the kernels; fed the
     words evogp_hip_random_words writes for the same (seed, generation), the array forms must build the same rows bit for bit —
