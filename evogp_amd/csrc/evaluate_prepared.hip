@@ -157,8 +157,9 @@ hipError_t launch_eval_marked_general(unsigned pop, unsigned gp_len, unsigned va
 // find their leaf operands through the subtree sizes -- but with the tree in REGISTERS (cross-lane permutes instead of scattered
 // global gathers), evaluates every OUT node at once (lane = node; the tree's input row sits in the lanes of one register) and adds
 // the values to their outputs in execution order (higher node index first, forward.cu:239-240).  Same operations in the same order
-// as the stack interpreter and the prepared pass: the same bits.  Trees of more than 64 nodes, with node types outside the five
-// classes or with subtree sizes that do not describe them are marked for the stack interpreter (launched behind this kernel).
+// as the stack interpreter and the prepared pass: the same bits.  Trees of more than 64 nodes take the same reading chunk by chunk from
+// memory (round 5); trees with node types outside the five classes or with subtree sizes that do not describe them are marked for the
+// stack interpreter (launched behind this kernel).
 __global__ __launch_bounds__(256) void eval_direct_kernel(PreparedParams q, const float *value, const int16_t *type, const int16_t *size, int gp_len) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -187,8 +188,71 @@ __global__ __launch_bounds__(256) void eval_direct_kernel(PreparedParams q, cons
         fetch(t + nwaves);
         float *res = q.results + (size_t)t * q.out_len;
         len = len < 0 ? 0 : (len > gp_len ? gp_len : len);
-        if (len > 64) {   // (rows of up to 1024 nodes exist; the stack interpreter takes them)
-            if (lane == 0) res[0] = bits2f(kSentinelDeepEvalP);
+        if (len > 64) {
+            // A tree of more than 64 nodes (rows of up to 1024 exist; example/brax_task.py: max_tree_len 256): the same reading chunk by
+            // chunk, last chunk first (execution order), operands gathered from the row in memory the way eval_prepare_kernel does, the
+            // per-output sums carried from chunk to chunk in lane o.  (Round 4 marked these trees for the one-tree-per-wave stack
+            // interpreter on a grid of 2 x CUs workgroups: an evolved population of long rows ran almost entirely there -- ADVICE r04.)
+            const size_t row = (size_t)t * gp_len;
+            int carry_h = 0;
+            bool lbad = false, lfall = false;
+            float mine = 0.0f;
+            for (int c = (len + 63) / 64 - 1; c >= 0; --c) {
+                const int i = c * 64 + lane;
+                const bool in = i < len;
+                const int ty = in ? (int)type[row + i] : (int)T_CONST;
+                const float val = in ? value[row + i] : 0.0f;
+                const int sz = in ? (int)size[row + i] : 1;
+                const int cls = ty & T_MASK;
+                const int arity = cls <= T_CONST ? 0 : (cls <= T_TFUNC ? cls - 1 : 3);
+                if (__any(in && cls > T_TFUNC)) lfall = true;
+                const int delta = in ? 1 - arity : 0;
+                const int incl = wave_scan_incl(delta);
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                if (__any(in && carry_h + tot - (incl - delta) < 1)) lbad = true;
+                carry_h += tot;
+                const Decoded d = decode_node(ty, val, true, q.var_len, q.out_len);
+                int ci = i + 1, sum = 1;
+                bool ok = true;
+                float opnd[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {   // (the variable's value comes through a permute: every lane runs it)
+                    int sc = 0, lt = T_CONST;
+                    float lv = 0.0f;
+                    const bool want = in && a < arity && ok;
+                    if (want) {
+                        sc = ci < len ? (int)size[row + ci] : 0;
+                        if (sc < 1 || ci + sc > len) ok = false;
+                        else { const int leaf = ci + sc - 1; lt = (int)type[row + leaf] & T_MASK; lv = value[row + leaf]; }
+                    }
+                    int v = (int)lv;
+                    v = v < 0 ? 0 : (v >= q.var_len ? q.var_len - 1 : v);
+                    const float xv = bits2f((uint32_t)bperm((int)f2bits(xrow), v));
+                    if (want && ok) {
+                        if (lt > T_CONST) ok = false;
+                        else { opnd[a] = lt == T_CONST ? lv : xv; sum += sc; ci += sc; }
+                    }
+                }
+                if (__any(in && (!ok || sz != sum))) lfall = true;
+                const bool adds = in && arity > 0 && ok && d.pay != kNoOut && d.op != H_UN_ZERO && d.op != H_BIN_ZERO;
+                float r = 0.0f;
+                if (adds) r = prepared_apply(d.op, opnd[0], opnd[1], opnd[2]);
+                for (int o = 0; o < q.out_len; ++o) {
+                    unsigned long long m = __ballot(adds && d.pay == (uint32_t)o);
+                    if (m == 0ull) continue;
+                    float acc = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(mine), o));
+                    while (m) {
+                        const int hi = 63 - __builtin_clzll(m);
+                        m &= ~(1ull << hi);
+                        acc += bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(r), hi));
+                    }
+                    if (lane == o) mine = acc;
+                }
+            }
+            if (carry_h != 1) lbad = true;
+            if (lbad || lfall) {
+                for (int o = lane; o < q.out_len; o += 64) res[o] = (!lbad && o == 0) ? bits2f(kSentinelDeepEvalP) : __builtin_nanf("");
+            } else if (lane < q.out_len) res[lane] = mine;
             continue;
         }
         const bool in = lane < len;

@@ -147,11 +147,11 @@ def test_evaluate_arith_bit_exact(g, oracle, rng, out_len):
     assert np.array_equal(fbits(g.evaluate(*forest, X, out_len)), fbits(oracle.evaluate(*forest, X, out_len)))
 
 
-@pytest.mark.parametrize("pop,L,out_len,var_len,mlc", [(5003, 128, 6, 17, 7), (777, 64, 64, 64, 6), (20001, 64, 3, 5, 6), (9, 16, 2, 3, 3), (1001, 256, 10, 30, 5)])
+@pytest.mark.parametrize("pop,L,out_len,var_len,mlc", [(5003, 128, 6, 17, 7), (777, 64, 64, 64, 6), (20001, 64, 3, 5, 6), (9, 16, 2, 3, 3), (1001, 256, 10, 30, 5), (2001, 256, 6, 17, 8)])
 def test_evaluate_multi_output_trees_share_the_passes_of_a_wave(g, oracle, rng, pop, L, out_len, var_len, mlc):
-    """tree_evaluate on multi-output trees: several trees per wave pass (evaluate_prepared.hip eval_direct_packed_kernel) -- populations
-    that are no multiple of the batch, as many outputs as accumulator slots (one tree per pass), rows of more than 64 nodes (the
-    stack interpreter takes those trees), rows without a tree, a truncated tree and a subtree size that does not add up."""
+    """tree_evaluate on multi-output trees: one wave per tree, every OUT node at once (evaluate_prepared.hip eval_direct_kernel) --
+    populations that are no multiple of the workgroup, as many outputs as lanes, trees of more than 64 nodes (the same reading chunk
+    by chunk, round 5), rows without a tree, a truncated tree and a subtree size that does not add up (the stack interpreter)."""
     forest = oracle.generate(pop, L, var_len, out_len, 0.5, 0.5, [pop % 97, L], depth2leaf(mlc), roulette_uniform(ARITH), CS3)
     v, t, s = (a.copy() for a in forest)
     bad = []
