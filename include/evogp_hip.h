@@ -258,14 +258,15 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
 /* Engine-owned device memory (no counterpart in the reference, whose kernels keep a private copy of the tree per thread,
  * forward.cu:284-287).  evogp_hip_sr_fitness compiles every tree into PROGRAM RECORDS that its interpreter kernel reads: one
  * buffer per device, allocated with hipMalloc on first use, grown on demand (never while a HIP graph is being captured),
- * reused by every later call on that device and invisible to the caller's allocator.  Size law:
+ * reused by every later eager call on that device and invisible to the caller's allocator; calls recorded into HIP graphs share a
+ * second buffer of the same law that eager calls never touch (at most two population-sized buffers per device: round 5).  Size law:
  *     bytes = ceil(pop_size * 256 / 4096) * 4096 * max(2, ceil((gp_len + 2) / 31))    (+ 1/8 slack when it grows)
  * i.e. 768 MB for 1 M trees of gp_len 64 (three arrays of records; two up to gp_len 60), 8.7 GB for 1 M trees of gp_len 1024.
  * A single-output forest of gp_len <= 64 whose function mask (evogp_hip_sr_fitness_hinted) holds no unary function has programs of at
  * most 32 words: ONE array, 256 MB at 1 M trees (round 4).
  *   evogp_hip_set_program_buffer_limit  caps the buffer (default 16 GiB): a call that would need more runs on the register
  *                                       interpreters instead (same results, 3-6x slower); 0 disables the compiled path.
- *   evogp_hip_program_buffer_bytes      bytes currently held on the current device.
+ *   evogp_hip_program_buffer_bytes      bytes currently held on the current device (the eager buffer + the graphs').
  *   evogp_hip_release_workspaces        waits for the current device and frees the buffer (and the rings below); the next
  *                                       fitness call allocates again.
  * Round 4: a call whose trees cannot need the general program compiler (single output, gp_len <= 64, a dataset that fits LDS, and

@@ -50,6 +50,21 @@ calib)      # known-byte-count reads: what does FETCH_SIZE report for 2-, 4- and
   python $R/scripts/rocpd_summary.py $(find $OUT/calib_$TAG -name "*.db" | head -1) 2>&1 | grep -i "counter\|---\|calib_read" > $OUT/${TAG}_06_calib.md
   rm -rf $OUT/calib_$TAG; cd $R
   cat $OUT/${TAG}_06_calib.md | cut -c1-200 ;;
+opspmc)     # the HBM-bound operators under FETCH_SIZE / WRITE_SIZE (scripts/ops_pmc.py) -> ${TAG}_07_ops_pmc.md
+  cd /tmp
+  export OPS_JSON=$OUT/${TAG}_07_ops.json ROCPD_BY_GRID=1
+  for set in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/opspmc_$TAG$set -o pmc -- python $R/scripts/ops_pmc.py run > $OUT/${TAG}_07_ops_$set.log 2>&1
+    python $R/scripts/rocpd_summary.py $(find $OUT/opspmc_$TAG$set -name "*.db" | head -1) > $OUT/${TAG}_07_ops_$set.md 2>&1
+    rm -rf $OUT/opspmc_$TAG$set
+  done
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/opspmc_${TAG}st -o tr -- python $R/scripts/ops_pmc.py run > $OUT/${TAG}_07_ops_stats.log 2>&1
+  python $R/scripts/rocpd_summary.py $(find $OUT/opspmc_${TAG}st -name "*.db" | head -1) > $OUT/${TAG}_07_ops_stats.md 2>&1
+  rm -rf $OUT/opspmc_${TAG}st
+  unset ROCPD_BY_GRID
+  cd $R
+  python scripts/ops_pmc.py table $OUT/${TAG}_07_ops_FETCH_SIZE.md $OUT/${TAG}_07_ops_WRITE_SIZE.md $OUT/${TAG}_07_ops_stats.md $OPS_JSON > $OUT/${TAG}_07_ops_pmc.md 2>&1
+  cat $OUT/${TAG}_07_ops_pmc.md | cut -c1-260 ;;
 pytest:*)    # pytest:<file or node id> [-k expr]
   s=${step#pytest:}; n=$(basename ${s%% *} .py)
   timeout 1800 python -m pytest $s -m gpu -q -x > $OUT/${TAG}_01_pytest_$n.log 2>&1; echo "pytest rc=$?" >> $OUT/${TAG}_01_pytest_$n.log

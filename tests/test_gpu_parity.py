@@ -509,6 +509,24 @@ def test_sr_fitness_repeated_calls_streams_and_graph_replay(g, oracle, rng):
     call(out, cap); call(out, main)
     torch.cuda.synchronize()
     assert_close_classes(out.cpu().numpy(), want, RTOL_ARITH, 0.0, "after capture")
+    # a capture per generation with eager calls in between (a new forest every generation means a new capture): the engine holds one
+    # record buffer for eager calls and one for the graphs, however often the two alternate (round 4 leaked one per alternation)
+    import evogp_amd
+    held = evogp_amd.program_buffer_bytes()
+    graphs = []
+    for i in range(5):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(gr, stream=cap):
+                call(gout, torch.cuda.current_stream())
+        graphs.append(gr)
+        call(out, main)
+        gout.fill_(555.0)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert_close_classes(gout.cpu().numpy(), want, RTOL_ARITH, 0.0, f"capture {i} of the alternation")
+        assert_close_classes(out.cpu().numpy(), want, RTOL_ARITH, 0.0, f"eager call {i} of the alternation")
+    assert evogp_amd.program_buffer_bytes() == held, "record memory grew while captures and eager calls alternated"
 
 
 def test_graph_replay_survives_a_later_call_that_grows_the_record_buffer(g, oracle, rng):
