@@ -413,8 +413,14 @@ def test_library_functions_in_the_threaded_code(g, oracle, rng, funcs, out_len):
     be = g.batch_evaluate(*forest, X, out_len).astype(np.float64)
     with np.errstate(all="ignore"):
         ref = ((be - y[None, :, :].astype(np.float64)) ** 2).sum(2).mean(1)
-    both = np.isfinite(ref) & ok & (np.abs(ref) < 1e30)
-    assert np.allclose(got[both], ref[both], rtol=2e-5, atol=1e-30), "threaded code vs the register kernels on the same trees"
+    both = np.isfinite(ref) & ok & (np.abs(ref) < 1e30) & ~unstable
+    # (2e-5, or the tree's own sensitivity to 3-ulp changes of its library calls: the threaded code's compiler decides pow(x, 1),
+    # pow(x, -1) ... with the correctly rounded value where the library's powf is within an ulp of it, sr_tc.hip pow_fold_kind)
+    err = np.abs(got[both].astype(np.float64) - ref[both])
+    grant = np.maximum(2e-5 * np.abs(ref[both]) + 1e-30, tol[both])
+    worst = int(np.argmax(err - grant))
+    assert (err <= grant).all(), (f"threaded code vs the register kernels on the same trees: tree {np.flatnonzero(both)[worst]} {got[both][worst]!r} "
+                                  f"vs {ref[both][worst]!r}, granted {grant[worst]:.3g}; {(err > grant).sum()} trees beyond")
 
 
 # ---- small datasets: one row per lane (the K = 1 interpreter) --------------------------------------------------------------
