@@ -142,6 +142,63 @@ def test_every_program_compiler_gives_the_same_fitness_words(g, oracle, rng, mas
         assert_close_classes(got[keep], oracle.sr_fitness(v, t, s, X, y, True)[keep], RTOL, what=f"packed compilers, masked={masked}")
 
 
+@pytest.mark.parametrize("funcs,out_len,L,exact", [(EXACT_WIDE, 1, 64, True), (EXACT_WIDE, 1, 128, True), ([ADD, SUB, MUL, DIV, POW, LPOW, SINH, COSH, TANH, IF, MAX], 1, 64, False),
+                                                   (EXACT_WIDE, 4, 64, True), (EXACT_WIDE, 10, 128, True), ([ADD, MUL, POW, LPOW, TANH, SINH, IF, EXP], 3, 64, False)],
+                         ids=["exact", "exact-L128", "library", "mo4", "mo10-L128", "mo3-library"])
+def test_generic_and_multi_output_lines_of_the_packed_compiler(g, oracle, rng, funcs, out_len, L, exact):
+    """Round 5: the packed compiler's generic line (functions behind the generic stubs: csrc/sr_tc.hip compile_pack_generic) and its
+    multi-output line (compile_pack_mo) against tc_compile_general_kernel, one tree per wave pass (evogp_hip_debug_compile_batch(0)):
+    the same fitness WORDS -- on forests with rows without a tree, a subtree size that does not add up, a row that does not parse, OUT
+    indices beyond out_len, "no function" nodes, a population that is no multiple of a batch.  IEEE-exact function sets are also held
+    against the oracle; sets with library functions within their sensitivity envelope."""
+    from evogp_amd import _lib
+
+    pop, V = 20011, 5
+    stored_outs = max(out_len + 2, 2) if out_len > 1 else 1
+    v, t, s = oracle.generate(pop, L, V, stored_outs, 0.6 if out_len > 1 else 0.0, 0.5, [L, out_len], depth2leaf(7 if L > 64 else 5, 0.15), roulette_uniform(funcs), CS)
+    v, t, s = v.copy(), t.copy(), s.copy()
+    s[17, 0] = 0; s[18, 0] = -3; s[40000 % pop, 0] = 0          # rows without a tree: NaN
+    r = int(np.nonzero(s[:, 0] >= 5)[0][0]); s[r, 1] += 1        # a subtree size that does not add up: the register kernels
+    trunc = int(np.nonzero(s[:, 0] >= 7)[0][3]); s[trunc, 0] -= 2   # a truncated tree: it does not parse (NaN; the reference reads beyond it)
+    nofn = 0
+    for r in np.nonzero((s[:, 0] < min(L, 64) - 2) & (s[:, 0] >= 1))[0][200:240]:   # "no function" (unary, id 29) over whole trees
+        n = int(s[r, 0])
+        v[r, 1:n + 1] = v[r, :n].copy(); t[r, 1:n + 1] = t[r, :n].copy(); s[r, 1:n + 1] = s[r, :n].copy()
+        v[r, 0] = 29.0; t[r, 0] = 2; s[r, 0] = n + 1
+        nofn += 1
+    assert nofn >= 30
+    if L > 64:
+        assert (s[:, 0] > 64).sum() > 5, "no tree beyond 64 nodes: the long-row case is not covered"
+    X = rng.uniform(0.2, 2.5, (300, V)).astype(np.float32); y = rng.uniform(-3, 3, (300, out_len)).astype(np.float32)
+    words, skipped = {}, {}
+    try:
+        for batch in (0, 8, 32, -1):
+            assert _lib.lib.evogp_hip_debug_compile_batch(batch) == 0
+            words[batch] = g.sr_fitness(v, t, s, X, y).view(np.uint32).copy()
+            skipped[batch] = handler_histogram(g, pop)["skip"]
+    finally:
+        _lib.lib.evogp_hip_debug_compile_batch(-1)
+    for batch, w in words.items():
+        diff = np.nonzero(w != words[0])[0]
+        if exact or out_len > 1:   # (multi-output programs are the same words; so are single-output ones of IEEE-exact functions)
+            assert len(diff) == 0, f"batch {batch}: {len(diff)} fitness words differ from the general compiler's, first trees {diff[:5]}: {w[diff[:5]]} vs {words[0][diff[:5]]}"
+        else:   # constants under library functions are folded at one level more than compile_general folds them: the library's value either way
+            a, b = w.view(np.float32).astype(np.float64), words[0].view(np.float32).astype(np.float64)
+            fin = np.isfinite(a) & np.isfinite(b)
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.allclose(a[fin], b[fin], rtol=1e-4, atol=1e-30), f"batch {batch} against the general compiler"
+            assert len(diff) <= 0.02 * pop, f"batch {batch}: {len(diff)} fitness words differ from the general compiler's"
+        assert skipped[batch] <= skipped[0] + 2, f"batch {batch}: {skipped[batch]} trees left to the register kernels, {skipped[0]} by the general compiler"
+    got = words[-1].view(np.float32)
+    assert np.isnan(got[[17, 18, 40000 % pop, trunc]]).all()
+    keep = np.ones(pop, bool); keep[[17, 18, 40000 % pop, trunc]] = False
+    if exact:
+        assert_close_classes(got[keep], oracle.sr_fitness(*(a[keep] for a in (v, t, s)), X, y, True), RTOL, what=f"packed lines, out_len={out_len}")
+    else:
+        fo = tuple(a[keep] for a in (v, t, s))
+        want, tol, unstable = per_tree_tolerance(oracle, fo, X, y)
+        assert_within_sensitivity(got[keep], want, tol, unstable, f"packed lines with library functions, out_len={out_len}", max_unstable=0.15, min_tight=0.2)
+
+
 def _leaning_forest(rng, pop, L, var_len, funcs, right_funcs, lean_left=True, max_levels=60):
     """trees that lean to one side: level k is f_k(level k - 1, small) (lean_left) or f_k(small, level k - 1), `small` a function of two
     leaves.  In the interpreter's order -- the LAST operand first -- a left-leaning tree keeps one value per level on the operand
