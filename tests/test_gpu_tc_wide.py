@@ -189,8 +189,12 @@ def test_generic_and_multi_output_lines_of_the_packed_compiler(g, oracle, rng, f
             assert len(diff) <= 0.02 * pop, f"batch {batch}: {len(diff)} fitness words differ from the general compiler's"
         assert skipped[batch] <= skipped[0] + 2, f"batch {batch}: {skipped[batch]} trees left to the register kernels, {skipped[0]} by the general compiler"
     got = words[-1].view(np.float32)
-    assert np.isnan(got[[17, 18, 40000 % pop, trunc]]).all()
-    keep = np.ones(pop, bool); keep[[17, 18, 40000 % pop, trunc]] = False
+    # (with IF in the set a tree of seven levels can outgrow the row: the generator then announces more nodes than the row holds, the
+    # engine answers NaN for the cut-off tree, the reference reads on into the next row)
+    cut = np.nonzero(s[:, 0] > L)[0]
+    gone = np.concatenate([[17, 18, 40000 % pop, trunc], cut]).astype(np.int64)
+    assert np.isnan(got[gone]).all()
+    keep = np.ones(pop, bool); keep[gone] = False
     if exact:
         assert_close_classes(got[keep], oracle.sr_fitness(*(a[keep] for a in (v, t, s)), X, y, True), RTOL, what=f"packed lines, out_len={out_len}")
     else:
