@@ -307,6 +307,10 @@ int evogp_hip_debug_profile_read(float *stage_ms /* [3] */, int *calls);
  * compiler, 8 / 16 / 32 / 64 = the packed compiler with that many trees per wave.  The fitness words do not depend on the choice
  * (tests/test_gpu_tc_wide.py compares them bit for bit).  The environment variable EVOGP_TC_PACKED sets the same before the first call. */
 int evogp_hip_debug_compile_batch(int trees);
+/* Which compiler takes single-output trees of MORE than 64 nodes over + - * / and the unary functions with handlers of their own (tests
+ * and A/B measurements): 1 = the straight-line staged compiler of round 5 (DEFAULT; csrc/sr_tc.hip compile_long_arith), 0 = the general
+ * compiler's staged passes, as every other long tree; -1 = back to the default / the environment (EVOGP_TC_LONG_FAST).  Same fitness words. */
+int evogp_hip_debug_long_compiler(int fast);
 
 /* Handler histogram of the program records the most recent evogp_hip_sr_fitness call on the current device compiled:
  * device_hist[flavour * N + id] = number of program words with that handler among the first `pop` trees, N =

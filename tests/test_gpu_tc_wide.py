@@ -130,8 +130,12 @@ def test_every_program_compiler_gives_the_same_fitness_words(g, oracle, rng, mas
         for batch in (0, 8, 16, 32, 64, -1):
             assert _lib.lib.evogp_hip_debug_compile_batch(batch) == 0
             words[batch] = forest.SR_fitness(Xd, yd).cpu().numpy().view(np.uint32).copy()
+        if L > 64:   # trees of more than 64 nodes: the general compiler's staged passes against the straight-line staged compiler (round 5)
+            assert _lib.lib.evogp_hip_debug_long_compiler(0) == 0
+            words["long trees through compile_general"] = forest.SR_fitness(Xd, yd).cpu().numpy().view(np.uint32).copy()
     finally:
         _lib.lib.evogp_hip_debug_compile_batch(-1)
+        _lib.lib.evogp_hip_debug_long_compiler(-1)
     for batch, w in words.items():
         diff = np.nonzero(w != words[0])[0]
         assert len(diff) == 0, f"batch {batch}: {len(diff)} fitness words differ from the one-tree compiler's, first tree {diff[:5]}"
@@ -238,12 +242,14 @@ def _leaning_forest(rng, pop, L, var_len, funcs, right_funcs, lean_left=True, ma
     return v, t, s
 
 
+@pytest.mark.parametrize("arith_only", [False, True], ids=["generic", "arith"])
 @pytest.mark.parametrize("lean_left", [True, False], ids=["left", "right"])
-def test_leaning_trees_deeper_than_the_register_stack_are_reordered(g, oracle, rng, lean_left):
+def test_leaning_trees_deeper_than_the_register_stack_are_reordered(g, oracle, rng, lean_left, arith_only):
     """Left-leaning trees of up to 60 levels need up to 60 operand-stack entries in the interpreter's order; compile_general's second
     pass (the larger subtree of a binary function first, SWAP in front of a non-commutative function whose operands came in the
     other order) keeps every one of them in the threaded code: no SKIP records, SWAP words present, the oracle's values."""
-    funcs = [ADD, SUB, MUL, DIV, MAX, LT, LDIV]
+    # (arith: + - * / alone -- the straight-line staged compiler of round 5, compile_long_arith; generic: compile_general's passes)
+    funcs = [ADD, SUB, MUL, DIV] if arith_only else [ADD, SUB, MUL, DIV, MAX, LT, LDIV]
     forest = _leaning_forest(rng, 1500, 256, 5, funcs, [ADD, SUB, MUL, DIV], lean_left=lean_left)
     X = rng.uniform(-3, 3, (700, 5)).astype(np.float32); y = rng.uniform(-3, 3, (700, 1)).astype(np.float32)
     h = check(g, oracle, forest, X, y, f"leaning {'left' if lean_left else 'right'}", max_skipped=0.0)
