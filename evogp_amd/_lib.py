@@ -53,6 +53,7 @@ PROTOTYPES = {
     "evogp_hip_debug_profile_read": [C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "evogp_hip_debug_tc_histogram": [_u, _vp, _i, _vp],
     "evogp_hip_debug_tc_nhandlers": [],
+    "evogp_hip_debug_tc_program": [_u, _vp, _i],
     "evogp_hip_set_sr_division": [C.c_int],
     "evogp_hip_get_sr_division": [],
     "evogp_hip_abi_version": [],

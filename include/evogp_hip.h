@@ -318,6 +318,9 @@ int evogp_hip_debug_long_compiler(int fast);
  * (written by csrc/gen/gen_tc_asm.py).  bench.py derives the VALU-issue roofline of the interpreter from it. */
 int evogp_hip_debug_tc_histogram(unsigned pop, unsigned long long *device_hist, int hist_len, evogp_stream_t stream);
 int evogp_hip_debug_tc_nhandlers(void);
+/* The program of one tree as that call compiled it (diagnostics; waits for the device): up to max_words pairs {word 0, word 1} in execution
+ * order, NEXT words followed; returns the number of words (END / SKIP included), -1 on error. */
+int evogp_hip_debug_tc_program(unsigned tree, unsigned *host_words, int max_words);
 
 /* Human-readable text for a return code of any function above. */
 const char *evogp_hip_error_string(int code);

@@ -17,7 +17,7 @@ def main():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     if BY_GRID:
-        name_col = f"({name_col} || ' [grid ' || grid_x || ']')"
+        name_col = f"({name_col} || ' [grid ' || grid_x || ' lds ' || lds_size || ']')"
     rows = cur.execute(f"select {name_col}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
                        "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                        "max(workgroup_x), max(grid_x) from kernels group by 1 order by 3 desc").fetchall()
@@ -29,7 +29,7 @@ def main():
                    f"{r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]} | {r[11]} | {r[12]} |")
     try:
         if BY_GRID:
-            pm = cur.execute("select (p.name || ' [grid ' || k.grid_x || ']'), p.counter_name, count(*), sum(p.counter_value) from pmc_events p "
+            pm = cur.execute("select (p.name || ' [grid ' || k.grid_x || ' lds ' || k.lds_size || ']'), p.counter_name, count(*), sum(p.counter_value) from pmc_events p "
                              "join kernels k on k.dispatch_id = p.dispatch_id and k.guid = p.guid group by 1,2 order by 1,2").fetchall()
         else:
             pm = cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events group by 1,2 order by 1,2").fetchall()

@@ -209,3 +209,15 @@ def test_evolved_uci_sr_population_stays_in_the_threaded_code(g, oracle):
     fin = stable & np.isfinite(want) & np.isfinite(got[pick])
     beyond = np.abs(got[pick][fin].astype(np.float64) - want[fin].astype(np.float64)) > tol[fin]
     assert beyond.mean() <= 5e-3, (int(beyond.sum()), int(fin.sum()))
+    # the same trees ten times over (60 000 trees: several rounds of the long-tree compiler's workgroups, whose waves run out of step --
+    # round 5 found marked trees that no wave took there): every copy gets its tree's word, from the straight-line compiler of the long
+    # trees (csrc/sr_tc.hip tc_compile_long_kernel) and from the general compiler's passes
+    big = tuple(np.tile(a, (10, 1)) for a in trees)
+    try:
+        for fast in (1, 0):
+            assert _lib.lib.evogp_hip_debug_long_compiler(fast) == 0
+            w = g.sr_fitness(*big, X, y).view(np.uint32).reshape(10, pop)
+            bad = np.nonzero((w != got.view(np.uint32)[None, :]).any(0))[0]
+            assert len(bad) == 0, (fast, len(bad), bad[:5], w[:, bad[:3]], got.view(np.uint32)[bad[:3]])
+    finally:
+        _lib.lib.evogp_hip_debug_long_compiler(-1)
