@@ -56,10 +56,16 @@ class GeneticProgramming:
             f"fitness shape should be ({self.forest.pop_size}, ), but got {fitness.shape}")
         if self.enable_pareto_front:
             self.pareto_front.update(fitness, self.forest)
-        if self._native_default_ok():
-            nxt = self._native_default_step(fitness)
+        plan = self._native_plan()
+        if plan is not None:
+            first, rest = plan
+            nxt = self._native_default_step(fitness, first)
             if nxt is not None:
-                return nxt
+                # the other mutation operators of the list, one launch each over the offspring rows (csrc/mutate_ops.hip): the elites
+                # -- the first rows -- are copied (genetic_programming.py:118-122: only the offspring mutate)
+                for op in rest:
+                    self.forest = op(self.forest, skip_rows=self._last_n_elite)
+                return self.forest
             # (a selection whose lists the fused pass cannot take -- nothing but elites, no parents: the composed operators below)
         lists = self.__dict__.pop("_replay_lists", None)   # (the selection was already drawn by the fused pass that handed back)
         elite_indices, survivor_indices = lists if lists is not None else self.selection(self.forest, fitness)
@@ -70,29 +76,39 @@ class GeneticProgramming:
         return self.forest
 
     # ---- fused default step ------------------------------------------------------------
-    def _native_default_ok(self) -> bool:
-        """DefaultCrossover + DefaultMutation on a device forest, under ANY selection operator: one selection (a single
-        launch for DefaultSelection; the operator's own torch program otherwise — its survivor list may repeat trees,
-        selection/tournament.py:59-133), one randint, masked donor generation and ONE breeding pass instead of ~90 small
-        launches and two host syncs (same distribution of offspring; the random words come from one torch.randint instead
-        of the reference's seven draws).  EVOGP_NATIVE_STEP=0 disables it."""
+    def _native_plan(self):
+        """DefaultCrossover on a device forest, under ANY selection operator, with DefaultMutation and / or the reference's other
+        mutation operators (alone or as a CombinedMutation list, e.g. example/brax_task.py:38-45): one selection (a single launch for
+        DefaultSelection; the operator's own torch program otherwise -- its survivor list may repeat trees, selection/tournament.py:
+        59-133), masked donor generation and ONE breeding pass instead of ~90 small launches and two host syncs, then one launch per
+        further mutation operator (same distributions; the random words are counter-based).  Returns (the DefaultMutation that leads the
+        list or None, the operators behind it), or None where the composed torch programs have to run.  EVOGP_NATIVE_STEP=0 disables it."""
         from .crossover import DefaultCrossover
-        from .mutation import DefaultMutation
+        from .mutation import CombinedMutation, DefaultMutation
         from .selection import DefaultSelection
 
-        if os.environ.get("EVOGP_NATIVE_STEP", "1") == "0":
-            return False
-        if type(self.crossover) is not DefaultCrossover or type(self.mutation) is not DefaultMutation:
-            return False
+        if os.environ.get("EVOGP_NATIVE_STEP", "1") == "0" or type(self.crossover) is not DefaultCrossover:
+            return None
         f = self.forest
-        if not f.batch_node_value.is_cuda or self.mutation.descriptor.max_tree_len != f.max_tree_len:
-            return False
-        if type(self.selection) is not DefaultSelection:
-            return True
-        n_elite, n_surv = self.selection.counts(f.pop_size)
-        return 0 <= n_elite < f.pop_size and 0 < n_surv <= f.pop_size
+        if not f.batch_node_value.is_cuda:
+            return None
+        ops = list(self.mutation.mutation_operator) if type(self.mutation) is CombinedMutation else [self.mutation]
+        first = ops[0] if ops and type(ops[0]) is DefaultMutation else None
+        rest = ops[1:] if first is not None else ops
+        if first is not None and first.descriptor.max_tree_len != f.max_tree_len:
+            return None
+        if any(not getattr(op, "takes_skip_rows", False) for op in rest):
+            return None   # (an operator of the caller's own: it sees the offspring forest alone, as the reference hands it over)
+        if rest and os.environ.get("EVOGP_NATIVE_MUTATION", "1") == "0":
+            return None
+        if type(self.selection) is DefaultSelection:
+            n_elite, n_surv = self.selection.counts(f.pop_size)
+            if not (0 <= n_elite < f.pop_size and 0 < n_surv <= f.pop_size):
+                return None
+        return first, rest
 
-    def _native_default_step(self, fitness: torch.Tensor) -> Forest:
+    def _native_default_step(self, fitness: torch.Tensor, mutation=None) -> Forest:
+        """selection + DefaultCrossover + `mutation` (a DefaultMutation, or None: no offspring mutates here) in one breeding pass"""
         f = self.forest
         dev = f.batch_node_value.device
         pop, L = f.pop_size, f.max_tree_len
@@ -133,13 +149,21 @@ class GeneticProgramming:
         if not hasattr(self, "_word_seed"):
             self._word_seed = int(torch.randint(0, 2**40, (1,)).item())
         self._steps = getattr(self, "_steps", 0) + 1
-        below = int(min(max(self.mutation.mutation_rate, 0.0), 1.0) * (2**31 - 1))
-        d = self.mutation.descriptor
+        self._last_n_elite = n_elite
         value, ntype, size = f._tensors()
-        donors = torch.ops.evogp_hip.tree_generate_masked_hashed(
-            n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob,
-            d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, self._word_seed, self._steps, below)
+        if mutation is not None:
+            below = int(min(max(mutation.mutation_rate, 0.0), 1.0) * (2**31 - 1))
+            d = mutation.descriptor
+            donors = torch.ops.evogp_hip.tree_generate_masked_hashed(
+                n_new, L, d.input_len, d.output_len, d.const_samples.shape[0], d.out_prob, d.const_prob,
+                d.depth2leaf_probs, d.roulette_funcs, d.const_samples, 0, self._word_seed, self._steps, below)
+            mask = Forest.join_masks(f.func_mask, d.func_mask)
+        else:   # no offspring mutates in the pass: the donor rows are never read
+            below = 0
+            donors = (torch.empty((n_new, L), dtype=torch.float32, device=dev), torch.empty((n_new, L), dtype=torch.int16, device=dev),
+                      torch.empty((n_new, L), dtype=torch.int16, device=dev))
+            mask = f.func_mask
         nv, nt, ns = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elites, parents, self._word_seed, self._steps,
                                                            below, *donors, 0, pop)
-        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns, func_mask=Forest.join_masks(f.func_mask, d.func_mask))
+        self.forest = Forest(f.input_len, f.output_len, nv, nt, ns, func_mask=mask)
         return self.forest

@@ -5,6 +5,7 @@ random subtree (``tree_generate`` with the mutation descriptor) spliced in at a 
 CPU and uploads it, default.py:43 — SURVEY.md §8f N2)."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -17,14 +18,42 @@ class BaseMutation:
         raise NotImplementedError
 
 
+# ---- one launch per operator (csrc/mutate_ops.hip, round 5) -------------------------------------------------------------------
+# On a device forest the reference's operators below DRAW and APPLY in one native launch: the random numbers are counter-based words of
+# (the operator's seed, its call count), the distributions are those of the reference's draws.  `skip_rows`: the first rows of the forest
+# are copied whatever is drawn -- GeneticProgramming.step hands over the whole next generation, elites first, instead of the offspring
+# alone.  The torch programs (`draw` + `apply`) stay: they are what reproduces the reference bit for bit from ITS draws
+# (tests/test_gpu_mutation_parity.py), the CPU path, and EVOGP_NATIVE_MUTATION=0.
+def _native(forest: Forest) -> bool:
+    return forest.batch_node_value.is_cuda and os.environ.get("EVOGP_NATIVE_MUTATION", "1") != "0"
+
+
+def _next_call(op):
+    """(seed, call): the seed once per operator object from torch's CPU generator (reproducible under torch.manual_seed, no device sync)"""
+    if not hasattr(op, "_word_seed"):
+        op._word_seed = int(torch.randint(0, 2**40, (1,)).item())
+        op._calls = 0
+    op._calls += 1
+    return op._word_seed, op._calls
+
+
+def _keep_rows(mask: torch.Tensor, skip_rows: int) -> torch.Tensor:
+    if skip_rows > 0:
+        mask = mask.clone()
+        mask[:skip_rows] = False
+    return mask
+
+
 class DefaultMutation(BaseMutation):
     def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor):
         self.mutation_rate = mutation_rate
         self.descriptor = descriptor
 
-    def __call__(self, forest: Forest) -> Forest:
+    takes_skip_rows = True
+
+    def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
         dev = forest.batch_node_value.device
-        mask = torch.rand(forest.pop_size, device=dev) < self.mutation_rate
+        mask = _keep_rows(torch.rand(forest.pop_size, device=dev) < self.mutation_rate, skip_rows)
         n_mut = int(mask.sum())
         if n_mut == 0:
             return forest
@@ -90,8 +119,16 @@ class HoistMutation(BaseMutation):
         ar = torch.arange(forest.pop_size, dtype=torch.int32, device=dev)
         return forest.crossover(ar, ar, torch.where(mask, p, -1).to(torch.int32), q.to(torch.int32))
 
-    def __call__(self, forest: Forest) -> Forest:
-        return self.apply(forest, *self.draw(forest))
+    takes_skip_rows = True
+
+    def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
+        if _native(forest):
+            seed, call = _next_call(self)
+            v, t, s, _ = torch.ops.evogp_hip.structural_mutate(1, float(self.mutation_rate), 0, bool(self.inner_is_offset), int(skip_rows), seed, call,
+                                                               *forest._tensors(), False)
+            return Forest(forest.input_len, forest.output_len, v, t, s, func_mask=forest.func_mask)
+        mask, p, inner = self.draw(forest)
+        return self.apply(forest, _keep_rows(mask, skip_rows), p, inner)
 
 
 class DeleteMutation(BaseMutation):
@@ -132,9 +169,16 @@ class DeleteMutation(BaseMutation):
         ar = torch.arange(n, dtype=torch.int32, device=dev)
         return forest.crossover(ar, ar, torch.where(mask, p, -1).to(torch.int32), q.to(torch.int32))
 
-    def __call__(self, forest: Forest) -> Forest:
+    takes_skip_rows = True
+
+    def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
+        if _native(forest):
+            seed, call = _next_call(self)
+            v, t, s, _ = torch.ops.evogp_hip.structural_mutate(0, float(self.mutation_rate), int(self.max_mutatable_size or 0), False, int(skip_rows), seed,
+                                                               call, *forest._tensors(), False)
+            return Forest(forest.input_len, forest.output_len, v, t, s, func_mask=forest.func_mask)
         mask, scores, child_u = self.draw(forest)
-        return self.apply(forest, mask, scores, child_u)
+        return self.apply(forest, _keep_rows(mask, skip_rows), scores, child_u)
 
 
 class InsertMutation(BaseMutation):
@@ -178,9 +222,11 @@ class InsertMutation(BaseMutation):
         res[idx] = out
         return res
 
-    def __call__(self, forest: Forest) -> Forest:
+    takes_skip_rows = True
+
+    def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
         mask, p, keys, u = self.draw(forest)
-        return self.apply(forest, mask, p, keys, u)
+        return self.apply(forest, _keep_rows(mask, skip_rows), p, keys, u)
 
 
 _warned_roulette = False
@@ -281,13 +327,27 @@ class MultiPointMutation(BaseMutation):
         value = torch.where(targets, fresh, forest.batch_node_value)
         return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size)
 
-    def __call__(self, forest: Forest) -> Forest:
-        mask, intensity_u, node_draws = self.draw(forest)
-        return self.apply(forest, self.targets(forest, mask, intensity_u), node_draws)
+    takes_skip_rows = True
+    _native_mode = 0   # csrc/mutate_ops.hip point_mutate_kernel: 0 multi-point, 1 single-point
+
+    def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
+        d = self.descriptor
+        if _native(forest) and d.roulette_ufuncs is not None:
+            seed, call = _next_call(self)
+            value = torch.ops.evogp_hip.point_mutate(self._native_mode, float(self.mutation_rate), float(self.mutation_intensity), bool(self.per_node),
+                                                     bool(self.modify_output), bool(self.fix_roulette), int(skip_rows), forest.input_len, forest.output_len,
+                                                     seed, call, *forest._tensors(), d.roulette_ufuncs, d.roulette_bfuncs, d.roulette_tfuncs, d.const_samples)
+            # (without fix_roulette a draw can write the invalid function id 29, single_point.py:70-90: the function set is no longer known)
+            mask = Forest.join_masks(forest.func_mask, d.func_mask) if self.fix_roulette else 0
+            return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size, func_mask=mask)
+        mask, second, node_draws = self.draw(forest)
+        return self.apply(forest, self.targets(forest, _keep_rows(mask, skip_rows), second), node_draws)
 
 
 class SinglePointMutation(MultiPointMutation):
     """One random node of a mutating tree is replaced by a random node of its own kind (single_point.py:43-126)."""
+
+    _native_mode = 1
 
     def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor, modify_output: bool = False, fix_roulette: bool = False):
         super().__init__(mutation_rate, descriptor, 1.0, modify_output, fix_roulette=fix_roulette)
@@ -333,13 +393,25 @@ class MultiConstMutation(BaseMutation):
         value = torch.where(targets, fresh, forest.batch_node_value)
         return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size)
 
-    def __call__(self, forest: Forest) -> Forest:
+    takes_skip_rows = True
+    _native_mode = 2   # csrc/mutate_ops.hip point_mutate_kernel: 2 multi-const, 3 single-const
+
+    def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
+        d = self.descriptor
+        if _native(forest) and d.roulette_ufuncs is not None:   # (the kernel's argument list wants the roulettes; the constant modes do not read them)
+            seed, call = _next_call(self)
+            value = torch.ops.evogp_hip.point_mutate(self._native_mode, float(self.mutation_rate), float(self.mutation_intensity), bool(self.per_node),
+                                                     False, False, int(skip_rows), forest.input_len, forest.output_len, seed, call,
+                                                     *forest._tensors(), d.roulette_ufuncs, d.roulette_bfuncs, d.roulette_tfuncs, d.const_samples)
+            return Forest(forest.input_len, forest.output_len, value, forest.batch_node_type, forest.batch_subtree_size, func_mask=forest.func_mask)
         mask, u, const_idx = self.draw(forest)
-        return self.apply(forest, self.targets(forest, mask, u), const_idx)
+        return self.apply(forest, self.targets(forest, _keep_rows(mask, skip_rows), u), const_idx)
 
 
 class SingleConstMutation(MultiConstMutation):
     """One random constant of a mutating tree is redrawn (single_const.py:39-98); trees without constants are unchanged."""
+
+    _native_mode = 3
 
     def __init__(self, mutation_rate: float, descriptor: GenerateDescriptor):
         super().__init__(mutation_rate, descriptor, 1.0)
@@ -368,9 +440,13 @@ class CombinedMutation(BaseMutation):
     def __init__(self, mutation_operator):
         self.mutation_operator = list(mutation_operator)
 
-    def __call__(self, forest: Forest) -> Forest:
+    @property
+    def takes_skip_rows(self) -> bool:
+        return all(getattr(op, "takes_skip_rows", False) for op in self.mutation_operator)
+
+    def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
         for op in self.mutation_operator:
-            forest = op(forest)
+            forest = op(forest, skip_rows=skip_rows) if skip_rows else op(forest)
         return forest
 
 

@@ -505,6 +505,49 @@ Tensor3 breed_rows_hashed(int64_t pop_size, int64_t gp_len, const Tensor &value,
                            donor_type, donor_size, row_begin, row_count);
 }
 
+// DeleteMutation (mode 0) / HoistMutation (mode 1) drawn and applied in one launch (include/evogp_hip.h evogp_hip_structural_mutate)
+std::tuple<Tensor, Tensor, Tensor, Tensor> structural_mutate(int64_t mode, double rate, int64_t max_size, bool inner_is_offset, int64_t skip_rows, int64_t seed,
+                                                             int64_t call, const Tensor &value, const Tensor &type, const Tensor &size, bool want_decisions) {
+    TORCH_CHECK(value.dim() == 2, "value must be a (pop, gp_len) tensor");
+    const int64_t pop = value.size(0), gp_len = value.size(1);
+    check_sizes(pop, gp_len);
+    const c10::Device dev = value.device();
+    check_forest(pop, gp_len, value, type, size, dev);
+    c10::DeviceGuard guard(dev);
+    Tensor3 out = empty_forest(pop, gp_len, dev);
+    Tensor dec = want_decisions ? at::empty({pop, 2}, value.options().dtype(at::kInt)) : at::empty({0}, value.options().dtype(at::kInt));
+    check_rc(evogp_hip_structural_mutate((int)pop, (int)gp_len, (int)mode, (float)rate, (int)max_size, inner_is_offset ? 1 : 0, (int)skip_rows, seed, call,
+                                         value.data_ptr<float>(), type.data_ptr<int16_t>(), size.data_ptr<int16_t>(), std::get<0>(out).data_ptr<float>(),
+                                         std::get<1>(out).data_ptr<int16_t>(), std::get<2>(out).data_ptr<int16_t>(),
+                                         want_decisions ? dec.data_ptr<int>() : nullptr, current_stream(dev)),
+             "structural_mutate");
+    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), dec};
+}
+
+// Multi / Single Point / Const mutation drawn and applied in one launch: the new value array (evogp_hip_point_mutate)
+Tensor point_mutate(int64_t mode, double rate, double intensity, bool per_node, bool modify_output, bool fix_roulette, int64_t skip_rows, int64_t input_len,
+                    int64_t output_len, int64_t seed, int64_t call, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &roulette_ufuncs,
+                    const Tensor &roulette_bfuncs, const Tensor &roulette_tfuncs, const Tensor &const_samples) {
+    TORCH_CHECK(value.dim() == 2, "value must be a (pop, gp_len) tensor");
+    const int64_t pop = value.size(0), gp_len = value.size(1);
+    check_sizes(pop, gp_len);
+    const c10::Device dev = value.device();
+    check_forest(pop, gp_len, value, type, size, dev);
+    check_tensor(roulette_ufuncs, {29}, "roulette_ufuncs", dev, at::kFloat);
+    check_tensor(roulette_bfuncs, {29}, "roulette_bfuncs", dev, at::kFloat);
+    check_tensor(roulette_tfuncs, {29}, "roulette_tfuncs", dev, at::kFloat);
+    TORCH_CHECK(const_samples.dim() == 1 && const_samples.size(0) > 0, "const_samples must be a non-empty vector");
+    check_tensor(const_samples, {const_samples.size(0)}, "const_samples", dev, at::kFloat);
+    c10::DeviceGuard guard(dev);
+    Tensor out = at::empty_like(value);
+    check_rc(evogp_hip_point_mutate((int)pop, (int)gp_len, (int)mode, (float)rate, (float)intensity, per_node ? 1 : 0, modify_output ? 1 : 0, fix_roulette ? 1 : 0,
+                                    (int)skip_rows, (int)input_len, (int)output_len, (int)const_samples.size(0), seed, call, value.data_ptr<float>(),
+                                    type.data_ptr<int16_t>(), size.data_ptr<int16_t>(), roulette_ufuncs.data_ptr<float>(), roulette_bfuncs.data_ptr<float>(),
+                                    roulette_tfuncs.data_ptr<float>(), const_samples.data_ptr<float>(), out.data_ptr<float>(), current_stream(dev)),
+             "point_mutate");
+    return out;
+}
+
 }  // namespace
 
 // schemas of the reference, verbatim (torch_wrapper.cu:294-298)
@@ -554,6 +597,11 @@ TORCH_LIBRARY(evogp_hip, m) {
     m.def("breed_rows_hashed(int pop_size, int gp_len, Tensor value, Tensor node_type, Tensor subtree_size, Tensor elite_rows, Tensor parent_rows,"
           " int seed, int generation, int mutate_below, Tensor donor_value, Tensor donor_type, Tensor donor_size, int row_begin, int row_count)"
           " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
+    m.def("structural_mutate(int mode, float rate, int max_size, bool inner_is_offset, int skip_rows, int seed, int call, Tensor value, Tensor node_type,"
+          " Tensor subtree_size, bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)");
+    m.def("point_mutate(int mode, float rate, float intensity, bool per_node, bool modify_output, bool fix_roulette, int skip_rows, int input_len, int output_len,"
+          " int seed, int call, Tensor value, Tensor node_type, Tensor subtree_size, Tensor roulette_ufuncs, Tensor roulette_bfuncs, Tensor roulette_tfuncs,"
+          " Tensor const_samples) -> Tensor");
     m.def("tree_generate_masked_hashed(int pop_size, int gp_len, int var_len, int out_len, int const_samples_len, float out_prob, float const_prob,"
           " Tensor depth2leaf_probs, Tensor roulette_funcs, Tensor const_samples, int tree_index_offset, int seed, int generation, int active_below)"
           " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
@@ -575,6 +623,8 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("breed_rows", &breed_rows);
     m.impl("breed_rows_hashed", &breed_rows_hashed);
     m.impl("tree_generate_masked_hashed", &tree_generate_masked_hashed);
+    m.impl("structural_mutate", &structural_mutate);
+    m.impl("point_mutate", &point_mutate);
     m.impl("tree_SR_fitness_masked", &tree_SR_fitness_masked);
     m.impl("select_survivors", &select_survivors);
     m.impl("tournament_select", &tournament_select);

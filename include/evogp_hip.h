@@ -189,6 +189,26 @@ int evogp_hip_breed_lists_hashed(int pop_size, int table_rows, int gp_len, int n
                                  const int16_t *donor_type, const int16_t *donor_size, float *value_res, int16_t *type_res,
                                  int16_t *size_res, int *decisions, int row_begin, int row_count, evogp_stream_t stream);
 
+/* The reference's structural and point mutations, drawn and applied in one launch each (no counterpart in the
+ * reference's ABI, whose operators are torch programs around tree_crossover: src/evogp/algorithm/mutation/hoist.py:43-75,
+ * delete.py:44-105, single_point.py:43-126, multi_point.py:46-143, single_const.py:39-98, multi_const.py:43-95).  The random numbers are the
+ * counter-based words of evogp_hip_random_words under (seed, call): word 0 of tree n decides whether it mutates (u < rate), words 1 and 2
+ * the nodes; words 8-12 of node n * gp_len + i its new payload.  Trees below skip_rows (the elites of a generation step) are copied.
+ *   evogp_hip_structural_mutate  mode 0 = DeleteMutation (a function node whose subtree has at most max_size nodes -- 0: any -- is replaced by
+ *       its child number trunc(1 + u (arity - 1)), the reference's draw), 1 = HoistMutation (node trunc(u S) is replaced by node
+ *       trunc(u' size) taken as an absolute index, or as an offset into the subtree with inner_is_offset); the fall-back rules of
+ *       tree_crossover apply (mutation.cu:256-266, 279-289).  decisions: optional i32[pop][2] = {replaced node or -1, donor node}.
+ *   evogp_hip_point_mutate       mode 0 = MultiPointMutation, 1 = SinglePointMutation, 2 = MultiConstMutation, 3 = SingleConstMutation;
+ *       only the value array changes.  roulette_*funcs: the descriptor's cumulative per-arity tables, f32[29] each. */
+int evogp_hip_structural_mutate(int pop_size, int gp_len, int mode, float rate, int max_size, int inner_is_offset, int skip_rows,
+                                long long seed, long long call, const float *value, const int16_t *type, const int16_t *size,
+                                float *value_res, int16_t *type_res, int16_t *size_res, int *decisions, evogp_stream_t stream);
+int evogp_hip_point_mutate(int pop_size, int gp_len, int mode, float rate, float intensity, int per_node, int modify_output,
+                           int fix_roulette, int skip_rows, int input_len, int output_len, int n_consts, long long seed, long long call,
+                           const float *value, const int16_t *type, const int16_t *size, const float *roulette_ufuncs,
+                           const float *roulette_bfuncs, const float *roulette_tfuncs, const float *const_samples, float *value_res,
+                           evogp_stream_t stream);
+
 /* Counter-based random words for the breeding pass of a sharded run (no counterpart in the reference, which draws with
  * torch's generator): out[k][i] for k < rows, i in [lo, hi) = hash(seed, generation, k, i) mapped to [0, 2^31 - 1), the value
  * evogp_amd/parallel.py random_words computes on any device; out: i32[rows][n_cols], only columns [lo, hi) are written.  Every

@@ -1,0 +1,201 @@
+"""GPU: the reference's structural and point mutations as one native launch each (csrc/mutate_ops.hip, round 5).
+
+The kernels draw with the counter-based words of evogp_amd/parallel.py random_words, so every decision can be recomputed here: the
+tests rebuild the draws in numpy (the same float32 arithmetic), derive what the operator must do with them from the REFERENCE's rules
+(delete.py:44-105, hoist.py:43-75, single_point.py / multi_point.py / single_const.py / multi_const.py) and demand equality -- of the
+decisions, and of the resulting forests with tree_crossover (already bit-exact against the reference) fed those decisions."""
+import numpy as np
+import pytest
+
+from helpers import ARITH, depth2leaf, roulette_uniform
+
+pytestmark = pytest.mark.gpu
+IF, ADD, SUB, MUL, DIV, LDIV, POW, LPOW, MAX, MIN, LT, GT, LE, GE = range(14)
+SIN, COS, TAN, SINH, COSH, TANH, LOG, LLOG, EXP, INV, LINV, NEG, ABS, SQRT, LSQRT = range(14, 29)
+CS = [-1.0, 0.0, 1.0, 0.5, 2.0]
+
+
+@pytest.fixture(scope="module")
+def g():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import gpu_capi
+
+    return gpu_capi
+
+
+def words(seed, call, rows, lo, hi):
+    import torch
+
+    from evogp_amd.parallel import random_words
+
+    return random_words(seed, call, rows, lo, hi, torch.device("cpu")).numpy().astype(np.int64)
+
+
+def uniform(w):
+    return ((w >> 7).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode,L,funcs,max_size,offset,skip", [(0, 64, ARITH + [NEG, IF], 0, False, 0), (0, 256, ARITH + [SIN], 5, False, 100), (1, 64, ARITH + [NEG, IF], 0, False, 37),
+                                                              (1, 256, ARITH, 0, True, 0)], ids=["delete", "delete-L256-max5", "hoist", "hoist-offset-L256"])
+def test_structural_mutation_decisions_and_rows(g, oracle, mode, L, funcs, max_size, offset, skip):
+    import torch
+
+    import evogp_amd  # noqa: F401
+
+    pop, rate, seed, call = 5003, 0.7, 123456789, 17
+    v, t, s = oracle.generate(pop, L, 5, 1, 0.0, 0.5, [L, mode], depth2leaf(7 if L > 64 else 5, 0.15), roulette_uniform(funcs), CS)
+    v, t, s = v.copy(), t.copy(), s.copy()
+    s[11, 0] = 0                                                  # a row without a tree: copied
+    keep = s[:, 0] <= L                                           # (IF can outgrow the row: such rows are whatever they are -- skipped below)
+    dv, dt, ds = (torch.from_numpy(a).to(g.DEV) for a in (v, t, s))
+    rv, rt, rs, dec = torch.ops.evogp_hip.structural_mutate(mode, rate, max_size, offset, skip, seed, call, dv, dt, ds, True)
+    dec = dec.cpu().numpy()
+    w = words(seed, call, 3, 0, pop)
+    u0, u2 = uniform(w[0]), uniform(w[2])
+    S = np.clip(s[:, 0].astype(np.int64), 0, L)
+    want_p, want_q = np.full(pop, -1, np.int64), np.zeros(pop, np.int64)
+    for n in range(pop):
+        if n < skip or not (u0[n] < np.float32(rate)) or S[n] < 1:
+            continue
+        if mode == 0:
+            if S[n] <= 1:
+                continue
+            sz = s[n, :S[n]].astype(np.int64)
+            elig = np.nonzero((sz > 1) & ((max_size <= 0) | (sz <= max_size)))[0]
+            p = int(elig[int(w[1][n]) % len(elig)]) if len(elig) else 0
+            arity = (int(t[n, p]) & 0x7F) - 2 + 1
+            nth = int(np.float32(1.0) + u2[n] * np.float32(arity - 1))
+            c1 = min(p + 1, L - 1); c2 = min(c1 + int(s[n, c1]), L - 1); c3 = min(c2 + int(s[n, c2]), L - 1)
+            want_p[n], want_q[n] = p, (c3 if nth == 3 else c2 if nth == 2 else c1)
+        else:
+            p = min(int(uniform(w[1][n:n + 1])[0] * np.float32(S[n])), int(S[n]) - 1)
+            want_p[n], want_q[n] = p, int(u2[n] * np.float32(int(s[n, p]))) + (p if offset else 0)
+    assert np.array_equal(dec[keep, 0], want_p[keep]), np.nonzero(dec[:, 0] != want_p)[0][:5]
+    mut = (want_p >= 0) & keep
+    assert np.array_equal(dec[mut, 1], want_q[mut])
+    share = mut[skip:].mean()
+    assert abs(share - rate * (np.mean(S[skip:] > 1) if mode == 0 else 1.0)) < 0.03, share
+    if mode == 0:   # the replaced node is a function, the donor one of its children
+        assert ((t[np.nonzero(mut)[0], want_p[mut]] & 0x7F) >= 2).all()
+    # the rows: tree_crossover of every tree with itself at those nodes (replace.hip, bit-exact against the reference)
+    ar = np.arange(pop, dtype=np.int32)
+    cv, ct, cs = g.crossover(v, t, s, ar, ar, want_p.astype(np.int32), want_q.astype(np.int32))
+    got = (rv.cpu().numpy(), rt.cpu().numpy(), rs.cpu().numpy())
+    for a, b in zip(got, (cv, ct, cs)):
+        a, b = a[keep], b[keep]
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    assert np.array_equal(got[2][:skip], s[:skip]) and np.array_equal(got[0][:skip].view(np.uint32), v[:skip].view(np.uint32))
+
+
+def _roulettes(funcs):
+    w = np.zeros(29, np.float64); w[list(funcs)] = 1.0 / len(funcs)
+    p = w.astype(np.float32)
+
+    def of(lo, hi):
+        only = np.zeros(29, np.float32); only[lo:hi] = p[lo:hi]
+        return np.cumsum(only, dtype=np.float32)
+    return of(14, 29), of(1, 14), of(0, 1)
+
+
+@pytest.mark.parametrize("mode,per_node,modify_output,fix,out_len", [(0, False, False, False, 1), (0, True, True, True, 3), (1, False, False, False, 1), (1, False, True, False, 3),
+                                                                     (2, False, False, False, 1), (2, True, False, False, 1), (3, False, False, False, 1)],
+                         ids=["multi-point", "multi-point-per-node-out-fix", "single-point", "single-point-out", "multi-const", "multi-const-per-node", "single-const"])
+def test_point_mutations_node_by_node(g, oracle, mode, per_node, modify_output, fix, out_len):
+    import torch
+
+    import evogp_amd  # noqa: F401
+
+    pop, L, V, rate, intensity, seed, call, skip = 3001, 64, 6, 0.6, 0.4, 987654321, 5, 29
+    funcs = ARITH + [NEG, SIN, IF, MAX]
+    consts = np.linspace(-3, 3, 101).astype(np.float32)
+    v, t, s = oracle.generate(pop, L, V, out_len, 0.5 if out_len > 1 else 0.0, 0.5, [mode, out_len], depth2leaf(5, 0.15), roulette_uniform(funcs), CS)
+    ru, rb, rt_ = _roulettes(funcs)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(g.DEV)
+    got = torch.ops.evogp_hip.point_mutate(mode, rate, intensity, per_node, modify_output, fix, skip, V, out_len, seed, call, dev(v), dev(t), dev(s), dev(ru),
+                                           dev(rb), dev(rt_), dev(consts)).cpu().numpy()
+    wt = words(seed, call, 2, 0, pop)
+    wn = words(seed, call, 13, 0, pop * L).reshape(13, pop, L)
+    u0, u1 = uniform(wt[0]), uniform(wt[1])
+    S = np.clip(s[:, 0].astype(np.int64), 0, L)
+    mutate = (np.arange(pop) >= skip) & (u0 < np.float32(rate))
+    live = np.arange(L)[None, :] < S[:, None]
+    if mode == 1:
+        pos = np.minimum((u1 * S.astype(np.float32)).astype(np.int64), S - 1)
+        target = mutate[:, None] & (np.arange(L)[None, :] == pos[:, None]) & live
+    elif mode == 3:
+        target = np.zeros((pop, L), bool)
+        for n in np.nonzero(mutate)[0]:
+            c = np.nonzero((t[n, :S[n]] == 1))[0]
+            if len(c):
+                target[n, c[int(wt[1][n]) % len(c)]] = True
+    else:
+        on = (uniform(wn[12]) < np.float32(intensity)) if per_node else (u1 < np.float32(intensity))[:, None]
+        target = mutate[:, None] & live & on
+    if mode >= 2:
+        target &= t == 1
+    want = v.copy()
+    kind = t.astype(np.int64) & 0x7F
+    is_out = (t.astype(np.int64) & 0x80) != 0
+    bits = v.view(np.uint32).astype(np.int64)
+    const_new = consts[np.minimum((uniform(wn[10]) * np.float32(len(consts))).astype(np.int64), len(consts) - 1)]
+    var_new = np.minimum((uniform(wn[9]) * np.float32(V)).astype(np.int64), V - 1).astype(np.float32)
+    u8 = uniform(wn[8])
+    func = np.zeros((pop, L), np.int64)
+    for k, rou in ((2, ru), (3, rb), (4, rt_)):
+        sel = kind == k if k < 4 else kind >= 4
+        if fix:
+            total = rou[-1]
+            idx = np.minimum(np.searchsorted(rou, (u8 * total).astype(np.float32), side="right"), 28)
+            old_func = np.where(is_out, bits & 0xFFFF, v.astype(np.int64))
+            idx = idx if total > 0 else old_func
+        else:
+            idx = np.searchsorted(rou, u8, side="left")
+        func = np.where(sel, idx, func)
+    oi = bits >> 16
+    if modify_output:
+        oi = np.minimum((uniform(wn[11]) * np.float32(out_len)).astype(np.int64), out_len - 1)
+    packed = ((func + (oi << 16)) & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+    func_new = np.where(is_out, packed, func.astype(np.float32))
+    fresh = np.where((mode >= 2) | (kind == 1), const_new, np.where(kind == 0, var_new, func_new))
+    want = np.where(target, fresh, v).astype(np.float32)
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))
+    assert len(bad[0]) == 0, (len(bad[0]), bad[0][:5], bad[1][:5], got[bad][:5], want[bad][:5], t[bad][:5])
+    assert target.any() and abs(mutate[skip:].mean() - rate) < 0.04
+    assert np.array_equal(got[:skip].view(np.uint32), v[:skip].view(np.uint32))
+
+
+def test_generation_step_with_the_reference_paper_operator_set(g, oracle):
+    """example/brax_task.py:38-45: DefaultCrossover + CombinedMutation[DefaultMutation(0.2), DeleteMutation(0.8)] under DefaultSelection --
+    the fused breeding pass and ONE more launch; elites come first and unchanged, every row is a well-formed tree (its fitness is what the
+    oracle computes for it), trees get shorter on average under Delete, and the composed torch programs (EVOGP_NATIVE_MUTATION=0) still run."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.algorithm import (CombinedMutation, DefaultCrossover, DefaultMutation, DefaultSelection, DeleteMutation, GeneticProgramming, HoistMutation,
+                                     InsertMutation, MultiConstMutation, SinglePointMutation)
+    from evogp_amd.tree import Forest, GenerateDescriptor
+    from helpers import assert_close_classes, c2_dataset
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    desc = GenerateDescriptor(max_tree_len=128, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6, const_samples=[-1, 0, 1])
+    pop = 6000
+    X, y = c2_dataset()
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    for ops in ([DefaultMutation(0.2, desc.update(max_layer_cnt=3)), DeleteMutation(0.8)], [HoistMutation(0.3), InsertMutation(0.3, desc.update(max_layer_cnt=3))],
+                [SinglePointMutation(0.5, desc, fix_roulette=True), MultiConstMutation(0.5, desc)]):
+        algo = GeneticProgramming(Forest.random_generate(pop, desc, keys=torch.tensor([5, 6], dtype=torch.uint32, device=dev)), DefaultCrossover(),
+                                  CombinedMutation(ops), DefaultSelection(survival_rate=0.3, elite_rate=0.01))
+        assert algo._native_plan() is not None
+        for gen in range(3):
+            fit = -algo.forest.SR_fitness(Xd, yd)
+            fit = torch.where(torch.isnan(fit), torch.full_like(fit, float("-inf")), fit)
+            best = torch.topk(fit, 60).values.sort().values       # DefaultSelection(elite_rate 0.01): the 60 best come first, untouched by any mutation
+            algo.step(fit)
+            f = algo.forest
+            again = -f.SR_fitness(Xd, yd)[:60]
+            assert torch.equal(again.sort().values, best), "the first rows of the next generation are not the elites"
+        trees = (f.batch_node_value.cpu().numpy(), f.batch_node_type.cpu().numpy(), f.batch_subtree_size.cpu().numpy())
+        assert_close_classes(f.SR_fitness(Xd, yd).cpu().numpy(), oracle.sr_fitness(*trees, X, y), 1e-5, what=f"generation 3 under {[type(o).__name__ for o in ops]}")
