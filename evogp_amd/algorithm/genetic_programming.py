@@ -134,7 +134,7 @@ class GeneticProgramming:
                     self._word_seed = int(torch.randint(0, 2**40, (1,)).item())
                 lists = counter_based(fitness, self._word_seed, getattr(self, "_steps", 0) + 1)
             elites, parents = lists if lists is not None else self.selection(f, fitness)
-            # the same guards DefaultSelection's counts get in _native_default_ok: at least one offspring row, at least one parent, lists
+            # the same guards DefaultSelection's counts get in _native_plan: at least one offspring row, at least one parent, lists
             # on the forest's device
             if elites.numel() >= pop or parents.numel() == 0:
                 self._replay_lists = (elites, parents)

@@ -132,7 +132,7 @@ def test_genetic_programming_default_step_uses_the_fused_path_and_stays_valid(g)
     pop = 5000
     forest = Forest.random_generate(pop, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
     algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
-    assert algo._native_default_ok()
+    assert algo._native_plan() is not None
     X = torch.rand(256, 4, device=dev) * 4 - 2
     y = (X[:, 0] * X[:, 1] - X[:, 2]).unsqueeze(1)
     best = []
@@ -315,7 +315,7 @@ def test_genetic_programming_step_with_tournament_selection_takes_the_fused_path
     forest = Forest.random_generate(pop, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
     sel = TournamentSelection(4, best_probability=0.95, replace=False, survivor_rate=0.5, elite_rate=0.005)
     algo = GeneticProgramming(forest, DefaultCrossover(), DefaultMutation(0.2, desc.update(max_layer_cnt=3)), sel)
-    assert algo._native_default_ok()
+    assert algo._native_plan() is not None
     X = torch.rand(256, 4, device=dev) * 4 - 2
     y = (X[:, 0] * X[:, 1] - X[:, 2] / (X[:, 3] * X[:, 3] + 1.5) + 0.5 * X[:, 0]).unsqueeze(1)    # not in generation 0
     best, median = [], []

@@ -86,7 +86,8 @@ def test_structural_mutation_decisions_and_rows(g, oracle, mode, L, funcs, max_s
     for a, b in zip(got, (cv, ct, cs)):
         a, b = a[keep], b[keep]
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
-    assert np.array_equal(got[2][:skip], s[:skip]) and np.array_equal(got[0][:skip].view(np.uint32), v[:skip].view(np.uint32))
+    livek = np.arange(L)[None, :] < S[:skip, None]                # (the rows of the elites: copied -- the live prefix; the tail is zeroed)
+    assert np.array_equal(got[2][:skip][livek], s[:skip][livek]) and np.array_equal(got[0][:skip][livek].view(np.uint32), v[:skip][livek].view(np.uint32))
 
 
 def _roulettes(funcs):
