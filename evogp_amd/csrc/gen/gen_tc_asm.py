@@ -68,6 +68,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ocml_bodies import BODIES  # noqa: E402  (the library's sequences for pow / sinh / cosh, gen/ocml_transcribe.py)
+from pair_rows import Pairing, check as check_pairing  # noqa: E402
 
 FORMS = ("SS", "SV", "VS", "SC", "CS", "VV", "VC", "CV")
 SENTINEL_HEAVY = 0x7FC0FEED  # sr_params.hpp kSentinelHeavy: "evaluate me in the FULL register kernel"
@@ -98,6 +99,7 @@ KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_T
 FUSED_SIZE_OFF, FUSED_LEN_OFF = 96 + 16, 96 + 60   # FusedParams (sr_tc.hip): c.size and c.gp_len behind the 96 bytes of TcParams (static_asserts there)
 TOUCH = True     # fused build: the block's entry touches the rows of the wave's next batch (EVOGP_TC_GEN_TOUCH=0: off)
 TRIGPK = True    # sin / cos / tan over row pairs with packed multiplications and fused multiply-adds (EVOGP_TC_GEN_TRIGPK=0: row by row)
+LIBPK = True     # pow / sinh / cosh: the library's sequences over row PAIRS (gen/pair_rows.py; EVOGP_TC_GEN_LIBPK=0: row by row)
 RECGLC = False   # fused build: the record loads carry glc (EVOGP_TC_GEN_RECGLC=1) instead of one s_dcache_inv per batch
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
 
@@ -1030,6 +1032,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
                     a(f"v_mov_b32 v{Q + k}, v{cur + k}")
                 elif rb == "C":
                     a(f"v_mov_b32 v{Q + k}, s{sA}")
+            if fl == 1:
+                a(f"s_add_u32 s{T2}, s{T2}, {len(GBIN)}")     # (the second half of the body table: this flavour's copies)
             a(f"s_branch {lab('gbin_dispatch')}")
         # ---- generic unary stubs: operand -> T bank, result slot in sDST, body named by aux
         begin("gun_S", fl)
@@ -1398,6 +1402,44 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
         a("s_mov_b32 m0, 0")
         for i, r in enumerate(SPILL):
             a(f"v_readlane_b32 s{r}, v{spill}, {i}")
+    def row_pair_loop(label, body, nin, out_bank, vpool):
+        """the sequence over row PAIRS (gen/pair_rows.py): operands T[k], T[k + 1] (and Q) -> two rows of the sequence with its
+        multiplications, additions and fused multiply-adds packed -> out_bank[k], out_bank[k + 1].  `vpool`: the aligned VGPR pairs it
+        may use.  Returns False (nothing emitted) when the registers do not suffice -- the caller then runs the rows one by one."""
+        if not (LIBPK and K >= 2):
+            return False
+        # (ten more control registers wait in the spill register's lanes: jump target, J, H, the result slot, the tile, the mask of
+        # evaluated trees, the record address)
+        spill = SPILL + [20, 21, 22, 23, 24, 25, 30, 31, 32, 33]
+        counter = 24
+        try:
+            res = Pairing(body, label).run().allocate(vpool, SPAIRS + [20, 22, 30, 32], vsingles=[22, 23])
+        except AssertionError:
+            return False
+        check_pairing(body, res, label)                # (symbolic execution: both rows equal the library's sequence)
+        spill_v = 9
+        for i, r in enumerate(spill):
+            a(f"v_writelane_b32 v{spill_v}, s{r}, {i}")
+        a(f"s_mov_b32 s{counter}, 0")
+        a(f"{lab(label + '_row')}:")
+        a(f"s_add_u32 m0, s{counter}, {hex(MODE['SRC0'] << 12)}")
+        for j in (0, 1):
+            a(f"v_mov_b32 v{res['inputs'][0] + j}, v{T + j}")
+            if nin == 2:
+                a(f"v_mov_b32 v{res['inputs'][1] + j}, v{Q + j}")
+        a("s_mov_b32 m0, 0")
+        for ln in res["lines"]:
+            a(ln)
+        a(f"s_add_u32 m0, s{counter}, {hex(MODE['DST'] << 12)}")
+        for j in (0, 1):
+            a(f"v_mov_b32 v{out_bank + j}, v{res['output'] + j}")
+        a(f"s_add_u32 s{counter}, s{counter}, 2")
+        a(f"s_cmp_lt_u32 s{counter}, {K}")
+        a(f"s_cbranch_scc1 {lab(label + '_row')}")
+        a("s_mov_b32 m0, 0")
+        for i, r in enumerate(spill):
+            a(f"v_readlane_b32 s{r}, v{spill_v}, {i}")
+        return True
     # ---- bodies behind the generic stubs.  Binary: a in T, b in Q, result left in T; unary: operand in T, result in Q.
     a(f"{lab('gbin_dispatch')}:")
     a(f"s_lshl_b32 s{T2}, s{T2}, 2")
@@ -1409,8 +1451,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
     a(f"s_addc_u32 s{sA + 1}, s{sA + 1}, 0")
     a(f"s_setpc_b64 s[{sA}:{sA + 1}]")
     a(f"{lab('gbin_table')}:")
-    for body in GBIN:
-        a(f"s_branch {lab('gbody_' + body)}")
+    for fl_ in (0, 1):   # (the stubs of flavour 1 add len(GBIN) to the body number: pow over row pairs borrows the flavour's own operand bank)
+        for body in GBIN:
+            a(f"s_branch {lab('gbody_' + body + (f'_fl{fl_}' if body == 'pow' else ''))}")
     a(f"{lab('gun_dispatch')}:")
     a(f"s_lshl_b32 s{T2}, s{T2}, 2")
     a(f"s_getpc_b64 s[{sA}:{sA + 1}]")
@@ -1446,7 +1489,16 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
                 div_rows([T + k], [Q + k], [4], nanfix=False)
                 a(f"v_div_fixup_f32 v{T + k}, v4, v{Q + k}, v{T + k}")
         elif body == "pow":             # forward.cu:193-194
-            row_loop("pow", BODIES["pow"], 2, T)
+            # (over row pairs the sequence needs 19 register pairs: the registers above the stack, the temporaries and the CURRENT
+            # operand bank -- the stubs have copied its values to T / Q --, hence one copy of the body per flavour)
+            base_pool = [4, 18, 20] + list(range(top, top + HEAVY_REGS, 2))
+            a(f"{lab('gbody_pow_fl0')}:")
+            if not row_pair_loop("pow_fl0", BODIES["pow"], 2, T, base_pool + list(range(P[0], P[0] + K - 1, 2))):
+                row_loop("pow_fl0", BODIES["pow"], 2, T)
+            a(f"s_branch {lab('gbin_tail')}")
+            a(f"{lab('gbody_pow_fl1')}:")
+            if not row_pair_loop("pow_fl1", BODIES["pow"], 2, T, base_pool + list(range(P[1], P[1] + K - 1, 2))):
+                row_loop("pow_fl1", BODIES["pow"], 2, T)
         elif body == "lpow":            # forward.cu:195-200: (a == 0 && b == 0) ? 0 : pow(|a|, b)
             row_loop("lpow", BODIES["pow"], 2, T, extra_v=1,
                      pre=(lambda c: f"v_and_b32 v{c['a']}, 0x7fffffff, v{c['a']}",
@@ -1475,7 +1527,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
                 div_rows([9], [T + k], [4], nanfix=False)
                 a(f"v_div_fixup_f32 v{Q + k}, v4, v{T + k}, v9")
         elif body in ("sinh", "cosh"):  # forward.cu:129-134
-            row_loop(body, BODIES[body], 1, Q)
+            if not row_pair_loop(body, BODIES[body], 1, Q, [4, 18, 20] + list(range(top, top + HEAVY_REGS, 2))):
+                row_loop(body, BODIES[body], 1, Q)
         elif body == "tanh":            # the library's tanhf: both of its branches, then the select it makes with the exec mask
             t2, t3, t4, t5 = 18, 19, 20, 21
             for k in range(K):
@@ -2258,6 +2311,7 @@ if __name__ == "__main__":
     RECGLC = os.environ.get("EVOGP_TC_GEN_RECGLC", "0") == "1"
     TOUCH = os.environ.get("EVOGP_TC_GEN_TOUCH", "1") != "0"
     TRIGPK = os.environ.get("EVOGP_TC_GEN_TRIGPK", "1") != "0"
+    LIBPK = os.environ.get("EVOGP_TC_GEN_LIBPK", "1") != "0"
     outdir = sys.argv[1] if len(sys.argv) > 1 else "."
     import json
     table = {}

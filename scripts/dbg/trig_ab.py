@@ -37,6 +37,14 @@ def forests():
     el = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/", "exp", "log", "pow"], max_layer_cnt=6,
                             const_samples=[-1, 0, 1])
     yield "exp_log_pow_100k", Forest.random_generate(100_000, el, keys=keys(42, 0)), Xd, yd
+    # pow / loose pow / sinh / cosh / tanh: the library's sequences over row pairs (round 5, gen/pair_rows.py) -- 8, 4 and 1 rows per lane
+    hy = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "*", "pow", "loose_pow", "sinh", "cosh", "tanh", "/"], max_layer_cnt=6,
+                            const_samples=[-1, 0, 1, 0.5, 2, 3.5])
+    fh = Forest.random_generate(100_000, hy, keys=keys(9, 9))
+    yield "pow_hyperbolic_100k", fh, Xd, yd
+    yield "pow_hyperbolic_wide_arguments", fh, (Xd * torch.tensor([1, 20, 1e-3, 1, 1e4, 1, -1, 1, 1e-20, 1e30], device=dev)).contiguous(), yd
+    yield "pow_hyperbolic_300rows", fh[:50_000], Xd[:300].contiguous(), yd[:300].contiguous()
+    yield "pow_hyperbolic_40rows", fh[:50_000], Xd[:40].contiguous(), yd[:40].contiguous()
 
 
 def run(tag):

@@ -228,7 +228,7 @@ def test_interpreter_generator_switches_still_generate():
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
     defaults = {k: getattr(g, k) for k in ("DIVRANGE", "TRUST", "PKCONST", "PKARITH", "DIVABREAST", "DIVFIX", "EARLYREC", "L2WARM", "KWARM", "TRIGPK",
-                                           "TOUCH", "RECGLC")}
+                                           "TOUCH", "RECGLC", "LIBPK")}
     try:
         for flip in [None] + list(defaults):
             for k, v in defaults.items():
@@ -243,8 +243,9 @@ def test_interpreter_generator_switches_still_generate():
                     h = info["handlers"]
                     assert set(("end", "mul_SS", "divip_SS", "div_VV", "push_c")) <= set(h)
                     assert all(v["valu_clk"] >= v["valu"] for v in h.values())
-                    packed = "v_pk_fma_f32" in text   # the range-tested division rows and (round 4) the sin / cos / tan rows over row pairs
-                    assert packed == ((g.DIVRANGE and fast in (1, 2) and K >= 2) or (g.TRIGPK and K >= 2)), (flip, K, fast)
+                    packed = "v_pk_fma_f32" in text   # the range-tested division rows, (round 4) sin / cos / tan and (round 5) pow / sinh / cosh over row pairs
+                    assert packed == ((g.DIVRANGE and fast in (1, 2) and K >= 2) or (g.TRIGPK and K >= 2) or (g.LIBPK and K >= 2)), (flip, K, fast)
+                    assert ("Ltc_pow_fl1_row" in text) and (("v_pk_mov_b32" in text.split("Ltc_sinh_row")[1].split("s_cbranch_scc1")[0]) == (g.LIBPK and K >= 2))
                     assert "swap" in h and "Ltc_triglib_sin" in text
                     if K == 8:   # the build that runs ONE batch per entry and returns (sr_fused_kernel)
                         fused = g.gen(K, depth, fast=fast, fused=True)
