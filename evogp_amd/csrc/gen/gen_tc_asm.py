@@ -1763,7 +1763,77 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
             a("v_mov_b32 v9, 0xce6e6b28")                           # -1e9
         if uop == "exp":
             a("v_mov_b32 v9, 0x7f800000")
-        for k in range(K):
+        if LIBPK and K >= 2 and uop in ("exp", "log", "llog"):
+            # Row PAIRS (round 5, as sin / cos / tan in round 4): the multiplications, fused multiply-adds and additions of the library's
+            # sequence as v_pk_* over two rows -- the same IEEE operations, the same bits --, a constant from one SGPR for both halves;
+            # rounding, conversion, v_exp / v_log, ldexp and the range selects stay per row.  21 instead of 30 vector instructions per pair.
+            A, B, C, D = 4, 18, 20, 22
+
+            def pkc(ins, dst, srcs, const, cpos, neg=None):
+                """packed instruction, the constant `const` at source position cpos"""
+                a(f"s_mov_b32 s{T1}, {const}")
+                ops = [f"v[{r}:{r + 1}]" for r in srcs]
+                ops.insert(cpos, f"s[{T1}:{T2}]")
+                sel = ["1"] * len(ops)
+                sel[cpos] = "0"
+                tail = f" op_sel_hi:[{','.join(sel)}]"
+                if neg:
+                    tail += f" neg_lo:[{','.join(neg)}] neg_hi:[{','.join(neg)}]"
+                a(f"{ins} v[{dst}:{dst + 1}], {', '.join(ops)}{tail}")
+
+            for k in range(0, K, 2):
+                X, R = T + k, Q + k
+                if uop == "exp":
+                    pkc("v_pk_mul_f32", A, [X], "0x3fb8aa3b", 1)                                  # t2 = x * log2(e)
+                    pkc("v_pk_fma_f32", B, [X, A], "0x3fb8aa3b", 1, ["0", "0", "1"])              # t3 = x * log2(e) - t2
+                    for j in (0, 1):
+                        a(f"v_rndne_f32 v{C + j}, v{A + j}")
+                    pkc("v_pk_fma_f32", B, [X, B], "0x32a5705f", 1)                               # t3 = x * (low part) + t3
+                    a(f"v_pk_add_f32 v[{A}:{A + 1}], v[{A}:{A + 1}], v[{C}:{C + 1}] neg_lo:[0,1] neg_hi:[0,1]")
+                    a(f"v_pk_add_f32 v[{A}:{A + 1}], v[{A}:{A + 1}], v[{B}:{B + 1}]")
+                    for j in (0, 1):
+                        a(f"v_cvt_i32_f32 v{C + j}, v{C + j}")
+                    for j in (0, 1):
+                        a(f"v_exp_f32 v{A + j}, v{A + j}")
+                    a(f"s_mov_b32 s{T1}, 0xc2ce8ed0")
+                    for j in (0, 1):
+                        a(f"v_cmp_ngt_f32 vcc, s{T1}, v{X + j}")
+                        a(f"v_ldexp_f32 v{A + j}, v{A + j}, v{C + j}")
+                        a(f"v_cndmask_b32 v{A + j}, 0, v{A + j}, vcc")
+                    a(f"s_mov_b32 s{T1}, 0x42b17218")
+                    for j in (0, 1):
+                        a(f"v_cmp_nlt_f32 vcc, s{T1}, v{X + j}")
+                        a("s_nop 1")
+                        a(f"v_cndmask_b32 v{R + j}, v9, v{A + j}, vcc")
+                else:
+                    a(f"s_mov_b32 s{T1}, 0x800000")
+                    for j in (0, 1):
+                        a(f"v_cmp_gt_f32 vcc, s{T1}, v{X + j}")                                    # denormal operand: scale by 2^32
+                        a(f"v_cndmask_b32_e64 v{B + j}, 0, 32, vcc")
+                        a(f"v_ldexp_f32 v{A + j}, v{X + j}, v{B + j}")
+                        a(f"v_mov_b32 v{B + j}, 0x41b17218")
+                        a(f"v_cndmask_b32 v{B + j}, 0, v{B + j}, vcc")
+                    for j in (0, 1):
+                        a(f"v_log_f32 v{A + j}, v{A + j}")
+                    a("s_nop 1")
+                    pkc("v_pk_mul_f32", C, [A], "0x3f317217", 1)
+                    pkc("v_pk_fma_f32", D, [A, C], "0x3f317217", 1, ["0", "0", "1"])
+                    pkc("v_pk_fma_f32", D, [A, D], "0x3377d1cf", 1)
+                    a(f"v_pk_add_f32 v[{C}:{C + 1}], v[{C}:{C + 1}], v[{D}:{D + 1}]")
+                    a(f"s_mov_b32 s{T1}, 0x7f800000")
+                    for j in (0, 1):
+                        a(f"v_cmp_lt_f32_e64 vcc, |v{A + j}|, s{T1}")
+                        a("s_nop 1")
+                        a(f"v_cndmask_b32 v{A + j}, v{A + j}, v{C + j}, vcc")
+                    if uop == "log":
+                        a(f"v_pk_add_f32 v[{R}:{R + 1}], v[{A}:{A + 1}], v[{B}:{B + 1}] neg_lo:[0,1] neg_hi:[0,1]")
+                    else:
+                        a(f"v_pk_add_f32 v[{A}:{A + 1}], v[{A}:{A + 1}], v[{B}:{B + 1}] neg_lo:[0,1] neg_hi:[0,1]")
+                        for j in (0, 1):
+                            a(f"v_cmp_eq_f32 vcc, 0, v{X + j}")
+                            a("s_nop 1")
+                            a(f"v_cndmask_b32 v{R + j}, v{A + j}, v9, vcc")                        # LOOSE_LOG(0) = -MAX_VAL
+        for k in range(K if not (LIBPK and K >= 2 and uop in ("exp", "log", "llog")) else 0):
             x, res = T + k, Q + k
             if uop == "sqrt":
                 a(f"v_mul_f32 v{t2}, 0x4f800000, v{x}")
