@@ -406,6 +406,9 @@ def main():
                 "global_pop": P, "pop_per_gpu": pop, "datapoints": DATAPOINTS, "var_len": VAR_LEN, "max_tree_len": GP_LEN,
                 "mean_tree_len": all_nodes / P, "sharding": f"trees x{world} (contiguous shards, tree-index offset), no data-path collective in the step",
                 "ranks": world, "backend": backend,
+                # (both numbers: the timed K steps follow PREWARM untimed passes -- the device's clock ramp --; the same W + K steps of a
+                # fresh process are cold_start.ms_per_step)
+                "device_prewarm_calls": PREWARM, "ms_per_step_after_prewarm": elapsed / args.steps * 1000.0, "ms_per_step_fresh_process": cold_elapsed / args.steps * 1e3,
             },
             "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
             "roofline": {
@@ -742,6 +745,40 @@ def main():
             del calgo, cprob
         except Exception as exc:
             extras["configs3"] = {"error": repr(exc)[:300]}
+
+    if not args.headline_only and rank == 0:
+        # one generation (selection + crossover + mutation, the fitness handed in) under the reference's OTHER operator
+        # sets -- example/brax_task.py:38-45 CombinedMutation[DefaultMutation(0.2), DeleteMutation(0.8)] at configs[4]'s population, a Hoist /
+        # Insert list, the point mutations at configs[1]'s -- next to the default step on the same forests: the fused breeding pass plus one
+        # launch per further operator (csrc/mutate_ops.hip; round 4's torch programs: 0.7-1.1 ms and 90-120 launches, profiles/r05A_n3_generation.log)
+        try:
+            from evogp_amd.algorithm import CombinedMutation, DeleteMutation, HoistMutation, InsertMutation, MultiConstMutation, SinglePointMutation
+
+            def gen_ms(forest, mutation, reps=10):
+                algo = GeneticProgramming(forest, DefaultCrossover(), mutation, DefaultSelection(survival_rate=0.3, elite_rate=0.01))
+                fit = torch.rand(forest.pop_size, device=device)
+                for _ in range(3):
+                    algo.step(fit)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps):
+                    algo.step(fit)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e3
+
+            d6 = GenerateDescriptor(max_tree_len=256, input_len=17, output_len=6, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6, const_range=[-1, 1], sample_cnt=100)
+            d1 = GenerateDescriptor(max_tree_len=64, input_len=10, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=6, const_samples=[-1, 0, 1])
+            f6 = lambda: Forest.random_generate(50_000, d6, keys=torch.tensor([7, 1], dtype=torch.uint32, device=device))
+            f1 = lambda: Forest.random_generate(100_000, d1, keys=torch.tensor([42, 0], dtype=torch.uint32, device=device))
+            n3 = {"pop50k_L256_out6": {"default_step": gen_ms(f6(), DefaultMutation(0.2, d6.update(max_layer_cnt=3))),
+                                       "brax_task_combined_default_delete": gen_ms(f6(), CombinedMutation([DefaultMutation(0.2, d6.update(max_layer_cnt=3)), DeleteMutation(0.8)])),
+                                       "combined_hoist_insert": gen_ms(f6(), CombinedMutation([HoistMutation(0.2), InsertMutation(0.2, d6.update(max_layer_cnt=3))]))},
+                  "pop100k_L64": {"default_step": gen_ms(f1(), DefaultMutation(0.2, d1.update(max_layer_cnt=3))),
+                                  "single_point": gen_ms(f1(), SinglePointMutation(0.2, d1)),
+                                  "combined_single_point_multi_const": gen_ms(f1(), CombinedMutation([SinglePointMutation(0.2, d1), MultiConstMutation(0.2, d1)]))}}
+            extras["n3_operator_sets"] = {"generation_ms": n3, "what": "selection + DefaultCrossover + the named mutation(s) on a random fitness vector, ms per generation; "
+                                          "DefaultSelection(0.3, elite_rate 0.01)"}
+        except Exception as exc:
+            extras["n3_operator_sets"] = {"error": repr(exc)[:300]}
 
     if rank == 0:
         emit(extras)

@@ -64,6 +64,33 @@ __device__ inline bool marks_pending(const SrParams &p, int i) {
 
 __device__ inline float err_term(float diff, int use_mse) { return use_mse ? diff * diff : fabsf(diff); }
 
+// The fitness of ONE single-output tree with the operand stack in scratch memory (sr_general_kernel's per-tree work): one wave, lanes are
+// datapoints.  sr_fast_kernel's build behind the threaded code runs it itself for the rare tree whose stack its registers do not hold
+// (only_marked == 5, round 5: the scratch-stack kernel is then not launched at all -- two launches that find nothing were 10 us of every call).
+__device__ __attribute__((noinline)) void general_tree_fitness(const SrParams &p, int t, float *stk) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)t * p.gp_len;
+    const float *tv = p.value + row;
+    const int16_t *tt = p.type + row;
+    int len = uni((int)p.size[row]);
+    len = len < 0 ? 0 : (len > p.gp_len ? p.gp_len : len);
+    const int cls = uni(classify_tree(tt, tv, len, false, p.var_len, p.out_len, kMaxStack));
+    if (cls != TREE_OK) {
+        if (lane == 0) p.fitness[t] = __builtin_nanf("");
+        return;
+    }
+    float acc = 0.0f, outs[1];
+    for (int base = 0; base < p.D; base += kWave) {
+        const int d = base + lane;
+        const int dc = d < p.D ? d : p.D - 1;
+        const float res = run_general<false>(tt, tv, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, outs, stk);
+        const float e = err_term(p.y[dc] - res, p.use_mse);
+        acc += d < p.D ? e : 0.0f;
+    }
+    const float total = wave_sum(acc);
+    if (lane == 0) p.fitness[t] = total / (float)p.D;
+}
+
 // K rows per lane, DEPTH-entry register stack, VL variable registers, MO = multi-output,
 // MAXW = waves per workgroup the launch bound allows.
 // The LEAN build is held to 128 VGPRs (4 resident waves per SIMD): the interpreter is latency bound,
@@ -77,7 +104,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
     __shared__ int cls_s[2][kMaxBatch];
     __shared__ int next_s[2];
 
-    if (p.only_marked && p.marks && !marks_pending(p, 0)) return;  // nothing was marked for this build
+    if (p.only_marked && p.marks && !marks_pending(p, 0) && !(p.only_marked == 5 && marks_pending(p, 4))) return;  // nothing was marked for this build
     // Behind another kernel the batch size follows the share of marked trees the marking kernel sampled: few marked
     // trees -> full 64-tree batches (the work is one mark word per lane), many -> the launcher's load-balancing size.
     int batch = p.batch;
@@ -144,7 +171,8 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
                     const int t = scan + j * (int)blockDim.x + (int)threadIdx.x;
                     if (t < scan_end) {
                         const float *mark = STORE ? p.results + (size_t)t * p.D * p.out_len : p.fitness + t;
-                        if (f2bits(*mark) == kSentinelHeavy) q_s[atomicAdd(&qn_s, 1)] = t;
+                        const uint32_t mw = f2bits(*mark);   // (only_marked 5: the ONLY follow-up behind the threaded code -- a tree left for a general compiler that was not launched is this kernel's too)
+                        if (mw == kSentinelHeavy || (p.only_marked == 5 && mw == kSentinelGeneral)) q_s[atomicAdd(&qn_s, 1)] = t;
                     }
                 }
                 scan += SCAN * (int)blockDim.x;
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
         if (p.marks && threadIdx.x < 64) {  // batches are at most 64 trees: wave 0 sees every class of the batch
             const int c = (int)threadIdx.x < nb ? cls_s[par][threadIdx.x] : TREE_OK;
             if (__any(c == TREE_HEAVY) && threadIdx.x == 0) p.marks[0] = 1u;
-            if (__any(c == TREE_DEEP) && threadIdx.x == 0) p.marks[1] = 1u;
+            if (__any(c == TREE_DEEP) && threadIdx.x == 0 && p.only_marked != 5) p.marks[1] = 1u;
         }
         if (STORE) {
             if ((int)threadIdx.x < nb) {
@@ -278,6 +306,18 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
                 f = c == TREE_DEEP ? bits2f(kSentinelDeep) : c == TREE_HEAVY ? bits2f(kSentinelHeavy) : __builtin_nanf("");
             }
             p.fitness[tree_of(b)] = f;
+        }
+        if (!STORE && !MO && !LEAN && p.only_marked == 5) {   // a tree too deep for the register stack: the scratch stack, here and now (wave 0)
+            bool deep_any = false;
+            for (int b = 0; b < nb; ++b) deep_any |= uni(cls_s[par][b]) == TREE_DEEP;
+            if (deep_any) {
+                __syncthreads();   // (phase 3's sentinel words are written before the values replace them)
+                if (w == 0) {
+                    float stk[kMaxStack + 2];
+                    for (int b = 0; b < nb; ++b)
+                        if (uni(cls_s[par][b]) == TREE_DEEP) general_tree_fitness(p, uni(tree_of(b)), stk);
+                }
+            }
         }
         par ^= 1;
     }
@@ -459,7 +499,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         return (int)launch_general<STORE>(p, 0, stream);
     }
     const bool mo = p.out_len > 1;
-    bool tc_done = false;
+    bool tc_done = false, folded = false;
     ProfCall prof{};
     bool profiling = false;
     if (!STORE) {
@@ -518,10 +558,15 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         if (p.D >= 128) e = p.var_len <= 16 ? launch_fast<2, 16, 16, true, 8, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<2, 16, 32, true, 8, STORE, false>(p, 1, stream, p.marks + 3);
         else e = p.var_len <= 16 ? launch_fast<1, 32, 16, true, 16, STORE, false>(p, 1, stream, p.marks + 3) : launch_fast<1, 32, 32, true, 16, STORE, false>(p, 1, stream, p.marks + 3);
     } else if (tc_done) {
-        if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
-        else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
-        else if (p.var_len <= 16) e = launch_fast<4, 16, 16, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
-        else e = launch_fast<4, 16, 32, false, 4, STORE, false>(p, 1, stream, p.marks + 3);
+        // (one follow-up launch: the FULL register build takes what the threaded code marked and runs the scratch stack itself for the rare
+        // tree that is too deep for its registers; EVOGP_SR_FOLD=0: the scratch-stack kernel as a launch of its own, as in round 4)
+        static const int env_fold = env_int("EVOGP_SR_FOLD", 1);
+        folded = env_fold != 0 && !STORE;
+        const int om = folded ? 5 : 1;
+        if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, om, stream, p.marks + 3);
+        else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, om, stream, p.marks + 3);
+        else if (p.var_len <= 16) e = launch_fast<4, 16, 16, false, 4, STORE, false>(p, om, stream, p.marks + 3);
+        else e = launch_fast<4, 16, 32, false, 4, STORE, false>(p, om, stream, p.marks + 3);
     } else if (!mo && p.D >= 256) {
         if (p.var_len <= 9) e = launch_pair<4, 16, 9, false, 4, STORE>(p, stream);
         else if (p.var_len <= 10) e = launch_pair<4, 16, 10, false, 4, STORE>(p, stream);
@@ -536,7 +581,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         e = p.var_len <= 16 ? launch_pair<1, 32, 16, true, 16, STORE>(p, stream) : launch_pair<1, 32, 32, true, 16, STORE>(p, stream);
     }
     if (e != hipSuccess) return (int)e;
-    e = launch_general<STORE>(p, tc_done && !mo && !p.hint_general ? 4 : 1, stream);
+    if (!folded) e = launch_general<STORE>(p, tc_done && !mo && !p.hint_general ? 4 : 1, stream);
     static const bool dbg_marks = getenv("EVOGP_DEBUG_MARKS") != nullptr;   // diagnostics: the call's flag words (synchronises)
     if (dbg_marks && p.marks) {
         unsigned h[8] = {};

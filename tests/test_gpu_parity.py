@@ -341,6 +341,47 @@ def test_sr_fitness_evolved_forest_against_the_oracle(g, oracle, rng):
     assert_close_classes(g.sr_fitness(*trees, X, y), oracle.sr_fitness(*trees, X, y), RTOL_ARITH, what="generation 30")
 
 
+def test_sr_fitness_trees_too_deep_for_every_register_stack(g, oracle, rng):
+    """Left-leaning trees of 18-20 levels in rows of 64 nodes, every right operand a unary function of a leaf: the operand stack of the
+    interpreter's evaluation order reaches 19-21 entries -- beyond the threaded code's 9 (no reordering in rows of 64) AND beyond the FULL
+    register build's 16, so the scratch-stack evaluation takes them: since round 5 inside the FULL build's launch (csrc/sr_fitness.hip
+    general_tree_fitness; the scratch-stack kernel is no launch of its own behind the threaded code any more).  Mixed with ordinary trees,
+    against the oracle, whole and in halves."""
+    pop, L = 3000, 64
+    v, t, s = (a.copy() for a in oracle.generate(pop, L, 5, 1, 0.0, 0.5, [8, 8], depth2leaf(6), roulette_uniform(ARITH), CS3))
+    deep = 0
+    for r in range(0, pop, 7):
+        levels = int(rng.integers(18, 21))
+        nodes = []
+        for k in range(levels, 0, -1):          # prefix order: level k = f(level k - 1, neg(leaf)), size 3 k + 1
+            nodes.append((3, float(rng.integers(1, 5)), 3 * k + 1))
+        nodes.append((0, float(rng.integers(0, 5)), 1))   # level 0: a variable
+        for _ in range(levels):
+            nodes.append((2, 25.0, 2)); nodes.append((0, float(rng.integers(0, 5)), 1)) if rng.random() < 0.7 else nodes.append((1, float(rng.choice(CS3)), 1))
+        # the right operands follow their level's left subtree: rebuild in true prefix order
+        def build(k):
+            if k == 0:
+                return [(0, float(rng.integers(0, 5)), 1)]
+            left = build(k - 1)
+            right = [(2, 25.0, 2), (0, float(rng.integers(0, 5)), 1)]
+            return [(3, float(rng.integers(1, 5)), 1 + len(left) + 2)] + left + right
+        nodes = build(levels)
+        assert len(nodes) <= L
+        v[r] = 0; t[r] = 0; s[r] = 0
+        for i, (ty, val, sz) in enumerate(nodes):
+            t[r, i], v[r, i], s[r, i] = ty, val, sz
+        deep += 1
+    assert deep > 400
+    X = rng.uniform(-2, 2, (700, 5)).astype(np.float32); y = rng.uniform(-2, 2, (700, 1)).astype(np.float32)
+    want = oracle.sr_fitness(v, t, s, X, y)
+    got = g.sr_fitness(v, t, s, X, y)
+    assert_close_classes(got, want, RTOL_ARITH, what="trees of 19-21 stack entries")
+    h = pop // 2
+    halves = np.concatenate([g.sr_fitness(v[:h], t[:h], s[:h], X, y), g.sr_fitness(v[h:], t[h:], s[h:], X, y)])
+    assert np.array_equal(bits(got), bits(halves))
+    assert np.array_equal(bits(g.sr_fitness(v, t, s, X, y, func_mask=ARITH_MASK | (1 << 25))), bits(got)), "the masked call (no general compiler launch)"
+
+
 def test_full_size_properties(g, oracle):
     """BASELINE full size (pop 100k x 1024 datapoints): size-independent checks —
     (1) fitness of a forest equals fitness of its two halves concatenated (row independence),
