@@ -277,7 +277,7 @@ def main():
     pop = hi - lo
     forest, Xd, yd, X, y = sr_inputs(lo, pop, device)
     total_nodes = int(forest.batch_subtree_size[:, 0].to(torch.int64).sum())
-    # The device reaches its steady clocks only after ~25 ms of work (scripts/dbg/first_calls.py, profiles/r03_first_calls.log: calls
+    # The device reaches its steady clocks only after ~25 ms of work (profiles/r03_first_calls.log: calls
     # 1-4 of a fresh process take 1.28 ms, 5-9 1.23, 10-19 1.18, every later one 1.14): the W warm-up steps the driver asks for
     # (5) end inside that ramp.  PREWARM untimed passes of the same step precede them, so that W + K measure the state a run of
     # thousands of generations is in; the count is reported in the JSON line (`device_prewarm_calls`).
