@@ -46,6 +46,7 @@ PROTOTYPES = {
     "evogp_hip_tournament_select": [_u, _u, _u, C.c_longlong, C.c_longlong, _vp, _vp, _vp],
     "evogp_hip_set_program_buffer_limit": [C.c_ulonglong],
     "evogp_hip_release_workspaces": [],
+    "evogp_hip_set_allocator": [_vp, _vp],
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
     "evogp_hip_debug_set_stats": [_vp],

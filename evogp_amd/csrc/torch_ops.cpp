@@ -13,6 +13,7 @@
 // implementation and no fallback: a CPU tensor fails in the dispatcher exactly as with the reference.
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -566,6 +567,21 @@ TORCH_LIBRARY_IMPL(evogp_cuda, CUDA, m) {
     m.impl("tree_evaluate", &tree_evaluate);
     m.impl("tree_SR_fitness", &tree_SR_fitness);
 }
+
+// the engine's record buffers come out of torch's caching allocator: torch.cuda.memory_allocated() / memory_summary() show them
+// (include/evogp_hip.h evogp_hip_set_allocator; EVOGP_TORCH_ALLOCATOR=0: plain hipMalloc as in rounds 1-4)
+static void *torch_pool_alloc(size_t bytes) {
+    try {
+        return c10::hip::HIPCachingAllocator::raw_alloc(bytes);
+    } catch (...) {
+        return nullptr;
+    }
+}
+static void torch_pool_free(void *ptr) { c10::hip::HIPCachingAllocator::raw_delete(ptr); }
+static const int installed_allocator = [] {
+    const char *e = getenv("EVOGP_TORCH_ALLOCATOR");
+    return (e && e[0] == '0') ? 0 : evogp_hip_set_allocator(&torch_pool_alloc, &torch_pool_free);
+}();
 
 TORCH_LIBRARY(evogp_hip, m) {
     m.def("tree_generate_offset(int pop_size, int gp_len, int var_len, int out_len, int const_samples_len, float out_prob, float const_prob,"

@@ -298,6 +298,14 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
  * HIP graph that holds such a call stays valid while later calls grow or shrink the population.
  *   evogp_hip_record_ring_bytes         bytes of rings currently held on the current device. */
 int evogp_hip_set_program_buffer_limit(unsigned long long bytes);
+/* Where that memory comes from (round 5): by default hipMalloc / hipFree; a caller with an allocator of its own hands in a pair of functions
+ * (alloc returns NULL on failure) and the buffers become visible in its statistics -- the libtorch binding installs torch's caching
+ * allocator when it is loaded, so torch.cuda.memory_allocated() counts them.  The engine synchronises the device before it first touches a
+ * block from a caller's pool.  Only while the engine holds no memory (evogp_hip_release_workspaces first), else EVOGP_E_BADARG; NULL, NULL
+ * restores hipMalloc / hipFree. */
+typedef void *(*evogp_alloc_fn)(size_t bytes);
+typedef void (*evogp_free_fn)(void *ptr);
+int evogp_hip_set_allocator(evogp_alloc_fn alloc, evogp_free_fn free_fn);
 unsigned long long evogp_hip_program_buffer_bytes(void);
 unsigned long long evogp_hip_record_ring_bytes(void);
 int evogp_hip_release_workspaces(void);

