@@ -261,7 +261,7 @@ def test_function_mask_skips_launches_but_never_changes_a_result():
     assert np.array_equal(np.isnan(got), np.isnan(honest.cpu().numpy())) and np.allclose(got[ok], honest.cpu().numpy()[ok], rtol=1e-4)
 
 
-def test_record_memory_is_visible_to_torchs_allocator(g):
+def test_record_memory_is_visible_to_torchs_allocator():
     """The engine's program-record buffer comes out of torch's caching allocator when the libtorch binding is loaded (include/evogp_hip.h
     evogp_hip_set_allocator): torch.cuda.memory_allocated() rises by what evogp_amd.program_buffer_bytes() reports and falls again after
     release_workspaces (VERDICT r04 weak #10: 256-768 MB that torch's statistics did not show)."""
