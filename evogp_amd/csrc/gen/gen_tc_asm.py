@@ -149,7 +149,7 @@ def count_path(L, start, taken, idx_on=True):
     return c
 
 
-def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
+def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     assert K % 4 == 0 or K == 1
     assert 24 + 4 * K + K * DEPTH <= 256
     G = max(K // 4, 1)   # 1-KiB groups of a variable's tile: 64 lanes x 16 bytes (K = 1 uses the first row of every lane's four)
@@ -2332,10 +2332,10 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False):
     body = "\n".join(f'    "{line}\\n\\t"' for line in L)
     clob = ['"memory"', '"vcc"', '"scc"'] + [f'"s{i}"' for i in range(8, 102)] + [f'"v{i}"' for i in range(0, NV)]
     clob_txt = ", ".join(clob)
-    name = f"K{K}" + ("S" if stats else "") + ("", "F", "H")[fast] + ("U" if fused else "")
+    name = f"K{K}" + ("W" if wide else "") + ("S" if stats else "") + ("", "F", "H")[fast] + ("U" if fused else "")
     out = f"// GENERATED by gen/gen_tc_asm.py (K = {K} rows per lane, {DEPTH}-entry operand stack, VGPRs v0..v{NV - 1}) — do not edit.\n"
     out += f"#define EVOGP_TC_{name}_DEPTH {DEPTH}\n#define EVOGP_TC_{name}_VGPRS {NV}\n"
-    if K == 8 and not stats and not fast and not fused:
+    if K == 8 and not stats and not fast and not fused and not wide:
         out += f"#define EVOGP_TC_SLOT {SLOT}\n#define EVOGP_TC_NHANDLERS {NHF}\n#define EVOGP_TC_UNARY_MASK {(1 << len(UNARY)) - 1}\n#define EVOGP_TC_HEAVY_REGS {HEAVY_REGS}\n#define EVOGP_TC_DIVIP_REGS {DIVIP_REGS}\n"
         for n, i in sorted(hid.items(), key=lambda kv: kv[1]):
             out += f"#define EVOGP_TC_H_{n.upper()} {i}\n"
@@ -2398,6 +2398,11 @@ if __name__ == "__main__":
                 for fast in (0, 1, 2):   # the fused build (one batch per entry, sr_fused_kernel)
                     f.write(gen(K, depth, fast=fast, fused=True))
                 f.write(gen(K, depth, stats=True))  # cycle-accounting build (its top stack slot holds the counters)
+                # the WIDE-stack build: 13 entries (160 VGPRs, three waves per SIMD, workgroups of 12 waves) for forests of 7-10 outputs,
+                # whose accumulators do not fit the nine entries above and which otherwise run 4 rows per lane (BASELINE configs[3]:
+                # 10 outputs, 1797 rows -- twice the dispatches for the same rows)
+                for fast in (0, 1, 2):
+                    f.write(gen(K, 13, fast=fast, wide=True))
         print("wrote", f"{outdir}/tc_interp_k{K}.inc")
     # per-handler instruction counts of the generated interpreters, read by bench.py (a build artefact like the .inc files)
     os.makedirs(f"{outdir}/../lib", exist_ok=True)

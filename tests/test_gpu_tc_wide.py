@@ -437,7 +437,9 @@ def test_division_in_place_and_gather_forms_at_every_stack_height(g, oracle, rng
 
 # ---- multi-output trees ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("out_len,D,funcs,L", [(2, 1024, ARITH, 64), (4, 1024, ARITH, 64), (6, 700, ARITH, 64), (4, 1024, EXACT_WIDE, 128),
-                                               (10, 200, ARITH, 128), (12, 1797, ARITH, 64), (3, 8, ARITH, 64), (4, 1024, ARITH + [SIN, EXP, LOG], 64)])
+                                               (10, 200, ARITH, 128), (12, 1797, ARITH, 64), (3, 8, ARITH, 64), (4, 1024, ARITH + [SIN, EXP, LOG], 64),
+                                               # 7-10 outputs over more than 256 rows: the 8-row interpreter's wide-stack build
+                                               (8, 1024, ARITH, 64), (10, 1797, EXACT_WIDE, 128), (7, 600, ARITH + [SIN, EXP, LOG], 64)])
 def test_multi_output(g, oracle, rng, out_len, D, funcs, L):
     mlc = 5 if IF in funcs else 6   # full trees must fit the row: ternary depth 5 = 121 nodes, binary depth 6 = 63
     forest = oracle.generate(5000, L, 7, out_len, 0.5, 0.5, [out_len, D], depth2leaf(mlc, 0.15), roulette_uniform(funcs), CS)
