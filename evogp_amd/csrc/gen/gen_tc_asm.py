@@ -96,7 +96,7 @@ DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such 
 EARLYREC = True  # END of a tree's last tile sends for the record of the batch's next tree (EVOGP_TC_GEN_EARLYREC=0: the tree loop does)
 L2WARM = True    # vector loads that pull the next batch's records into L2 (EVOGP_TC_GEN_L2WARM=0: off)
 KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_TC_GEN_KWARM_LINES)
-FUSED_SIZE_OFF, FUSED_LEN_OFF = 96 + 16, 96 + 60   # FusedParams (sr_tc.hip): c.size and c.gp_len behind the 96 bytes of TcParams (static_asserts there)
+FUSED_SIZE_OFF, FUSED_LEN_OFF = 104 + 16, 104 + 60   # FusedParams (sr_tc.hip): c.size and c.gp_len behind the 104 bytes of TcParams (static_asserts there)
 TOUCH = True     # fused build: the block's entry touches the rows of the wave's next batch (EVOGP_TC_GEN_TOUCH=0: off)
 TRIGPK = True    # sin / cos / tan over row pairs with packed multiplications and fused multiply-adds (EVOGP_TC_GEN_TRIGPK=0: row by row)
 LIBPK = True     # pow / sinh / cosh: the library's sequences over row PAIRS (gen/pair_rows.py; EVOGP_TC_GEN_LIBPK=0: row by row)
@@ -2012,104 +2012,92 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     a(f"s_add_u32 s{T1}, s{sTILE}, 1")
     a(f"s_branch {lab('end_acc')}")
 
-    # end of a classifier program: per row the arg-max over the out_len accumulators as torch.argmax(clip(softmax(x))) sees it
-    # -- the FIRST maximum; index 0 when any output is NaN or the maximum is infinite (the soft-max row is then NaN) -- compared
-    # with the row's label; v6 counts the hits (as a float: exact below 2^24 rows).  aux = K * out_len is in T2, the labels
-    # (int32 bits) in the T bank.  Row registers: maximum M in P0 (made NaN when the row holds a NaN: a NaN sum <=> a NaN output,
-    # or both infinities -- which the infinite maximum already covers), the sum, then the tie threshold M - 1.25 * 2^-23 in P1, and in Q
-    # two 16-bit minima: low half = first index whose output EQUALS M (the arg-max), high half = first index whose output is
-    # >= the threshold.  high < low: an output in front of the maximum is so close to it that torch's fp32 soft-max may round both
-    # to the same float and return the earlier index (interp.hpp kSoftmaxTieMargin) -- such a row is AMBIGUOUS, and a tree with an
-    # ambiguous row leaves through the run-time bail-out: sr_wide.hip's recount kernel evaluates it with torch's own arithmetic.
-    Mx, Sm, Bx = P[0], P[1], Q
+    # end of a classifier program: per row, is the arg-max over the out_len accumulators -- as torch.argmax(clip(softmax(x))) sees it:
+    # the FIRST maximum; index 0 when any output is NaN or the maximum is infinite (the soft-max row is then NaN) -- the row's label?
+    # v6 counts the hits (as a float: exact below 2^24 rows).  aux = K * out_len is in T2, the labels (int32 bits) in the T bank.
+    # The launch staged the rows IN THE ORDER OF THEIR LABELS (sr_tc.hip, tc_label_groups_kernel): the 64 lanes of a row register hold
+    # one label, or a few in consecutive lanes (-1: no row), so the label L of a SEGMENT of lanes is a scalar and the question needs no
+    # index search.  With P_j = max(out_0 .. out_j), the running maxima written over the accumulators, and M = P_(n-1):
+    #     hit        <=>  P_L == M  and  P_(L-1) < M - d       (output L is the maximum and nothing in front of it comes close)
+    #     ambiguous  <=>  P_L >= M - d  and  P_(L-1) < M  and not hit
+    # d = 1.25 * 2^-23 (interp.hpp kSoftmaxTieMargin): an output within d of the maximum may round to the same soft-max probability, and
+    # torch then returns whichever comes first.  A tree with an ambiguous row leaves through the run-time bail-out: sr_wide.hip's recount
+    # kernel evaluates it with torch's own arithmetic.  (Ambiguity only matters where the label is one of the close outputs; a near-tie
+    # between two other outputs in front of the label also trips the test: rare, and the recount is exact.)  Rows whose maximum is
+    # infinite or that hold a NaN -- a NaN sum <=> a NaN output, or both infinities, which the infinite maximum covers -- get M = NaN:
+    # every compare fails, and they are hits where the label is 0.
+    # Per tile and 10 outputs: ~270 vector instructions instead of the ~620 of the index search over all outputs (round 5).
+    Mx, Sm = P[0], P[1]
+    LOGK = K.bit_length() - 1
     a(f"{lab('endcls_body')}:")
-    a(f"s_mov_b32 m0, {hex(MODE['SRC0'] << 12)}")     # output 0
-    for k in range(K):
-        a(f"v_mov_b32 v{Mx + k}, v{S0 + k}")
-    for k in range(K):
-        a(f"v_mov_b32 v{Sm + k}, v{Mx + k}")
     a("s_mov_b32 m0, 0")
+    rows_mov(Sm, S0)
+    for k in range(K):
+        a(f"v_mov_b32 v{Q + k}, 0xff800000")           # "the maximum in front of output 0" (the registers below the accumulators)
     a(f"s_mov_b32 s{sX}, {K}")                         # K * output index
     a(f"s_cmp_lt_u32 s{sX}, s{T2}")
     a(f"s_cbranch_scc0 {lab('endcls_first')}")
     a(f"{lab('endcls_max')}:")
     a(f"s_add_u32 m0, s{sX}, {hex(MODE['SRC0'] << 12)}")
+    if K >= 2:
+        for k in range(0, K, 2):
+            a(f"v_pk_add_f32 v[{Sm + k}:{Sm + k + 1}], v[{S0 + k}:{S0 + k + 1}], v[{Sm + k}:{Sm + k + 1}]")
+    else:
+        a(f"v_add_f32 v{Sm}, v{S0}, v{Sm}")
+    a(f"s_add_u32 m0, s{sX}, {hex((MODE['SRC0'] | MODE['SRC1'] | MODE['DST']) << 12)}")
     for k in range(K):
-        a(f"v_max_f32 v{Mx + k}, v{S0 + k}, v{Mx + k}")
-        a(f"v_add_f32 v{Sm + k}, v{S0 + k}, v{Sm + k}")
+        a(f"v_max_f32 v{S0 + k}, v{S0 + k}, v{S0 - K + k}")      # P_j = max(out_j, P_(j-1)), in place
     a(f"s_add_u32 s{sX}, s{sX}, {K}")
     a(f"s_cmp_lt_u32 s{sX}, s{T2}")
     a(f"s_cbranch_scc1 {lab('endcls_max')}")
     a(f"{lab('endcls_first')}:")
+    a(f"s_sub_u32 s{sX}, s{T2}, {K}")
+    a(f"s_add_u32 m0, s{sX}, {hex(MODE['SRC0'] << 12)}")
+    for k in range(K):
+        a(f"v_mov_b32 v{Mx + k}, v{S0 + k}")
     a("s_mov_b32 m0, 0")
     for k in range(K):
-        a(f"v_cmp_u_f32 vcc, v{Sm + k}, v{Sm + k}")
+        a(f"v_fma_f32 v9, v{Mx + k}, 0, v{Sm + k}")              # NaN <=> a NaN sum or an infinite (NaN) maximum
+        a("v_cmp_u_f32 vcc, v9, v9")
         a("s_nop 1")
         a(f"v_cndmask_b32 v{Mx + k}, v{Mx + k}, v8, vcc")          # v8 = NaN
-        a(f"v_add_f32 v{Sm + k}, 0xb4200000, v{Mx + k}")           # threshold: M - 1.25 * 2^-23 (interp.hpp kSoftmaxTieMargin)
-        a(f"v_mov_b32 v{Bx + k}, -1")
-    # every output, from the last down to output 0: index minima under the two compares (source 0 is M0-relative inside this loop,
-    # so the running minima cannot be source 0 of anything, and an SGPR operand plus VCC would be two constant-bus operands: the
-    # compares write EXEC and the packed minimum takes its constant from an SGPR)
-    a(f"s_sub_u32 s{sX}, s{T2}, {K}")
-    a(f"{lab('endcls_arg')}:")
-    a(f"s_add_u32 m0, s{sX}, {hex(MODE['SRC0'] << 12)}")
-    a(f"s_lshr_b32 s{T1}, s{sX}, {K.bit_length() - 1}")   # output index = sX / K (K is a power of two)
-    a(f"s_lshl_b32 s{sA}, s{T1}, 16")
-    a(f"s_or_b32 s{sA}, s{sA}, 0xffff")                   # {index, 0xffff}: lowers the high half only
-    a(f"s_or_b32 s{T4}, s{T1}, 0xffff0000")               # {0xffff, index}: lowers the low half only
+        a(f"v_add_f32 v{Sm + k}, 0xb4200000, v{Mx + k}")           # M - d
     for k in range(K):
-        a(f"v_cmpx_ge_f32 exec, v{S0 + k}, v{Sm + k}")
-        a(f"v_pk_min_u16 v{Bx + k}, s{sA}, v{Bx + k}")
-        a(f"v_cmpx_eq_f32 exec, v{S0 + k}, v{Mx + k}")
-        a(f"v_pk_min_u16 v{Bx + k}, s{T4}, v{Bx + k}")
+        seg, row, nsp = lab(f"endcls_seg{k}"), lab(f"endcls_row{k}"), lab(f"endcls_nsp{k}")
+        a(f"v_cmp_le_i32 vcc, 0, v{T + k}")
+        a(f"s_mov_b64 s[{sA}:{sA + 1}], vcc")                      # lanes of this register still to be judged
+        a(f"{seg}:")
+        a(f"s_cmp_eq_u64 s[{sA}:{sA + 1}], 0")
+        a(f"s_cbranch_scc1 {row}")
+        a(f"s_ff1_i32_b64 s{T4}, s[{sA}:{sA + 1}]")
+        a(f"v_readlane_b32 s{T4}, v{T + k}, s{T4}")                # the segment's label
+        a("s_nop 1")
+        a(f"v_cmp_eq_u32 vcc, s{T4}, v{T + k}")
+        a(f"s_lshl_b32 s{T4}, s{T4}, {LOGK}")
+        a(f"s_andn2_b64 s[{sA}:{sA + 1}], s[{sA}:{sA + 1}], vcc")
+        a("s_mov_b64 exec, vcc")
+        a(f"s_add_u32 m0, s{T4}, {hex(MODE['SRC0'] << 12)}")
+        a(f"v_mov_b32 v5, v{S0 + k}")                              # P_L
+        a(f"v_mov_b32 v4, v{S0 - K + k}")                          # P_(L-1)
+        a("s_mov_b32 m0, 0")
+        a(f"v_cmp_eq_f32 vcc, v5, v{Mx + k}")
+        a(f"v_cmp_lt_f32 s[{T1}:{T2}], v4, v{Sm + k}")
+        a(f"s_and_b64 s[{T1}:{T2}], vcc, s[{T1}:{T2}]")            # hit
+        a(f"s_cmp_lg_u32 s{T4}, 0")
+        a(f"s_cbranch_scc1 {nsp}")
+        a(f"v_cmp_u_f32 vcc, v{Mx + k}, v{Mx + k}")                # label 0: the rows without a soft-max
+        a(f"s_or_b64 s[{T1}:{T2}], s[{T1}:{T2}], vcc")
+        a(f"{nsp}:")
+        a(f"v_cndmask_b32_e64 v9, 0, 1.0, s[{T1}:{T2}]")
+        a("v_add_f32 v6, v6, v9")
+        a(f"v_cmp_ge_f32 vcc, v5, v{Sm + k}")
+        a(f"s_andn2_b64 vcc, vcc, s[{T1}:{T2}]")
+        a(f"v_cmp_lt_f32 s[{T1}:{T2}], v4, v{Mx + k}")
+        a(f"s_and_b64 vcc, vcc, s[{T1}:{T2}]")
         a("s_mov_b64 exec, -1")
-    a(f"s_sub_u32 s{sX}, s{sX}, {K}")
-    a(f"s_cmp_ge_i32 s{sX}, 0")
-    a(f"s_cbranch_scc1 {lab('endcls_arg')}")
-    a("s_mov_b32 m0, 0")
-    a(f"s_mov_b64 s[{sA}:{sA + 1}], 0")                   # (sA, sX: free from here on)
-    a(f"s_movk_i32 s{T1}, 0x207")                        # NaN | -inf | +inf
-    for k in range(K):
-        a(f"v_lshrrev_b32 v9, 16, v{Bx + k}")
-        a(f"v_and_b32 v{Bx + k}, 0xffff, v{Bx + k}")
-        a(f"v_cmp_lt_u32 vcc, v9, v{Bx + k}")
-        a(f"s_or_b64 s[{sA}:{sA + 1}], s[{sA}:{sA + 1}], vcc")
-        a(f"v_cmp_class_f32_e64 vcc, v{Mx + k}, s{T1}")
-        a("s_nop 1")
-        a(f"v_cndmask_b32_e64 v{Bx + k}, v{Bx + k}, 0, vcc")
-    a(f"s_cmp_lg_u64 s[{sA}:{sA + 1}], 0")
-    a(f"s_cbranch_scc1 {lab('bail')}")
-    # hits: rows of this tile that exist (flags bit 1 / bit 4 as in END) and whose arg-max is their label
-    a(f"s_add_u32 s{T1}, s{sTILE}, 1")
-    a(f"s_cmp_lt_u32 s{T1}, s15")
-    a(f"s_cselect_b32 s{T1}, 0, s17")
-    a("s_bitcmp1_b32 s17, 4")
-    a(f"s_cselect_b32 s{T1}, s17, s{T1}")
-    a(f"s_and_b32 s{T1}, s{T1}, 2")
-    a(f"s_cmp_eq_u32 s{T1}, 0")
-    a(f"s_cbranch_scc1 {lab('endcls_full')}")
-    a(f"s_mul_i32 s{T4}, s{sTILE}, {64 * K}")
-    a(f"v_mul_u32_u24 v5, {RPL}, v0")
-    a(f"v_add_u32 v5, s{T4}, v5")
-    for k in range(K):
-        g, q = divmod(k, 4)
-        a(f"v_add_u32 v9, {g * 256 + q}, v5")
-        a(f"v_cmp_eq_u32 vcc, v{Bx + k}, v{T + k}")
-        a("s_nop 1")
-        a("v_cndmask_b32_e64 v4, 0, 1.0, vcc")
-        a("v_cmp_gt_u32 vcc, s13, v9")
-        a("s_nop 1")
-        a("v_cndmask_b32 v4, 0, v4, vcc")
-        a("v_add_f32 v6, v6, v4")
-    a(f"s_branch {lab('endcls_done')}")
-    a(f"{lab('endcls_full')}:")
-    for k in range(K):
-        a(f"v_cmp_eq_u32 vcc, v{Bx + k}, v{T + k}")
-        a("s_nop 1")
-        a("v_cndmask_b32_e64 v4, 0, 1.0, vcc")
-        a("v_add_f32 v6, v6, v4")
-    a(f"{lab('endcls_done')}:")
+        a(f"s_cbranch_vccnz {lab('bail')}")
+        a(f"s_branch {seg}")
+        a(f"{row}:")
     a("s_set_gpr_idx_off")
     a(f"s_add_u32 s{T1}, s{sTILE}, 1")
     a(f"s_branch {lab('end_acc')}")
