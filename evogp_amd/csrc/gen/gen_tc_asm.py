@@ -96,7 +96,7 @@ DIV_LO, DIV_HI = 0x28800000, 0x56800000  # 2^-46, 2^46: v_div_scale leaves such 
 EARLYREC = True  # END of a tree's last tile sends for the record of the batch's next tree (EVOGP_TC_GEN_EARLYREC=0: the tree loop does)
 L2WARM = True    # vector loads that pull the next batch's records into L2 (EVOGP_TC_GEN_L2WARM=0: off)
 KWARM_LINES = 4  # 64-byte lines of the next record the warm-up touches (EVOGP_TC_GEN_KWARM_LINES)
-FUSED_SIZE_OFF, FUSED_LEN_OFF = 104 + 16, 104 + 60   # FusedParams (sr_tc.hip): c.size and c.gp_len behind the 104 bytes of TcParams (static_asserts there)
+FUSED_SIZE_OFF, FUSED_LEN_OFF = 96 + 16, 96 + 60   # FusedParams (sr_tc.hip): c.size and c.gp_len behind the 96 bytes of TcParams (static_asserts there)
 TOUCH = True     # fused build: the block's entry touches the rows of the wave's next batch (EVOGP_TC_GEN_TOUCH=0: off)
 TRIGPK = True    # sin / cos / tan over row pairs with packed multiplications and fused multiply-adds (EVOGP_TC_GEN_TRIGPK=0: row by row)
 LIBPK = True     # pow / sinh / cosh: the library's sequences over row PAIRS (gen/pair_rows.py; EVOGP_TC_GEN_LIBPK=0: row by row)
@@ -2032,8 +2032,6 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     a(f"{lab('endcls_body')}:")
     a("s_mov_b32 m0, 0")
     rows_mov(Sm, S0)
-    for k in range(K):
-        a(f"v_mov_b32 v{Q + k}, 0xff800000")           # "the maximum in front of output 0" (the registers below the accumulators)
     a(f"s_mov_b32 s{sX}, {K}")                         # K * output index
     a(f"s_cmp_lt_u32 s{sX}, s{T2}")
     a(f"s_cbranch_scc0 {lab('endcls_first')}")
@@ -2056,12 +2054,24 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     for k in range(K):
         a(f"v_mov_b32 v{Mx + k}, v{S0 + k}")
     a("s_mov_b32 m0, 0")
+    # (control registers that are dead until the next pass of the program re-initialises them -- the handler address's low word, J, H --
+    # serve as scratch: three mask registers besides VCC)
+    sL, sM2 = sPC, sJ
+    assert sJ % 2 == 0 and sH == sJ + 1
+    masks = ["vcc", f"s[{sM2}:{sM2 + 1}]", f"s[{T1}:{T2}]"]
     for k in range(K):
-        a(f"v_fma_f32 v9, v{Mx + k}, 0, v{Sm + k}")              # NaN <=> a NaN sum or an infinite (NaN) maximum
-        a("v_cmp_u_f32 vcc, v9, v9")
-        a("s_nop 1")
-        a(f"v_cndmask_b32 v{Mx + k}, v{Mx + k}, v8, vcc")          # v8 = NaN
+        a(f"v_fma_f32 v{Q + k}, v{Mx + k}, 0, v{Sm + k}")          # NaN <=> a NaN sum or an infinite (NaN) maximum
+    for k in range(K + 2):                                        # (the mask of row k is read two instructions after its compare)
+        if k < K:
+            a(f"v_cmp_u_f32 {masks[k % 3]}, v{Q + k}, v{Q + k}")
+        if k >= 2:
+            j = k - 2
+            if K < 3:
+                a("s_nop 1")
+            a(f"v_cndmask_b32_e64 v{Mx + j}, v{Mx + j}, v8, {masks[j % 3]}")   # v8 = NaN
+    for k in range(K):
         a(f"v_add_f32 v{Sm + k}, 0xb4200000, v{Mx + k}")           # M - d
+        a(f"v_mov_b32 v{Q + k}, 0xff800000")                       # "the maximum in front of output 0" (the registers below the accumulators)
     for k in range(K):
         seg, row, nsp = lab(f"endcls_seg{k}"), lab(f"endcls_row{k}"), lab(f"endcls_nsp{k}")
         a(f"v_cmp_le_i32 vcc, 0, v{T + k}")
@@ -2073,16 +2083,18 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a(f"v_readlane_b32 s{T4}, v{T + k}, s{T4}")                # the segment's label
         a("s_nop 1")
         a(f"v_cmp_eq_u32 vcc, s{T4}, v{T + k}")
-        a(f"s_lshl_b32 s{T4}, s{T4}, {LOGK}")
+        a(f"s_lshl_b32 s{sL}, s{T4}, {LOGK}")
         a(f"s_andn2_b64 s[{sA}:{sA + 1}], s[{sA}:{sA + 1}], vcc")
         a("s_mov_b64 exec, vcc")
-        a(f"s_add_u32 m0, s{T4}, {hex(MODE['SRC0'] << 12)}")
-        a(f"v_mov_b32 v5, v{S0 + k}")                              # P_L
-        a(f"v_mov_b32 v4, v{S0 - K + k}")                          # P_(L-1)
-        a("s_mov_b32 m0, 0")
-        a(f"v_cmp_eq_f32 vcc, v5, v{Mx + k}")
-        a(f"v_cmp_lt_f32 s[{T1}:{T2}], v4, v{Sm + k}")
+        a(f"s_add_u32 m0, s{sL}, {hex(MODE['SRC0'] << 12)}")       # source 0: P_L / P_(L-1)
+        a(f"v_cmp_eq_f32 vcc, v{S0 + k}, v{Mx + k}")
+        a(f"v_cmp_lt_f32 s[{T1}:{T2}], v{S0 - K + k}, v{Sm + k}")
+        a(f"v_cmp_ge_f32 s[{sM2}:{sM2 + 1}], v{S0 + k}, v{Sm + k}")
         a(f"s_and_b64 s[{T1}:{T2}], vcc, s[{T1}:{T2}]")            # hit
+        a(f"v_cmp_lt_f32 vcc, v{S0 - K + k}, v{Mx + k}")
+        a("s_mov_b32 m0, 0")
+        a(f"s_and_b64 s[{sM2}:{sM2 + 1}], s[{sM2}:{sM2 + 1}], vcc")
+        a(f"s_andn2_b64 s[{sM2}:{sM2 + 1}], s[{sM2}:{sM2 + 1}], s[{T1}:{T2}]")   # ambiguous
         a(f"s_cmp_lg_u32 s{T4}, 0")
         a(f"s_cbranch_scc1 {nsp}")
         a(f"v_cmp_u_f32 vcc, v{Mx + k}, v{Mx + k}")                # label 0: the rows without a soft-max
@@ -2090,12 +2102,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a(f"{nsp}:")
         a(f"v_cndmask_b32_e64 v9, 0, 1.0, s[{T1}:{T2}]")
         a("v_add_f32 v6, v6, v9")
-        a(f"v_cmp_ge_f32 vcc, v5, v{Sm + k}")
-        a(f"s_andn2_b64 vcc, vcc, s[{T1}:{T2}]")
-        a(f"v_cmp_lt_f32 s[{T1}:{T2}], v4, v{Mx + k}")
-        a(f"s_and_b64 vcc, vcc, s[{T1}:{T2}]")
         a("s_mov_b64 exec, -1")
-        a(f"s_cbranch_vccnz {lab('bail')}")
+        a(f"s_cmp_lg_u64 s[{sM2}:{sM2 + 1}], 0")
+        a(f"s_cbranch_scc1 {lab('bail')}")
         a(f"s_branch {seg}")
         a(f"{row}:")
     a("s_set_gpr_idx_off")
