@@ -80,7 +80,8 @@ HEAVY_REGS = 24  # VGPRs the transcribed library sequences borrow from the top o
 SLOT = 256  # bytes per handler slot
 DIVIP_REGS = 12  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
 DIVIP = ("SS", "SC", "CS")  # division forms with an in-place handler (operands read where they are, temporaries above the stack)
-NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1 + 1  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls + swap
+DIVR = ("SV", "VV", "CV")   # divisions by a variable through the launch's reciprocal columns (divr_*: the product with 1 / v)
+NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1 + 1 + len(DIVR)  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls + swap + divisions by reciprocal columns
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
@@ -216,7 +217,9 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         hid[f"divip_{form}"] = nh + 14 + i
     hid["end_cls"] = nh + 14 + len(DIVIP)
     hid["swap"] = nh + 14 + len(DIVIP) + 1
-    assert NHF == nh + 14 + len(DIVIP) + 2
+    for i, form in enumerate(DIVR):
+        hid[f"divr_{form}"] = nh + 14 + len(DIVIP) + 2 + i
+    assert NHF == nh + 14 + len(DIVIP) + 2 + len(DIVR)
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -541,11 +544,13 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
             for k in range(K):
                 a(f"v_mov_b32 v{dst + k}, v{src + k}")
 
-    def arith(op, form, fl):
+    def arith(op, form, fl, name=None, guard=None):
         cur, nxt = P[fl], P[1 - fl]
         ins = {"add": "v_add_f32", "sub": "v_sub_f32", "mul": "v_mul_f32"}[op]
         rev = {"add": "v_add_f32", "sub": "v_subrev_f32", "mul": "v_mul_f32"}[op]
-        begin(f"{op}_{form}", fl)
+        begin(name or f"{op}_{form}", fl)
+        if guard:
+            guard()
         entry()
         if form == "SS":
             prefetch(nxt)
@@ -1132,6 +1137,41 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         m0_stack(MODE["DST"], -2 * K)
         rows_mov(S0, T)
         epilogue()
+        # x / v with the reciprocal of v read instead of computed.  A launch in the SHORT / FAST division modes may stage a second copy of
+        # the variables' columns behind the labels (sr_tc.hip, tc_stage_dataset; TcCompileParams::recip): when EVERY column of the
+        # dataset lies in [2^-46, 2^46] (NaN allowed) it holds the correctly rounded reciprocals and flags bit 11 is set.  The compiler
+        # then names a division by a variable divr_* and puts the KiB index of the variable's reciprocal column into the word's aux
+        # field; everything else in the word is the division's.  The handler is the trusted-variable division (range test of a
+        # stack numerator, quotient estimate, one correction) without its v_rcp_f32 -- the eight of them were half of such a handler's
+        # vector clocks.  Without bit 11 (or in a build without the range-tested rows) the word runs through the division's own handler.
+        for form in DIVR:
+            begin(f"divr_{form}", fl)
+            if not (use_range and TRUST):
+                a(f"s_branch {lab(f'h{fl}_div_{form}')}")
+                continue
+            a("s_bitcmp1_b32 s17, 11")
+            a(f"s_cbranch_scc0 {lab(f'h{fl}_div_{form}')}")
+            read_aux(T2)
+            entry()
+            a(f"v_lshl_add_u32 v5, s{T2}, 10, v2")
+            read_bank(Q, 5)                                   # the reciprocals of the divisor's rows
+            if form == "VV":
+                a(f"s_movrels_b32 s{sBop}, s{W + 1}")
+                a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
+                read_bank(T, 5)                               # the divisor's rows
+            if form == "CV":
+                a(f"s_movrels_b32 s{sA}, s{W + 1}")
+            prefetch(nxt)
+            wait_cur()
+            if form == "SV":
+                m0_stack(MODE["SRC0"] | MODE["SRC1"], -K)
+                rows_mov(T, S0)
+                a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
+                a("s_mov_b32 m0, 0")
+            else:
+                a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
+                a(f"s_add_u32 s{sH}, s{sH}, {K}")
+            a(f"s_branch {lab(f'divr_body_{form}{fl}')}")
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # In-place division bodies.  The gather forms above copy the operands into fixed banks because the division's temporaries
@@ -1325,6 +1365,43 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
             wait_cur()
             push_dst()
             fast_pair_rows(cur, [T + k for k in range(K)], TT + (QT if DIVABREAST and K >= 8 else []), out, out_m0=sDST)
+            epilogue()
+
+    # divr_* (see the handlers): the rows of a division whose divisor's reciprocals are in the Q bank
+    if use_range and TRUST:
+        def recip_pair_rows(xs, ys, out):
+            """fast_pair_rows with the reciprocals read from the Q bank; two row pairs abreast (quotient estimates in v18-v19 / v22-v23,
+            residuals in v20-v21 / v4-v5)"""
+            sets = [(18, 20), (22, 4)]
+            pairs = list(range(0, K, 2))
+            for g0 in range(0, len(pairs), len(sets)):
+                grp = list(zip(pairs[g0:g0 + len(sets)], sets))
+                for k, (q, e) in grp:
+                    xp, xh = pk(xs, k)
+                    a(f"v_pk_mul_f32 v[{q}:{q + 1}], {xp}, v[{Q + k}:{Q + k + 1}] op_sel_hi:[{xh},1]")
+                for k, (q, e) in grp:
+                    xp, xh = pk(xs, k)
+                    yp, yh = pk(ys, k)
+                    a(f"v_pk_fma_f32 v[{e}:{e + 1}], {yp}, v[{q}:{q + 1}], {xp} op_sel_hi:[{yh},1,{xh}] neg_lo:[1,0,0] neg_hi:[1,0,0]")
+                a(f"s_mov_b32 m0, s{sDST}")
+                for k, (q, e) in grp:
+                    a(f"v_pk_fma_f32 v[{out[k]}:{out[k] + 1}], v[{e}:{e + 1}], v[{Q + k}:{Q + k + 1}], v[{q}:{q + 1}]")
+                if g0 + len(sets) < len(pairs):
+                    a("s_mov_b32 m0, 0")
+
+        for fl in (0, 1):
+            cur = [P[fl] + k for k in range(K)]
+            tb = [T + k for k in range(K)]
+            out = [S0 + k for k in range(K)]
+            a(f"{lab(f'divr_body_SV{fl}')}:")                  # the numerator (a copy of the stack's top entry in T) is tested; a block
+            range_test(tb, [], [18, 19, 20, 21, 22, 23], lab(f"divbody_Tc{fl}"))   # that fails goes to the division's own body
+            recip_pair_rows(tb, cur, out)
+            epilogue()
+            a(f"{lab(f'divr_body_CV{fl}')}:")                  # (the compiler checked the constant's range)
+            recip_pair_rows(f"s{sA}", cur, out)
+            epilogue()
+            a(f"{lab(f'divr_body_VV{fl}')}:")
+            recip_pair_rows(cur, tb, out)
             epilogue()
 
     # ---- library sequences run row by row (pow, sinh, cosh: 120-190 instructions and 14-24 registers each; K unrolled
