@@ -34,7 +34,7 @@ for name, funcs, out_len in (("+ - * /", ["+", "-", "*", "/"], 1), ("+ - * / sin
                              ("+ - * / exp log pow", ["+", "-", "*", "/", "exp", "log", "pow"], 1),
                              ("+ - * / max min < > if (generic stubs)", ["+", "-", "*", "/", "max", "min", "<", ">", "if"], 1),
                              ("+ - * /, 4 outputs", ["+", "-", "*", "/"], 4), ("+ - * /, 6 outputs", ["+", "-", "*", "/"], 6),
-                             ("+ - * /, 10 outputs (K = 4)", ["+", "-", "*", "/"], 10),
+                             ("+ - * /, 10 outputs (8 rows, wide stack)", ["+", "-", "*", "/"], 10),
                              ("+ - * / sin cos tan, 4 outputs", ["+", "-", "*", "/", "sin", "cos", "tan"], 4),
                              ("vis.ipynb set: + - log sqrt pow / inv", ["+", "-", "log", "sqrt", "pow", "/", "inv"], 1)):
     mlc = 4 if "if" in funcs else 6   # a full tree must fit the 64-node row (descriptor.py:19-31)

@@ -549,6 +549,64 @@ def test_classifier_count_on_the_threaded_code(g, oracle, rng, var_len, out_len,
     assert np.array_equal(got, want), (np.abs(got - want).max(), (got != want).mean(), np.flatnonzero(got != want)[:5])
 
 
+@pytest.mark.parametrize("var_len,out_len,D,classes", [(5, 4, 150, "skewed"), (6, 10, 700, "sparse"), (4, 3, 1300, "out-of-range"), (3, 2, 40, "one")])
+def test_classifier_rows_in_label_order(g, oracle, rng, var_len, out_len, D, classes):
+    """The interpreter launches of a classifier call stage the rows sorted by label (tc_label_groups_kernel) and END_CLS judges a
+    SEGMENT of lanes against its scalar label.  Label distributions that shape the segments: one class with almost all rows, classes with a
+    handful of rows each (several segments per row register), labels outside [0, out_len) (-3, out_len, 1000: never a hit,
+    classification.py:62-75 compares an index below out_len with them), a single class.  Outputs that tie exactly (two outputs carrying
+    the same variable or constant: the FIRST maximum wins) are frequent in these forests of few variables."""
+    funcs = [ADD, SUB, MUL, DIV, MAX, NEG]
+    pop = 1500
+    f = oracle.generate(pop, 64, var_len, out_len, 0.5, 0.5, [D, out_len + 1], depth2leaf(5, 0.1), roulette_uniform(funcs), [-1.0, 0.0, 1.0, 0.5])
+    X = rng.uniform(-4, 4, (D, var_len)).astype(np.float32)
+    X[rng.random((D, var_len)) < 0.05] = 0.0
+    if classes == "skewed":
+        labels = np.where(rng.random(D) < 0.9, 1, rng.integers(0, out_len, D))
+    elif classes == "sparse":
+        labels = np.repeat(np.arange(out_len), [3, 90, 1, 64, 65, 200, 2, 127, 128, 20])[:D]
+        labels = np.concatenate([labels, np.full(D - len(labels), 5)])
+        rng.shuffle(labels)
+    elif classes == "out-of-range":
+        labels = rng.choice(np.array([-3, 0, 1, 2, out_len, 1000]), D)
+    else:
+        labels = np.full(D, 1)
+    labels = labels.astype(np.int32)
+    got = g.batch_argmax_count(*f, X, labels, out_len)
+    h = handler_histogram(g, pop)
+    assert h["end_cls"] >= 0.9 * pop, h
+    want = torch_rule_counts(oracle.batch_evaluate(*f, X, out_len), labels)
+    assert np.array_equal(got, want), (classes, np.abs(got - want).max(), (got != want).mean(), np.flatnonzero(got != want)[:5])
+
+
+def test_divisions_by_a_variable_read_the_reciprocal_columns(g, oracle, rng):
+    """SHORT division mode: a launch whose dataset lies in [2^-46, 2^46] stages the variables' reciprocals behind the labels and its
+    divisions by a variable (S / v, v / w, c / v, inv(v)) read them (divr_* words, gen_tc_asm.py); with a zero anywhere in the dataset
+    the same words run the division's own handlers.  Both must meet the oracle as the IEEE mode does, and the two modes may differ
+    by rounding only."""
+    pop, L, var_len = 20000, 64, 6
+    for funcs, what in ((ARITH, "arith"), (ARITH + [NEG, INV], "unary")):
+        f = oracle.generate(pop, L, var_len, 1, 0.5, 0.5, [3, 9], depth2leaf(6), roulette_uniform(funcs), CS)
+        y = rng.uniform(-2, 2, (300, 1)).astype(np.float32)
+        for zero in (False, True):
+            X = (rng.uniform(0.3, 3, (300, var_len)) * rng.choice([-1.0, 1.0], (300, var_len))).astype(np.float32)
+            if zero:
+                X[17, 2] = 0.0
+            want = oracle.sr_fitness(*f, X, y)
+            got = g.sr_fitness(*f, X, y)
+            h = handler_histogram(g, pop)
+            assert h["divr_SV"] > 0 and h["divr_VV"] > 0 and h["divr_CV"] > 0, h
+            assert g.L.evogp_hip_set_sr_division(0) == 0
+            try:
+                ieee = g.sr_fitness(*f, X, y)
+                assert sum(handler_histogram(g, pop)[k] for k in ("divr_SV", "divr_VV", "divr_CV")) == 0
+            finally:
+                assert g.L.evogp_hip_set_sr_division(2) == 0
+            assert_close_classes(ieee, want, RTOL, what=f"{what} zero={zero}: IEEE division")
+            assert_close_classes(got, want, RTOL, what=f"{what} zero={zero}: reciprocal columns")
+            assert_close_classes(got, ieee, 1e-6, what=f"{what} zero={zero}: SHORT against IEEE")
+
+
 def test_chunked_pipeline_on_a_large_population(g, oracle):
     """a population beyond the sizes of the other tests (and, with EVOGP_TC_CHUNKS set, the chunked two-stream pipeline of
     sr_tc.hip): the result must equal that of the halves run on their own, and the oracle's on a sample"""
