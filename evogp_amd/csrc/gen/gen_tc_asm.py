@@ -81,7 +81,12 @@ SLOT = 256  # bytes per handler slot
 DIVIP_REGS = 12  # VGPRs an in-place division uses above its operands (the compiler reserves ceil(DIVIP_REGS / K) stack entries)
 DIVIP = ("SS", "SC", "CS")  # division forms with an in-place handler (operands read where they are, temporaries above the stack)
 DIVR = ("SV", "VV", "CV")   # divisions by a variable through the launch's reciprocal columns (divr_*: the product with 1 / v)
-NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1 + 1 + len(DIVR)  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls + swap + divisions by reciprocal columns
+# Handlers with a twin that does NOT prefetch (name + "_np"): the compiler names the twin where the NEXT word has no variable operand (about
+# half of the headline's words) -- four instructions less of the fifteen of an addition: the shift of the next word's offset, the
+# address, two LDS reads
+NOPF_TWINS = tuple(f"{op}_{form}" for op in ("add", "sub", "mul") for form in FORMS) + ("push_c", "push_v") \
+    + tuple(f"divip_{f}" for f in DIVIP) + tuple(f"divr_{f}" for f in DIVR)
+NHF = 37 + 2 * len(UNARY) + 8 + 2 + 4 + len(DIVIP) + 1 + 1 + len(DIVR) + len(NOPF_TWINS)  # handlers per flavour: ... + generic binary forms + generic unary S/V + if, acc, mo_begin, end_mo + in-place divisions + end_cls + swap + divisions by reciprocal columns
 
 
 NOPF = False  # EVOGP_TC_GEN_NOPF=1: drop the operand prefetch (timing experiment, wrong results)
@@ -219,7 +224,10 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     hid["swap"] = nh + 14 + len(DIVIP) + 1
     for i, form in enumerate(DIVR):
         hid[f"divr_{form}"] = nh + 14 + len(DIVIP) + 2 + i
-    assert NHF == nh + 14 + len(DIVIP) + 2 + len(DIVR)
+    for i, name in enumerate(NOPF_TWINS):
+        hid[name + "_np"] = nh + 14 + len(DIVIP) + 2 + len(DIVR) + i
+    assert NHF == nh + 14 + len(DIVIP) + 2 + len(DIVR) + len(NOPF_TWINS) and 2 * NHF * SLOT <= 65536
+    twin = [False]   # True while a no-prefetch twin is being generated (begin, entry, prefetch, wait_cur look at it)
 
     # cycle accounting (stats build only); counters live in the top operand-stack slot
     A_REC, A_WORK, A_TREES, A_DISP, A_START, A_TICK = NV - 1, NV - 2, NV - 3, NV - 4, NV - 5, NV - 6
@@ -253,7 +261,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         """common head of a handler: address of the next handler and LDS offset of the next instruction's variable"""
         a(f"s_movrels_b32 s{sX}, s{W + 2}")                  # next word: {LDS offset / 1024 of its variable, aux, handler offset}
         a(f"s_pack_lh_b32_b16 s{sPC}, s{sX}, {BASE}")        # handler table is 64 KiB aligned: address = {base.hi16, offset}
-        a(f"s_lshr_b32 {PF}, s{sX}, 24")                    # (in 1-KiB units: the shift rides in prefetch's v_lshl_add)
+        if not twin[0]:
+            a(f"s_lshr_b32 {PF}, s{sX}, 24")                # (in 1-KiB units: the shift rides in prefetch's v_lshl_add)
 
     def read_aux(dst):
         """aux field (bits 23:16) of the CURRENT instruction's word; M0 must still be J (i.e. before any m0_stack)"""
@@ -261,7 +270,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a(f"s_bfe_u32 s{dst}, s{dst}, 0x80010")
 
     def prefetch(nxt):
-        if NOPF:  # timing experiment only: wrong results
+        if NOPF or twin[0]:  # (NOPF: timing experiment only, wrong results)
             return
         a(f"v_lshl_add_u32 v4, {PF}, 10, v2")
         read_bank(nxt, 4)
@@ -499,6 +508,8 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     a(f"{lab('hbase')}:")
 
     def begin(name, fl):
+        if twin[0]:
+            name += "_np"
         a(f".org {lab('hbase')}+{SLOT * (fl * NHF + hid[name])}")  # fails to assemble if the previous handler overflowed its slot
         a(f"{lab(f'h{fl}_' + name)}:")
 
@@ -510,7 +521,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a(f"s_add_u32 m0, s{sH}, {hex(imm & 0xFFFFFFFF)}")
 
     def wait_cur():
-        a(f"s_waitcnt lgkmcnt({G})")  # everything but the prefetch just issued has landed (LDS returns in order)
+        a(f"s_waitcnt lgkmcnt({0 if twin[0] else G})")  # everything but the prefetch just issued has landed (LDS returns in order)
 
     def splat(sreg):
         """the operand a constant takes in a K-row loop: its SGPR (default), or -- an experiment, the kernel-level ubench had an
@@ -904,29 +915,34 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         for form in FORMS:
             div_stub(form, fl)
         # push constant (folded constant subtree, or a tree that is a single constant)
-        begin("push_c", fl)
-        entry()
-        a(f"s_movrels_b32 s{sA}, s{W + 1}")
-        prefetch(nxt)
-        m0_stack(MODE["DST"], 0)
-        if PKCONST and K >= 2:
-            for k in range(0, K, 2):
-                a(f"v_pk_mov_b32 v[{S0 + k}:{S0 + k + 1}], s[{sA}:{sA + 1}], s[{sA}:{sA + 1}] op_sel:[0,0]")
-        else:
-            c = splat(sA)
-            for k in range(K):
-                a(f"v_mov_b32 v{S0 + k}, {c}")
-        a(f"s_add_u32 s{sH}, s{sH}, {K}")
-        epilogue()
+        def push_c(fl=fl, cur=cur, nxt=nxt):
+            begin("push_c", fl)
+            entry()
+            a(f"s_movrels_b32 s{sA}, s{W + 1}")
+            prefetch(nxt)
+            m0_stack(MODE["DST"], 0)
+            if PKCONST and K >= 2:
+                for k in range(0, K, 2):
+                    a(f"v_pk_mov_b32 v[{S0 + k}:{S0 + k + 1}], s[{sA}:{sA + 1}], s[{sA}:{sA + 1}] op_sel:[0,0]")
+            else:
+                c = splat(sA)
+                for k in range(K):
+                    a(f"v_mov_b32 v{S0 + k}, {c}")
+            a(f"s_add_u32 s{sH}, s{sH}, {K}")
+            epilogue()
+
         # push variable (a tree that is a single variable)
-        begin("push_v", fl)
-        entry()
-        prefetch(nxt)
-        m0_stack(MODE["DST"], 0)
-        wait_cur()
-        rows_mov(S0, cur)
-        a(f"s_add_u32 s{sH}, s{sH}, {K}")
-        epilogue()
+        def push_v(fl=fl, cur=cur, nxt=nxt):
+            begin("push_v", fl)
+            entry()
+            prefetch(nxt)
+            m0_stack(MODE["DST"], 0)
+            wait_cur()
+            rows_mov(S0, cur)
+            a(f"s_add_u32 s{sH}, s{sH}, {K}")
+            epilogue()
+        push_c()
+        push_v()
         begin("end", fl)
         a(f"s_branch {lab(f'endbody{fl}')}")
         # a tree the compiler could not take: leave its (marked) fitness word alone
@@ -1107,15 +1123,17 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         read_aux(T2)
         a(f"s_branch {lab('endmo_body')}")
         # ---- in-place divisions: the compiler picks these where one more stack entry is free above the operands
-        for form in DIVIP:
-            begin(f"divip_{form}", fl)
-            entry()
-            if form == "CS":
-                a(f"s_movrels_b32 s{sA}, s{W + 1}")
-            if form == "SC":
-                a(f"s_movrels_b32 s{sBop}, s{W + 1}")
-            prefetch(nxt)
-            a(f"s_branch {lab(f'divip_body_{form}{fl}')}")
+        def divip_stubs(fl=fl, nxt=nxt):
+            for form in DIVIP:
+                begin(f"divip_{form}", fl)
+                entry()
+                if form == "CS":
+                    a(f"s_movrels_b32 s{sA}, s{W + 1}")
+                if form == "SC":
+                    a(f"s_movrels_b32 s{sBop}, s{W + 1}")
+                prefetch(nxt)
+                a(f"s_branch {lab(f'divip_body_{form}{fl}')}")
+        divip_stubs()
         # ---- end of a CLASSIFIER program (no counterpart in forward.cu: the reference's Classification problem computes
         # batch_forward + soft-max + arg-max + compare in torch, classification.py:62-75): the class labels of the tile's rows
         # were prefetched into this flavour's bank like the regression labels of END; they move to the T bank for the shared body
@@ -1144,34 +1162,50 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         # field; everything else in the word is the division's.  The handler is the trusted-variable division (range test of a
         # stack numerator, quotient estimate, one correction) without its v_rcp_f32 -- the eight of them were half of such a handler's
         # vector clocks.  Without bit 11 (or in a build without the range-tested rows) the word runs through the division's own handler.
-        for form in DIVR:
-            begin(f"divr_{form}", fl)
-            if not (use_range and TRUST):
-                a(f"s_branch {lab(f'h{fl}_div_{form}')}")
-                continue
-            a("s_bitcmp1_b32 s17, 11")
-            a(f"s_cbranch_scc0 {lab(f'h{fl}_div_{form}')}")
-            read_aux(T2)
-            entry()
-            a(f"v_lshl_add_u32 v5, s{T2}, 10, v2")
-            read_bank(Q, 5)                                   # the reciprocals of the divisor's rows
-            if form == "VV":
-                a(f"s_movrels_b32 s{sBop}, s{W + 1}")
-                a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
-                read_bank(T, 5)                               # the divisor's rows
-            if form == "CV":
-                a(f"s_movrels_b32 s{sA}, s{W + 1}")
-            prefetch(nxt)
-            wait_cur()
-            if form == "SV":
-                m0_stack(MODE["SRC0"] | MODE["SRC1"], -K)
-                rows_mov(T, S0)
-                a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
-                a("s_mov_b32 m0, 0")
-            else:
-                a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
-                a(f"s_add_u32 s{sH}, s{sH}, {K}")
-            a(f"s_branch {lab(f'divr_body_{form}{fl}')}")
+        def divr_stubs(fl=fl, nxt=nxt):
+            for form in DIVR:
+                begin(f"divr_{form}", fl)
+                if not (use_range and TRUST):
+                    a(f"s_branch {lab(f'h{fl}_div_{form}')}")
+                    continue
+                a("s_bitcmp1_b32 s17, 11")
+                a(f"s_cbranch_scc0 {lab(f'h{fl}_div_{form}')}")
+                read_aux(T2)
+                entry()
+                a(f"v_lshl_add_u32 v5, s{T2}, 10, v2")
+                read_bank(Q, 5)                                   # the reciprocals of the divisor's rows
+                if form == "VV":
+                    a(f"s_movrels_b32 s{sBop}, s{W + 1}")
+                    a(f"v_lshl_add_u32 v5, s{sBop}, 4, v2")
+                    read_bank(T, 5)                               # the divisor's rows
+                if form == "CV":   # a constant numerator outside [2^-46, 2^46] (0 / v among them): the division's own handler
+                    a(f"s_movrels_b32 s{sA}, s{W + 1}")
+                    a(f"s_and_b32 s{T2}, s{sA}, 0x7fffffff")
+                    a(f"s_sub_u32 s{T2}, s{T2}, {hex(DIV_LO)}")
+                    a(f"s_cmp_gt_u32 s{T2}, {hex(DIV_HI - DIV_LO)}")
+                    a(f"s_cbranch_scc1 {lab(f'h{fl}_div_{form}')}")
+                prefetch(nxt)
+                wait_cur()
+                if form == "SV":
+                    m0_stack(MODE["SRC0"] | MODE["SRC1"], -K)
+                    rows_mov(T, S0)
+                    a(f"s_add_u32 s{sDST}, s{sH}, {hex((MODE['DST'] << 12) - K)}")
+                    a("s_mov_b32 m0, 0")
+                else:
+                    a(f"s_add_u32 s{sDST}, s{sH}, {hex(MODE['DST'] << 12)}")
+                    a(f"s_add_u32 s{sH}, s{sH}, {K}")
+                a(f"s_branch {lab(f'divr_body_{form}{fl}')}")
+        divr_stubs()
+        # ---- the twins that do not prefetch (NOPF_TWINS)
+        twin[0] = True
+        for op in ("add", "sub", "mul"):
+            for form in FORMS:
+                arith(op, form, fl)
+        push_c()
+        push_v()
+        divip_stubs()
+        divr_stubs()
+        twin[0] = False
     a(f".org {lab('hbase')}+{SLOT * 2 * NHF}")
 
     # In-place division bodies.  The gather forms above copy the operands into fixed banks because the division's temporaries

@@ -49,7 +49,11 @@ def handler_histogram(g, pop):
     assert rc == 0, g.L.evogp_hip_error_string(rc)
     h = hist.cpu().numpy()
     table = json.load(open(os.path.join(ROOT, "evogp_amd", "lib", "tc_handlers.json")))["K8_short"]["handlers"]
-    return {name: int(h[v["id"]] + h[nh + v["id"]]) for name, v in table.items()}
+    out = {}
+    for name, v in table.items():   # (a handler and its twin that does not prefetch, name + "_np", count as one)
+        base = name[:-3] if name.endswith("_np") else name
+        out[base] = out.get(base, 0) + int(h[v["id"]] + h[nh + v["id"]])
+    return out
 
 
 def check(g, oracle, forest, X, y, what, max_skipped=0.02, mse=(True, False)):
