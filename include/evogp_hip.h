@@ -363,6 +363,11 @@ const char *evogp_hip_error_string(int code);
  *                   were bit-identical to the IEEE mode (scripts/div_modes.py).  A block of 64 lanes x K rows whose operands
  *                   all lie in [2^-46, 2^46] -- where the range scaling does nothing -- runs the same four operations
  *                   without it (same quotients, bit for bit; docs/DESIGN_history_r01_r03.md section 3.1d).
+ *                   Round 5: under SHORT and FAST a launch whose whole dataset lies in [2^-46, 2^46] (NaN allowed) keeps the correctly
+ *                   rounded reciprocals of the variables' columns in LDS, and a division BY A VARIABLE reads its reciprocal instead of
+ *                   computing it with v_rcp_f32 (1 ulp); the residual correction against the divisor stays, so the quotient is
+ *                   faithfully rounded as before but need not be the same float in the rare pairs where SHORT and IEEE differ
+ *                   (EVOGP_TC_RECIP=0 switches it off).
  *   EVOGP_DIV_IEEE  every quotient is the correctly rounded IEEE-754 quotient, as the CPU oracle computes it (+45 % time).
  *   EVOGP_DIV_FAST  as SHORT, but a block with an operand outside [2^-46, 2^46] takes rows without range scaling:
  *                   |b| > 2^126 gives 0 and |a/b| >= 2^128 gives NaN instead of inf (-2 % time against SHORT).

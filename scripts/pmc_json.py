@@ -35,7 +35,7 @@ def main():
         raw = raw.strip()
         if raw.startswith("{") and '"metric"' in raw:
             line = json.loads(raw)
-    interp = next((k for k in t if "sr_tc_kernel<8, false, 2>" in k), None)
+    interp = next((k for k in t if "sr_tc_kernel<8, false, 2" in k), None)   # (<K, STATS, FAST[, WIDE]>: the short-division 8-row build)
     # the program compiler of the headline: the packed kernel (round 4), else the one-tree kernel -- never the general compiler's launch
     comp = next((k for k in t if "tc_compile_packed_kernel" in k), None) or next((k for k in t if "tc_compile_kernel" in k), None)
     out = {
