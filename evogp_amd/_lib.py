@@ -52,6 +52,7 @@ PROTOTYPES = {
     "evogp_hip_debug_set_stats": [_vp],
     "evogp_hip_debug_compile_batch": [_i],
     "evogp_hip_debug_long_compiler": [_i],
+    "evogp_hip_debug_twins": [_i],
     "evogp_hip_debug_profile": [_i],
     "evogp_hip_debug_profile_read": [C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "evogp_hip_debug_tc_histogram": [_u, _vp, _i, _vp],

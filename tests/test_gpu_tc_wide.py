@@ -39,7 +39,7 @@ def g():
     return gpu_capi
 
 
-def handler_histogram(g, pop):
+def handler_histogram(g, pop, fold_twins=True):
     """{handler name: words} of the programs the last sr_fitness call compiled (both flavours added)"""
     import torch
 
@@ -51,7 +51,7 @@ def handler_histogram(g, pop):
     table = json.load(open(os.path.join(ROOT, "evogp_amd", "lib", "tc_handlers.json")))["K8_short"]["handlers"]
     out = {}
     for name, v in table.items():   # (a handler and its twin that does not prefetch, name + "_np", count as one)
-        base = name[:-3] if name.endswith("_np") else name
+        base = name[:-3] if fold_twins and name.endswith("_np") else name
         out[base] = out.get(base, 0) + int(h[v["id"]] + h[nh + v["id"]])
     return out
 
@@ -134,12 +134,23 @@ def test_every_program_compiler_gives_the_same_fitness_words(g, oracle, rng, mas
         for batch in (0, 8, 16, 32, 64, -1):
             assert _lib.lib.evogp_hip_debug_compile_batch(batch) == 0
             words[batch] = forest.SR_fitness(Xd, yd).cpu().numpy().view(np.uint32).copy()
+        # the handlers' twins that do not prefetch (a launch of this size does without them by default): always / never, packed and one tree per pass
+        for twins in (1, 0):
+            assert _lib.lib.evogp_hip_debug_twins(twins) == 0
+            for batch in (0, 16, -1):
+                assert _lib.lib.evogp_hip_debug_compile_batch(batch) == 0
+                words[f"twins {twins}, batch {batch}"] = forest.SR_fitness(Xd, yd).cpu().numpy().view(np.uint32).copy()
+            if twins:
+                h = handler_histogram(g, pop, fold_twins=False)
+                assert sum(n for name, n in h.items() if name.endswith("_np")) > pop // 4, "no word names a twin"
+        assert _lib.lib.evogp_hip_debug_twins(-1) == 0 and _lib.lib.evogp_hip_debug_compile_batch(-1) == 0
         if L > 64:   # trees of more than 64 nodes: the general compiler's staged passes against the straight-line staged compiler (round 5)
             assert _lib.lib.evogp_hip_debug_long_compiler(0) == 0
             words["long trees through compile_general"] = forest.SR_fitness(Xd, yd).cpu().numpy().view(np.uint32).copy()
     finally:
         _lib.lib.evogp_hip_debug_compile_batch(-1)
         _lib.lib.evogp_hip_debug_long_compiler(-1)
+        _lib.lib.evogp_hip_debug_twins(-1)
     for batch, w in words.items():
         diff = np.nonzero(w != words[0])[0]
         assert len(diff) == 0, f"batch {batch}: {len(diff)} fitness words differ from the one-tree compiler's, first tree {diff[:5]}"
