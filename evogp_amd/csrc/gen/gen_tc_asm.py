@@ -107,6 +107,7 @@ TOUCH = True     # fused build: the block's entry touches the rows of the wave's
 TRIGPK = True    # sin / cos / tan over row pairs with packed multiplications and fused multiply-adds (EVOGP_TC_GEN_TRIGPK=0: row by row)
 LIBPK = True     # pow / sinh / cosh: the library's sequences over row PAIRS (gen/pair_rows.py; EVOGP_TC_GEN_LIBPK=0: row by row)
 RECGLC = False   # fused build: the record loads carry glc (EVOGP_TC_GEN_RECGLC=1) instead of one s_dcache_inv per batch
+CODEWARM = False  # EVOGP_TC_GEN_CODEWARM=1: every wave pulls the handler table and the bodies behind it into its XCD's L2 before it starts (experiment: 4-5 us SLOWER at 250 k - 1 M trees, no change at 125 k: profiles/r05Z_codewarm_ab.log)
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
 
 
@@ -392,6 +393,19 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a(f"s_addc_u32 s{T2}, s{T2}, 0")
         a(f"s_mov_b32 {BASE}, s{T1}")                 # 64 KiB aligned: its low half is zero
         a(f"s_mov_b32 s{sPC + 1}, s{T2}")
+        if CODEWARM:
+            # The handler table and the bodies behind it (~100 KiB) have left the L2 of this XCD since the last launch (a call moves
+            # 900 MB): every wave asks for all of it, one line per lane, before its first instruction fetch misses there -- the
+            # instruction cache then finds its lines in L2.  Experiment, off: see CODEWARM
+            a("v_lshlrev_b32 v4, 6, v0")
+            a(f"s_mov_b32 s{P3_}, ({lab('code_end')}-{lab('hbase')}+4095)/4096")
+            a(f"{lab('codewarm')}:")
+            a(f"global_load_dword v14, v4, s[{T1}:{T2}]")
+            a(f"s_add_u32 s{T1}, s{T1}, 4096")
+            a(f"s_addc_u32 s{T2}, s{T2}, 0")
+            a(f"s_sub_u32 s{P3_}, s{P3_}, 1")
+            a(f"s_cmp_lg_u32 s{P3_}, 0")
+            a(f"s_cbranch_scc1 {lab('codewarm')}")
         a(f"{lab('run')}:")
         if stats:
             for r in (A_REC, A_WORK, A_TREES, A_DISP):
@@ -2426,6 +2440,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     if not fused:
         a("s_endpgm")
     sect[0] = L
+    a(f"{lab('code_end')}:")
     at = L.index(".p2align 16")
     L[at:at] = tail
     if fused:
@@ -2474,6 +2489,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
 if __name__ == "__main__":
     import os
     KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "0") == "1"
+    CODEWARM = os.environ.get("EVOGP_TC_GEN_CODEWARM", "0") == "1"
     L2WARM = os.environ.get("EVOGP_TC_GEN_L2WARM", "1") != "0"
     EARLYREC = os.environ.get("EVOGP_TC_GEN_EARLYREC", "1") != "0"
     KWARM_LINES = int(os.environ.get("EVOGP_TC_GEN_KWARM_LINES", "4"))

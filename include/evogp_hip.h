@@ -340,7 +340,7 @@ int evogp_hip_debug_compile_batch(int trees);
  * compiler's staged passes, as every other long tree; -1 = back to the default / the environment (EVOGP_TC_LONG_FAST).  Same fitness words. */
 int evogp_hip_debug_long_compiler(int fast);
 /* Whether a program word whose successor has no variable operand names its handler's twin that does not prefetch:
- * -1 = by the launch's trees per CU (DEFAULT: from 700 on; the environment variable EVOGP_TC_TWINS = 0 / 2 sets never / always before the
+ * -1 = by the launch's trees per CU (DEFAULT: from 900 on; the environment variable EVOGP_TC_TWINS = 0 / 2 sets never / always before the
  * first call), 0 = never, 1 = always.  The fitness words do not depend on the choice (tests/test_gpu_tc_wide.py compares them bit for bit). */
 int evogp_hip_debug_twins(int mode);
 
