@@ -41,7 +41,9 @@ def g():
 # ---- generate: bit-exact ---------------------------------------------------------------------
 @pytest.mark.parametrize("funcs,out_len,var_len,L,mlc", [
     (ARITH, 1, 10, 64, 6), (ARITH, 1, 3, 32, 4), (PAPER7, 1, 5, 64, 6), (ALLF, 1, 4, 128, 5),
-    (ARITH, 3, 6, 64, 6), (ALLF, 4, 3, 128, 5), (ARITH, 1, 2, 1024, 9), ([0], 2, 3, 1024, 6)])
+    (ARITH, 3, 6, 64, 6), (ALLF, 4, 3, 128, 5), (ARITH, 1, 2, 1024, 9), ([0], 2, 3, 1024, 6),
+    # trees that outgrow their row by far (IF only, six levels: up to 1093 nodes in rows of 100 / 254 / 255: subtree sizes beyond a byte)
+    ([0], 1, 3, 100, 6), (ALLF, 2, 4, 254, 7), ([0], 1, 3, 255, 6)])
 def test_generate_bit_exact(g, oracle, funcs, out_len, var_len, L, mlc):
     rou, d2l = roulette_uniform(funcs), depth2leaf(mlc)
     cs = np.array([-1, 0, 1, 0.5, 2], np.float32)
