@@ -615,8 +615,13 @@ def test_divisions_by_a_variable_read_the_reciprocal_columns(g, oracle, rng):
             try:
                 ieee = g.sr_fitness(*f, X, y)
                 assert sum(handler_histogram(g, pop)[k] for k in ("divr_SV", "divr_VV", "divr_CV")) == 0
+                assert g.L.evogp_hip_set_sr_division(1) == 0
+                fast = g.sr_fitness(*f, X, y)   # (FAST differs from SHORT only in blocks with an operand outside [2^-46, 2^46]: rare here)
+                assert handler_histogram(g, pop)["divr_VV"] > 0
             finally:
                 assert g.L.evogp_hip_set_sr_division(2) == 0
+            same = (fast.view(np.uint32) == got.view(np.uint32)) | (np.isnan(fast) & np.isnan(got))
+            assert same.mean() > 0.995, f"{what} zero={zero}: FAST differs from SHORT in {(~same).sum()} of {pop} trees"
             assert_close_classes(ieee, want, RTOL, what=f"{what} zero={zero}: IEEE division")
             assert_close_classes(got, want, RTOL, what=f"{what} zero={zero}: reciprocal columns")
             assert_close_classes(got, ieee, 1e-6, what=f"{what} zero={zero}: SHORT against IEEE")
