@@ -36,6 +36,11 @@ DESIGN.md section 3.1 and docs/DESIGN_history_r01_r03.md have the numbers):
     operands all lie in [2^-46, 2^46] skips the range scaling (rcp, mul, two packed fmas per row pair, the quotient written in
     place), a numerator or denominator that is +-0 in the whole block is one instruction per row, and dataset variables whose
     whole column is in range (flags bits 17-30, set by sr_tc_kernel's prologue) need no test (DIVRANGE / TRUST below);
+  * round 5: a division BY A VARIABLE reads the variable's reciprocal from a second copy of the dataset's columns in LDS (divr_*: the
+    trusted-variable division without its v_rcp_f32; flags bit 11, aux = KiB index of the reciprocal column); the hot handlers have TWINS
+    that do not prefetch (NOPF_TWINS: the compiler names them where the next word has no variable operand); end_cls judges segments of
+    lanes against a scalar label (the launch stages the rows in label order); a wide-stack build of the 8-row variant (13 entries);
+    pow / sinh / cosh / exp / log run over row pairs (gen/pair_rows.py packs the transcribed bodies and proves the packed body equal);
   * constants enter + - * and PUSH_C through packed instructions (one SGPR source for two rows per issue slot, PKCONST);
   * the dataset lives in LDS, transposed so that a lane's rows of one variable are one ds_read_b128 per four rows.
     Variable operands are PREFETCHED one instruction ahead: every handler starts by issuing the LDS reads for the NEXT
