@@ -539,7 +539,8 @@ def test_small_dataset_library_functions_match_the_register_kernels(g, oracle, r
 
 
 # ---- classification epilogue on the threaded code ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("var_len,out_len,D", [(4, 2, 8), (4, 3, 64), (4, 3, 65), (4, 3, 200), (3, 5, 512), (4, 3, 700), (64, 10, 300), (64, 10, 1797), (30, 6, 2500)])
+@pytest.mark.parametrize("var_len,out_len,D", [(4, 2, 8), (4, 3, 64), (4, 3, 65), (4, 3, 200), (3, 5, 512), (4, 3, 700), (64, 10, 300), (64, 10, 1797), (30, 6, 2500),
+                                               (3, 2, 20000)])   # (the last: three pieces of 9216 rows, the label sort over twenty passes of its one workgroup)
 def test_classifier_count_on_the_threaded_code(g, oracle, rng, var_len, out_len, D):
     """evogp_hip_batch_argmax_count through compiled programs and the END_CLS handler (one column of int32 class labels staged
     behind X, per row the arg-max over the output accumulators as torch.argmax(clip(softmax(x))) sees it, hits counted per tree;
