@@ -225,6 +225,17 @@ class InsertMutation(BaseMutation):
     takes_skip_rows = True
 
     def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
+        d = self.descriptor
+        if _native(forest):
+            # two launches: fresh trees for the rows whose word lies under the rate (the donor kernel of the fused default step), then
+            # csrc/mutate_ops.hip insert_mutate_kernel under the same words -- no list of mutating trees, no host sync
+            seed, call = _next_call(self)
+            below = int(min(max(float(self.mutation_rate), 0.0), 1.0) * (2**31 - 1))
+            fresh = torch.ops.evogp_hip.tree_generate_masked_hashed(forest.pop_size, forest.max_tree_len, d.input_len, d.output_len, int(d.const_samples.shape[0]),
+                                                                    float(d.out_prob), float(d.const_prob), d.depth2leaf_probs, d.roulette_funcs,
+                                                                    d.const_samples, 0, seed, call, below)
+            v, t, s, _ = torch.ops.evogp_hip.insert_mutate(below, int(skip_rows), seed, call, *forest._tensors(), *fresh, False)
+            return Forest(forest.input_len, forest.output_len, v, t, s, func_mask=Forest.join_masks(forest.func_mask, d.func_mask))
         mask, p, keys, u = self.draw(forest)
         return self.apply(forest, _keep_rows(mask, skip_rows), p, keys, u)
 

@@ -12,6 +12,10 @@
 //     has at most max_size nodes (the root when there is none: the arg-max of an all-zero row), its replacement child number
 //     trunc(1 + u (arity - 1)) -- the reference's randint with the arity as exclusive bound (delete.py:96-101);
 //   * Hoist: node p = trunc(u S), inner node trunc(u' size[p]), taken as an ABSOLUTE index like the reference (hoist.py:58-68) or as an offset;
+//   * Insert (insert_mutate_kernel): node p = trunc(u S); a fresh tree F of the operator's descriptor -- generated for the mutating rows by
+//     evogp_hip_generate_masked_hashed under the SAME words (mask word 4, keys words 7) --; position r = trunc(1 + u' (|F| - 1)) of F takes
+//     the subtree at p, and the result takes that subtree's place (insert.py:45-85: tree_crossover, then tree_mutate, each of which leaves
+//     its recipient as it is when the row would overflow or a node is out of range);
 //   * point mutations: the nodes to redraw -- one per tree, every node of a tree (or node by node) under `intensity`, constants only -- get
 //     a payload of their own kind: a function of the same arity from the per-arity roulette (searchsorted left, or scaled to the class
 //     total and right with fix_roulette), a variable index, a constant sample; OUT nodes keep or redraw their output index.
@@ -95,6 +99,58 @@ __global__ __launch_bounds__(kRepBlock) void structural_mutate_kernel(StructPara
         }
         build_row(L, L, S, p, q, m, fallback, a.gp_len, a.rv + off, a.rt + off, a.rs + off);
         if (a.decisions && lane == 0) { a.decisions[2 * (size_t)n] = mutate ? p : -1; a.decisions[2 * (size_t)n + 1] = q; }
+    }
+}
+
+struct InsertParams {
+    const float *v; const int16_t *t; const int16_t *s;       // the forest
+    const float *dv; const int16_t *dt; const int16_t *ds;    // the fresh trees, row n for tree n (rows of trees that do not mutate are not read)
+    float *rv; int16_t *rt; int16_t *rs;
+    int *decisions;              // optional [pop][2]: node of the tree (-1: copied), position inside the fresh tree
+    int pop, gp_len, skip_rows;
+    unsigned below;              // tree n mutates when word (4, n) < below: the rule of the donor kernel
+    unsigned long long base;
+};
+
+// A wave per tree; the grafted fresh tree passes through LDS (8 bytes per node and wave).
+__global__ __launch_bounds__(kRepBlock) void insert_mutate_kernel(InsertParams a) {
+    extern __shared__ float ins_lds[];
+    const int lane = threadIdx.x & 63;
+    float *gv = ins_lds + (size_t)(threadIdx.x >> 6) * a.gp_len * 2;
+    int16_t *gt = reinterpret_cast<int16_t *>(gv + a.gp_len), *gs = gt + a.gp_len;
+    const int wave = uni((int)(blockIdx.x * (kRepBlock / 64) + (threadIdx.x >> 6)));
+    const int nwaves = gridDim.x * (kRepBlock / 64);
+    for (int n = wave; n < a.pop; n += nwaves) {
+        const size_t off = (size_t)n * a.gp_len;
+        const Row L{a.v + off, a.t + off, a.s + off};
+        int S = uni((int)L.s[0]);
+        S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
+        const bool mutate = n >= a.skip_rows && counter_word(a.base, 4u, (unsigned long long)n) < a.below && S >= 1;
+        int p = -1, r = 0;
+        bool fallback = true;
+        if (mutate) {
+            const Row F{a.dv + off, a.dt + off, a.ds + off};
+            int SF = uni((int)F.s[0]);
+            SF = SF < 0 ? 0 : (SF > a.gp_len ? a.gp_len : SF);
+            p = min((int)(word_uniform(counter_word(a.base, 1u, (unsigned long long)n)) * (float)S), S - 1);
+            r = (int)(1.0f + word_uniform(counter_word(a.base, 2u, (unsigned long long)n)) * (float)(SF - 1));   // randint(1, |F|)
+            const int m = uni((int)L.s[p]);          // the subtree that moves
+            // F with its subtree at r replaced by the tree's subtree at p (tree_crossover: recipient F); F as it is when that cannot be
+            const bool f1 = SF < 1 || r < 1 || r >= SF || m < 1 || p + m > a.gp_len || SF + (m - uni((int)F.s[r < SF ? r : 0])) > a.gp_len;
+            build_row(F, L, SF, r, p, m, f1, a.gp_len, gv, gt, gs);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const Row G{gv, gt, gs};
+            const int SG = uni((int)gs[0]);
+            // ... in the place of the subtree at p (tree_mutate); the tree as it is when the row would overflow
+            fallback = SG < 1 || S + (SG - m) > a.gp_len;
+            build_row(L, G, S, p, 0, SG, fallback, a.gp_len, a.rv + off, a.rt + off, a.rs + off, m);
+            __builtin_amdgcn_wave_barrier();         // (the next tree of this wave writes the same LDS rows)
+        } else {
+            build_row(L, L, S, 0, 0, 0, true, a.gp_len, a.rv + off, a.rt + off, a.rs + off);
+        }
+        if (a.decisions && lane == 0) { a.decisions[2 * (size_t)n] = mutate && !fallback ? p : -1; a.decisions[2 * (size_t)n + 1] = r; }
     }
 }
 
@@ -211,6 +267,21 @@ extern "C" int evogp_hip_structural_mutate(int pop_size, int gp_len, int mode, f
     const long cap = (long)device_info().num_cus * 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(structural_mutate_kernel, dim3((unsigned)blocks), dim3(kRepBlock), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int evogp_hip_insert_mutate(int pop_size, int gp_len, unsigned mutate_below, int skip_rows, long long seed, long long call,
+                                       const float *value, const int16_t *type, const int16_t *size, const float *donor_value,
+                                       const int16_t *donor_type, const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
+                                       int *decisions, evogp_stream_t stream) {
+    if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || skip_rows < 0) return EVOGP_E_BADARG;
+    if (!value || !type || !size || !donor_value || !donor_type || !donor_size || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
+    InsertParams a{value, type, size, donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions, pop_size, gp_len, skip_rows,
+                   mutate_below, counter_base(seed, call)};
+    long blocks = ((long)pop_size + 3) / 4;
+    const long cap = (long)device_info().num_cus * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(insert_mutate_kernel, dim3((unsigned)blocks), dim3(kRepBlock), (size_t)(kRepBlock / 64) * gp_len * 8, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -525,6 +525,28 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> structural_mutate(int64_t mode, doubl
     return {std::get<0>(out), std::get<1>(out), std::get<2>(out), dec};
 }
 
+// InsertMutation drawn and applied in one launch over fresh trees from tree_generate_masked_hashed(seed, call, mutate_below) (evogp_hip_insert_mutate)
+std::tuple<Tensor, Tensor, Tensor, Tensor> insert_mutate(int64_t mutate_below, int64_t skip_rows, int64_t seed, int64_t call, const Tensor &value,
+                                                         const Tensor &type, const Tensor &size, const Tensor &donor_value, const Tensor &donor_type,
+                                                         const Tensor &donor_size, bool want_decisions) {
+    TORCH_CHECK(value.dim() == 2, "value must be a (pop, gp_len) tensor");
+    const int64_t pop = value.size(0), gp_len = value.size(1);
+    check_sizes(pop, gp_len);
+    TORCH_CHECK(mutate_below >= 0 && mutate_below < (1LL << 32), "mutate_below must fit in 32 bits");
+    const c10::Device dev = value.device();
+    check_forest(pop, gp_len, value, type, size, dev);
+    check_forest(pop, gp_len, donor_value, donor_type, donor_size, dev);
+    c10::DeviceGuard guard(dev);
+    Tensor3 out = empty_forest(pop, gp_len, dev);
+    Tensor dec = want_decisions ? at::empty({pop, 2}, value.options().dtype(at::kInt)) : at::empty({0}, value.options().dtype(at::kInt));
+    check_rc(evogp_hip_insert_mutate((int)pop, (int)gp_len, (unsigned)mutate_below, (int)skip_rows, seed, call, value.data_ptr<float>(),
+                                     type.data_ptr<int16_t>(), size.data_ptr<int16_t>(), donor_value.data_ptr<float>(), donor_type.data_ptr<int16_t>(),
+                                     donor_size.data_ptr<int16_t>(), std::get<0>(out).data_ptr<float>(), std::get<1>(out).data_ptr<int16_t>(),
+                                     std::get<2>(out).data_ptr<int16_t>(), want_decisions ? dec.data_ptr<int>() : nullptr, current_stream(dev)),
+             "insert_mutate");
+    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), dec};
+}
+
 // Multi / Single Point / Const mutation drawn and applied in one launch: the new value array (evogp_hip_point_mutate)
 Tensor point_mutate(int64_t mode, double rate, double intensity, bool per_node, bool modify_output, bool fix_roulette, int64_t skip_rows, int64_t input_len,
                     int64_t output_len, int64_t seed, int64_t call, const Tensor &value, const Tensor &type, const Tensor &size, const Tensor &roulette_ufuncs,
@@ -615,6 +637,8 @@ TORCH_LIBRARY(evogp_hip, m) {
           " -> (Tensor value, Tensor node_type, Tensor subtree_size)");
     m.def("structural_mutate(int mode, float rate, int max_size, bool inner_is_offset, int skip_rows, int seed, int call, Tensor value, Tensor node_type,"
           " Tensor subtree_size, bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)");
+    m.def("insert_mutate(int mutate_below, int skip_rows, int seed, int call, Tensor value, Tensor node_type, Tensor subtree_size, Tensor donor_value,"
+          " Tensor donor_type, Tensor donor_size, bool want_decisions) -> (Tensor value, Tensor node_type, Tensor subtree_size, Tensor decisions)");
     m.def("point_mutate(int mode, float rate, float intensity, bool per_node, bool modify_output, bool fix_roulette, int skip_rows, int input_len, int output_len,"
           " int seed, int call, Tensor value, Tensor node_type, Tensor subtree_size, Tensor roulette_ufuncs, Tensor roulette_bfuncs, Tensor roulette_tfuncs,"
           " Tensor const_samples) -> Tensor");
@@ -640,6 +664,7 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("breed_rows_hashed", &breed_rows_hashed);
     m.impl("tree_generate_masked_hashed", &tree_generate_masked_hashed);
     m.impl("structural_mutate", &structural_mutate);
+    m.impl("insert_mutate", &insert_mutate);
     m.impl("point_mutate", &point_mutate);
     m.impl("tree_SR_fitness_masked", &tree_SR_fitness_masked);
     m.impl("select_survivors", &select_survivors);

@@ -203,6 +203,13 @@ int evogp_hip_breed_lists_hashed(int pop_size, int table_rows, int gp_len, int n
 int evogp_hip_structural_mutate(int pop_size, int gp_len, int mode, float rate, int max_size, int inner_is_offset, int skip_rows,
                                 long long seed, long long call, const float *value, const int16_t *type, const int16_t *size,
                                 float *value_res, int16_t *type_res, int16_t *size_res, int *decisions, evogp_stream_t stream);
+/* InsertMutation (mutation/insert.py:45-85): tree n mutates when counter word (4, n) of (seed, call) lies below mutate_below (of 2^31) -- the
+ * rule under which evogp_hip_generate_masked_hashed(seed, call, mutate_below) generated the fresh trees handed in as donor_* (row n for tree n).
+ * decisions (optional, [pop][2]): node of the tree that was replaced (-1: the tree was copied), position inside the fresh tree. */
+int evogp_hip_insert_mutate(int pop_size, int gp_len, unsigned mutate_below, int skip_rows, long long seed, long long call,
+                            const float *value, const int16_t *type, const int16_t *size, const float *donor_value,
+                            const int16_t *donor_type, const int16_t *donor_size, float *value_res, int16_t *type_res, int16_t *size_res,
+                            int *decisions, evogp_stream_t stream);
 int evogp_hip_point_mutate(int pop_size, int gp_len, int mode, float rate, float intensity, int per_node, int modify_output,
                            int fix_roulette, int skip_rows, int input_len, int output_len, int n_consts, long long seed, long long call,
                            const float *value, const int16_t *type, const int16_t *size, const float *roulette_ufuncs,

@@ -90,6 +90,58 @@ def test_structural_mutation_decisions_and_rows(g, oracle, mode, L, funcs, max_s
     assert np.array_equal(got[2][:skip][livek], s[:skip][livek]) and np.array_equal(got[0][:skip][livek].view(np.uint32), v[:skip][livek].view(np.uint32))
 
 
+@pytest.mark.parametrize("L,funcs,skip", [(64, ARITH + [NEG], 0), (128, ARITH + [SIN, IF], 41)], ids=["L64", "L128-if"])
+def test_insert_mutation_decisions_and_rows(g, oracle, L, funcs, skip):
+    """InsertMutation in two launches (insert.py:45-85): the fresh trees are those of the donor kernel under the operator's words -- checked
+    against the oracle's generate with the keys of words (7, 0 / 1) --, node p and position r are recomputed from words 1 and 2, and the
+    rows must be tree_mutate(tree, p, tree_crossover(fresh, tree, r, p)) with the bit-exact kernels of replace.hip."""
+    import torch
+
+    import evogp_amd  # noqa: F401
+
+    pop, rate, seed, call, V = 4001, 0.6, 987654321, 5, 4
+    d2l, rou = depth2leaf(6 if L > 64 else 5, 0.15), roulette_uniform(funcs)
+    v, t, s = (a.copy() for a in oracle.generate(pop, L, V, 1, 0.0, 0.5, [L, 9], d2l, rou, CS))
+    s[7, 0] = 0                                                   # a row without a tree: copied
+    keep = s[:, 0] <= L
+    dv, dt, ds = (torch.from_numpy(a).to(g.DEV) for a in (v, t, s))
+    d2l_f, rou_f = depth2leaf(3, 0.15), roulette_uniform(funcs)   # the operator's own descriptor: small fresh trees
+    below = int(rate * (2**31 - 1))
+    tabs = [torch.from_numpy(np.asarray(a, np.float32)).to(g.DEV) for a in (d2l_f, rou_f, CS)]
+    fresh = torch.ops.evogp_hip.tree_generate_masked_hashed(pop, L, V, 1, len(CS), 0.0, 0.5, *tabs, 0, seed, call, below)
+    rv, rt, rs, dec = torch.ops.evogp_hip.insert_mutate(below, skip, seed, call, dv, dt, ds, *fresh, True)
+    dec = dec.cpu().numpy()
+    w = words(seed, call, 8, 0, pop)
+    mask = w[4] < below
+    assert 0.55 < mask.mean() < 0.65
+    keys = [int(w[7][0]) % 1000000, int(w[7][1]) % 1000000]
+    fv, ft, fs = oracle.generate(pop, L, V, 1, 0.0, 0.5, keys, d2l_f, rou_f, CS)
+    got_fresh = [a.cpu().numpy() for a in fresh]
+    for a, b in zip(got_fresh, (fv, ft, fs)):
+        assert np.array_equal(a[mask].view(np.uint8), b[mask].view(np.uint8)), "the fresh trees are not the oracle's"
+    S = np.clip(s[:, 0].astype(np.int64), 0, L)
+    SF = np.clip(fs[:, 0].astype(np.int64), 0, L)
+    u1, u2 = uniform(w[1]), uniform(w[2])
+    mut = mask & (np.arange(pop) >= skip) & (S >= 1)
+    p = np.minimum((u1 * S.astype(np.float32)).astype(np.int64), S - 1)
+    r = (np.float32(1.0) + u2 * (SF - 1).astype(np.float32)).astype(np.int64)
+    # tree_crossover: recipients = the fresh trees, donors = the trees; then tree_mutate of the trees with the grafted rows
+    ar = np.arange(pop, dtype=np.int32)
+    both = tuple(np.concatenate([a, b]) for a, b in zip((fv, ft, fs), (v, t, s)))
+    gr = g.crossover(*both, ar, ar + pop, np.where(mut, r, -1).astype(np.int32), np.where(mut, p, 0).astype(np.int32))
+    want = g.mutate(v, t, s, np.where(mut, p, -1).astype(np.int32), *gr)
+    got = (rv.cpu().numpy(), rt.cpu().numpy(), rs.cpu().numpy())
+    sel = keep & (fs[:, 0] <= L)
+    live = np.arange(L)[None, :] < np.clip(want[2][:, :1].astype(np.int64), 0, L)
+    for a, b in zip(got, want):
+        a, b = a[sel], b[sel]
+        lv = live[sel]
+        assert np.array_equal(a[lv].view(np.uint8), b[lv].view(np.uint8)), "rows differ from tree_mutate(tree, p, tree_crossover(fresh, tree, r, p))"
+    changed = (got[2][:, 0] != s[:, 0]) & sel
+    assert changed[skip:].mean() > 0.3 and not changed[:skip].any()
+    assert np.array_equal(dec[mut & sel & changed, 0], p[mut & sel & changed]) and np.array_equal(dec[mut & sel, 1], r[mut & sel])
+
+
 def _roulettes(funcs):
     w = np.zeros(29, np.float64); w[list(funcs)] = 1.0 / len(funcs)
     p = w.astype(np.float32)
