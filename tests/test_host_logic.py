@@ -310,3 +310,65 @@ def test_pmc_json_takes_the_headline_compilers_counters_not_the_general_compiler
     assert "tc_compile_packed_kernel" in d["kernels"]["tc_compile_kernel"]["rocprof_name"]
     assert d["tc_compile_kernel_hbm_bytes_per_launch"] > 3e8 and d["sr_tc_kernel_hbm_bytes_per_launch"] > 2e8
     assert abs(d["call_hbm_bytes"] - d["tc_compile_kernel_hbm_bytes_per_launch"] - d["sr_tc_kernel_hbm_bytes_per_launch"]) < 1.0
+
+
+def test_next_kept_lane_by_a_carry():
+    """csrc/sr_tc.hip next_word_has_variable: the word that runs after a lane's is that of the nearest kept lane BELOW it; with K the kept
+    lanes and U those of them whose word has a variable operand, R = (~K + (U << 1)) & K marks the kept lanes whose predecessor (the next
+    kept lane below) is in U -- a carry that starts one above a lane of U runs through the lanes that are not kept and stops at the next
+    kept one.  Restated here with Python integers against the definition, on random masks."""
+    rng = np.random.default_rng(5)
+    M = (1 << 64) - 1
+    for _ in range(2000):
+        K = int(rng.integers(0, 2**63)) | (int(rng.integers(0, 2)) << 63)
+        K &= int(rng.integers(0, 2**63)) | (int(rng.integers(0, 2)) << 63) if rng.random() < 0.5 else M   # sparse and dense masks
+        U = K & (int(rng.integers(0, 2**63)) | (int(rng.integers(0, 2)) << 63))
+        R = (((~K & M) + ((U << 1) & M)) & M) & K
+        want, below = 0, None   # below: the nearest kept lane under the current one
+        for lane in range(64):
+            if (K >> lane) & 1:
+                if below is not None and (U >> below) & 1:
+                    want |= 1 << lane
+                below = lane
+        assert R == want, (hex(K), hex(U), hex(R), hex(want))
+
+
+def test_classifier_hit_rule_on_running_maxima():
+    """gen_tc_asm.py endcls_body: with P_j = max(out_0 .. out_j) and M = P_(n-1), a row whose label is L is a hit
+    iff P_L == M and P_(L-1) < M - d, and ambiguous iff P_L >= M - d and P_(L-1) < M and it is no hit; rows with a NaN or an infinite maximum
+    are hits iff L == 0.  Against the definition it replaces -- arg = first index of the maximum (0 for such rows); ambiguous when an output
+    IN FRONT of arg lies within d of the maximum -- the rule must agree wherever it says "hit" or "miss", and may only say "ambiguous"
+    more often (those trees are recounted exactly)."""
+    rng = np.random.default_rng(11)
+    d = np.float32(1.25 * 2.0 ** -23)
+    for _ in range(4000):
+        n = int(rng.integers(2, 11))
+        x = rng.choice(np.array([-2.0, -1.0, 0.0, 0.5, 1.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0, np.inf, -np.inf, np.nan], np.float32), n,
+                       p=[0.12, 0.12, 0.12, 0.12, 0.2, 0.1, 0.1, 0.08, 0.015, 0.015, 0.01]).astype(np.float32)
+        L = int(rng.integers(0, n))
+        special = bool(np.isnan(x).any() or np.isinf(np.nanmax(x) if not np.isnan(x).all() else np.nan))
+        # the definition
+        if special:
+            arg, amb_def = 0, False
+        else:
+            M = x.max()
+            arg = int(np.argmax(x))                      # first index of the maximum
+            amb_def = bool((x[:arg] >= M - d).any())     # an output in front of it within d (it is below M there by the choice of arg)
+        # the rule on running maxima
+        with np.errstate(invalid="ignore"):
+            P = np.fmax.accumulate(x)                    # v_max_f32 drops NaN operands
+        if special:
+            hit, amb = L == 0, False
+        else:
+            M = P[-1]
+            thr = np.float32(M - d)
+            before = P[L - 1] if L > 0 else np.float32(-np.inf)
+            hit = bool(P[L] == M and before < thr)
+            amb = bool(P[L] >= thr and before < M and not hit)
+        if amb:
+            continue                                     # (recounted with torch's arithmetic)
+        assert not (amb_def and hit), (x, L)             # a hit is never claimed where the definition wavers about the label's class
+        if not amb_def:
+            assert hit == (arg == L), (x, L, arg, hit)
+        else:   # the definition wavers between arg and the earlier outputs within d of it: the label is none of them (else the rule said so)
+            assert not hit and L not in set(np.flatnonzero(x[:arg + 1] >= M - d).tolist()), (x, L, arg)
