@@ -628,6 +628,25 @@ def test_divisions_by_a_variable_read_the_reciprocal_columns(g, oracle, rng):
             assert_close_classes(got, ieee, 1e-6, what=f"{what} zero={zero}: SHORT against IEEE")
 
 
+@pytest.mark.parametrize("bad_column", [None, 3, 17])
+def test_reciprocal_columns_with_more_variables_than_trust_bits(g, oracle, rng, bad_column):
+    """Twenty variables (the interpreter keeps one "whole column in range" bit for the first fourteen only; the reciprocal copy needs EVERY
+    column in range): all in range -> the divisions by a variable read reciprocals; a zero in column 3 or in column 17 -> the same words run
+    the division's own handlers.  The oracle's fitness either way."""
+    pop, L, var_len, D = 8000, 64, 20, 512
+    f = oracle.generate(pop, L, var_len, 1, 0.5, 0.5, [var_len, 2], depth2leaf(6), roulette_uniform(ARITH), CS)
+    X = (rng.uniform(0.3, 3, (D, var_len)) * rng.choice([-1.0, 1.0], (D, var_len))).astype(np.float32)
+    y = rng.uniform(-2, 2, (D, 1)).astype(np.float32)
+    if bad_column is not None:
+        X[100, bad_column] = 0.0
+    got = g.sr_fitness(*f, X, y)
+    h = handler_histogram(g, pop)
+    assert h["divr_SV"] > 0 and h["divr_VV"] > 0 and h["divr_CV"] > 0, h
+    assert_close_classes(got, oracle.sr_fitness(*f, X, y), RTOL, what=f"20 variables, zero in column {bad_column}")
+    if bad_column is not None:   # x / 0 is NaN (forward.cu:183-187): the trees that divide by that variable in that row
+        assert np.isnan(got).sum() > 0
+
+
 def test_chunked_pipeline_on_a_large_population(g, oracle):
     """a population beyond the sizes of the other tests (and, with EVOGP_TC_CHUNKS set, the chunked two-stream pipeline of
     sr_tc.hip): the result must equal that of the halves run on their own, and the oracle's on a sample"""
