@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # EVOGP_HIP_LIB: alternative build of the same engine (A/B benchmarking of compiler flags only)
 LIB_PATH = os.environ.get("EVOGP_HIP_LIB") or os.path.join(_HERE, "lib", "libevogp_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = C.c_void_p
 _u = C.c_uint
@@ -48,6 +48,13 @@ PROTOTYPES = {
     "evogp_hip_set_program_buffer_limit": [C.c_ulonglong],
     "evogp_hip_release_workspaces": [],
     "evogp_hip_set_allocator": [_vp, _vp],
+    "evogp_hip_set_sr_division": [C.c_int],
+    "evogp_hip_get_sr_division": [],
+    "evogp_hip_abi_version": [],
+}
+
+# include/evogp_hip_debug.h: measurement and test hooks (bench.py, scripts/, tests/); nothing in this package calls them
+DEBUG_PROTOTYPES = {
     "evogp_hip_timer_begin": [_vp],
     "evogp_hip_timer_end": [_vp, C.POINTER(C.c_float)],
     "evogp_hip_debug_set_stats": [_vp],
@@ -59,9 +66,10 @@ PROTOTYPES = {
     "evogp_hip_debug_tc_histogram": [_u, _vp, _i, _vp],
     "evogp_hip_debug_tc_nhandlers": [],
     "evogp_hip_debug_tc_program": [_u, _vp, _i],
-    "evogp_hip_set_sr_division": [C.c_int],
-    "evogp_hip_get_sr_division": [],
-    "evogp_hip_abi_version": [],
+    "evogp_hip_debug_forget_function_classes": [],
+    "evogp_hip_debug_structural_mutate_given": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evogp_hip_debug_insert_mutate_given": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evogp_hip_debug_point_mutate_given": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
 
@@ -73,7 +81,7 @@ def _load() -> C.CDLL:
             "evogp_amd has no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
-    for name, argtypes in PROTOTYPES.items():
+    for name, argtypes in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.argtypes = argtypes
         fn.restype = _i

@@ -318,4 +318,4 @@ extern "C" int evogp_hip_set_sr_division(int mode) {
 
 extern "C" int evogp_hip_get_sr_division(void) { return evogp::sr_division_mode(); }
 
-extern "C" int evogp_hip_abi_version(void) { return 4; }
+extern "C" int evogp_hip_abi_version(void) { return 5; }

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "../../include/evogp_hip.h"
+#include "../../include/evogp_hip_debug.h"   // (definitions are checked against their declarations)
 
 #ifndef EVOGP_SR_DEFAULT_K
 #define EVOGP_SR_DEFAULT_K 4

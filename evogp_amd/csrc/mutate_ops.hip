@@ -38,6 +38,8 @@ struct StructParams {
     int skip_rows, max_size, inner_is_offset;
     float rate;
     unsigned long long base;
+    const int *given;            // test entry (evogp_hip_debug_structural_mutate_given): [pop][3] = {mutates, node, child number (delete) / inner
+                                 // position (hoist)} in the reference's meaning (delete.py:66-101, hoist.py:53-68) instead of the hashed draws
 };
 
 __global__ __launch_bounds__(kRepBlock) void structural_mutate_kernel(StructParams a) {
@@ -53,7 +55,20 @@ __global__ __launch_bounds__(kRepBlock) void structural_mutate_kernel(StructPara
         const unsigned w1 = counter_word(a.base, 1u, (unsigned long long)n), w2 = counter_word(a.base, 2u, (unsigned long long)n);
         bool mutate = n >= a.skip_rows && u0 < a.rate && S >= 1;
         int p = -1, q = 0;
-        if (a.mode == 0) {
+        if (a.given) {   // the reference's own draws (tests): everything behind the draws is the code below
+            const int *g = a.given + 3 * (size_t)n;
+            mutate = n >= a.skip_rows && uni(g[0]) != 0;
+            if (mutate) {
+                p = uni(g[1]);
+                const int second = uni(g[2]);
+                if (a.mode == 0) {
+                    const int last = a.gp_len - 1;
+                    const int pc = min(max(p, 0), last);
+                    const int c1 = min(pc + 1, last), c2 = min(c1 + uni((int)L.s[c1]), last), c3 = min(c2 + uni((int)L.s[c2]), last);
+                    q = second == 3 ? c3 : (second == 2 ? c2 : c1);
+                } else q = second + (a.inner_is_offset ? p : 0);
+            }
+        } else if (a.mode == 0) {
             mutate = mutate && S > 1;
             if (mutate) {
                 // the k-th function node whose subtree is small enough, k uniform; the root when there is none (delete.py:66-85)
@@ -110,6 +125,8 @@ struct InsertParams {
     int pop, gp_len, skip_rows;
     unsigned below;              // tree n mutates when word (4, n) < below: the rule of the donor kernel
     unsigned long long base;
+    const int *given;            // test entry (evogp_hip_debug_insert_mutate_given): [pop][3] = {mutates, node of the tree, position inside the fresh
+                                 // tree} (insert.py:57-79) instead of the hashed draws
 };
 
 // A wave per tree; the grafted fresh tree passes through LDS (8 bytes per node and wave).
@@ -125,15 +142,21 @@ __global__ __launch_bounds__(kRepBlock) void insert_mutate_kernel(InsertParams a
         const Row L{a.v + off, a.t + off, a.s + off};
         int S = uni((int)L.s[0]);
         S = S < 0 ? 0 : (S > a.gp_len ? a.gp_len : S);
-        const bool mutate = n >= a.skip_rows && counter_word(a.base, 4u, (unsigned long long)n) < a.below && S >= 1;
+        const bool mutate = n >= a.skip_rows && S >= 1 &&
+                            (a.given ? uni(a.given[3 * (size_t)n]) != 0 : counter_word(a.base, 4u, (unsigned long long)n) < a.below);
         int p = -1, r = 0;
         bool fallback = true;
         if (mutate) {
             const Row F{a.dv + off, a.dt + off, a.ds + off};
             int SF = uni((int)F.s[0]);
             SF = SF < 0 ? 0 : (SF > a.gp_len ? a.gp_len : SF);
-            p = min((int)(word_uniform(counter_word(a.base, 1u, (unsigned long long)n)) * (float)S), S - 1);
-            r = (int)(1.0f + word_uniform(counter_word(a.base, 2u, (unsigned long long)n)) * (float)(SF - 1));   // randint(1, |F|)
+            if (a.given) {
+                p = min(max(uni(a.given[3 * (size_t)n + 1]), 0), S - 1);
+                r = uni(a.given[3 * (size_t)n + 2]);
+            } else {
+                p = min((int)(word_uniform(counter_word(a.base, 1u, (unsigned long long)n)) * (float)S), S - 1);
+                r = (int)(1.0f + word_uniform(counter_word(a.base, 2u, (unsigned long long)n)) * (float)(SF - 1));   // randint(1, |F|)
+            }
             const int m = uni((int)L.s[p]);          // the subtree that moves
             // F with its subtree at r replaced by the tree's subtree at p (tree_crossover: recipient F); F as it is when that cannot be
             const bool f1 = SF < 1 || r < 1 || r >= SF || m < 1 || p + m > a.gp_len || SF + (m - uni((int)F.s[r < SF ? r : 0])) > a.gp_len;
@@ -164,6 +187,11 @@ struct PointParams {
     int input_len, output_len, n_consts;
     float rate, intensity;
     unsigned long long base;
+    // test entry (evogp_hip_debug_point_mutate_given), all [pop][gp_len]: the nodes to redraw and the reference's per-node draws
+    // (single_point.py:64-124: the uniform number its roulette search takes for the node's own arity, variable / constant / output indices)
+    const unsigned char *g_target;
+    const float *g_u;
+    const int *g_var, *g_const, *g_out;
 };
 
 // searchsorted over a cumulative roulette of kNumFuncs entries: left = entries below x, right = entries not above x
@@ -222,18 +250,21 @@ __global__ __launch_bounds__(kRepBlock) void point_mutate_kernel(PointParams a) 
             if (a.mode == 1 || a.mode == 3) target = target && i == pos;
             else target = target && (a.per_node ? word_uniform(counter_word(a.base, 12u, node)) < a.intensity : tree_on);
             if (a.mode >= 2) target = target && ty == T_CONST;
+            if (a.g_target) target = n >= a.skip_rows && a.g_target[off + i] != 0;
             if (target) {
                 const int kind = ty & T_MASK;
                 if (a.mode >= 2 || kind == T_CONST) {
-                    out = a.consts[min((int)(word_uniform(counter_word(a.base, 10u, node)) * (float)a.n_consts), a.n_consts - 1)];
+                    const int ci = a.g_target ? a.g_const[off + i] : (int)(word_uniform(counter_word(a.base, 10u, node)) * (float)a.n_consts);
+                    out = a.consts[min(max(ci, 0), a.n_consts - 1)];
                 } else if (kind == T_VAR) {
-                    out = (float)min((int)(word_uniform(counter_word(a.base, 9u, node)) * (float)a.input_len), a.input_len - 1);
+                    const int vi = a.g_target ? a.g_var[off + i] : (int)(word_uniform(counter_word(a.base, 9u, node)) * (float)a.input_len);
+                    out = (float)min(vi, a.input_len - 1);
                 } else {
                     const bool is_out = (ty & T_OUT) != 0;
                     const uint32_t bits = f2bits(old);
                     const int old_func = is_out ? (int)(bits & 0xFFFFu) : (int)old;
                     const float *rou = kind >= T_TFUNC ? a.rou_t : (kind == T_BFUNC ? a.rou_b : a.rou_u);   // (single_point.py:86-89: the class index is clamped)
-                    const float u = word_uniform(counter_word(a.base, 8u, node));
+                    const float u = a.g_target ? a.g_u[off + i] : word_uniform(counter_word(a.base, 8u, node));
                     int func;
                     if (!a.fix_roulette) func = roulette_left(rou, u);                                    // may be 29: no function (single_point.py:70-90)
                     else {
@@ -242,7 +273,8 @@ __global__ __launch_bounds__(kRepBlock) void point_mutate_kernel(PointParams a) 
                     }
                     if (is_out) {
                         int oi = (int)(bits >> 16);
-                        if (a.modify_output) oi = min((int)(word_uniform(counter_word(a.base, 11u, node)) * (float)a.output_len), a.output_len - 1);
+                        if (a.modify_output)
+                            oi = min(a.g_target ? a.g_out[off + i] : (int)(word_uniform(counter_word(a.base, 11u, node)) * (float)a.output_len), a.output_len - 1);
                         out = bits2f((uint32_t)(func + (oi << 16)));
                     } else out = (float)func;
                 }
@@ -262,11 +294,60 @@ extern "C" int evogp_hip_structural_mutate(int pop_size, int gp_len, int mode, f
     if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || mode < 0 || mode > 1 || skip_rows < 0) return EVOGP_E_BADARG;
     if (!value || !type || !size || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
     StructParams a{value, type, size, value_res, type_res, size_res, decisions, pop_size, gp_len, mode, skip_rows, max_size, inner_is_offset, rate,
-                   counter_base(seed, call)};
+                   counter_base(seed, call), nullptr};
     long blocks = ((long)pop_size + 3) / 4;
     const long cap = (long)device_info().num_cus * 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(structural_mutate_kernel, dim3((unsigned)blocks), dim3(kRepBlock), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+// Test entries (include/evogp_hip_debug.h): the same kernels with the draws HANDED IN -- the numbers the reference's Python operators drew,
+// recorded by tests/golden/make_mutation_golden.py -- so that everything behind the draws is compared with the reference's own results
+// (tests/test_gpu_native_mutation.py).  given: int32 [pop][3] on the device.
+extern "C" int evogp_hip_debug_structural_mutate_given(int pop_size, int gp_len, int mode, int inner_is_offset, int skip_rows, const int *given,
+                                                       const float *value, const int16_t *type, const int16_t *size, float *value_res,
+                                                       int16_t *type_res, int16_t *size_res, evogp_stream_t stream) {
+    if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || mode < 0 || mode > 1 || skip_rows < 0) return EVOGP_E_BADARG;
+    if (!given || !value || !type || !size || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
+    StructParams a{value, type, size, value_res, type_res, size_res, nullptr, pop_size, gp_len, mode, skip_rows, 0, inner_is_offset, 0.0f, 0ull, given};
+    long blocks = ((long)pop_size + 3) / 4;
+    const long cap = (long)device_info().num_cus * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(structural_mutate_kernel, dim3((unsigned)blocks), dim3(kRepBlock), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int evogp_hip_debug_insert_mutate_given(int pop_size, int gp_len, int skip_rows, const int *given, const float *value, const int16_t *type,
+                                                   const int16_t *size, const float *donor_value, const int16_t *donor_type, const int16_t *donor_size,
+                                                   float *value_res, int16_t *type_res, int16_t *size_res, evogp_stream_t stream) {
+    if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || skip_rows < 0) return EVOGP_E_BADARG;
+    if (!given || !value || !type || !size || !donor_value || !donor_type || !donor_size || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
+    InsertParams a{value, type, size, donor_value, donor_type, donor_size, value_res, type_res, size_res, nullptr, pop_size, gp_len, skip_rows, 0u, 0ull, given};
+    long blocks = ((long)pop_size + 3) / 4;
+    const long cap = (long)device_info().num_cus * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(insert_mutate_kernel, dim3((unsigned)blocks), dim3(kRepBlock), (size_t)(kRepBlock / 64) * gp_len * 8, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+// target: uint8 [pop][gp_len]; u: float [pop][gp_len] (the uniform number of the node's own arity class); var_idx / const_idx / out_idx: int32 [pop][gp_len]
+// (out_idx may be null without modify_output).  mode 0 / 1 redraw nodes of every kind, 2 / 3 constants only.
+extern "C" int evogp_hip_debug_point_mutate_given(int pop_size, int gp_len, int mode, int modify_output, int fix_roulette, int skip_rows, int input_len,
+                                                  int output_len, int n_consts, const unsigned char *target, const float *u, const int *var_idx,
+                                                  const int *const_idx, const int *out_idx, const float *value, const int16_t *type, const int16_t *size,
+                                                  const float *roulette_ufuncs, const float *roulette_bfuncs, const float *roulette_tfuncs,
+                                                  const float *const_samples, float *value_res, evogp_stream_t stream) {
+    if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || mode < 0 || mode > 3 || skip_rows < 0 || input_len <= 0 || output_len <= 0 || n_consts <= 0)
+        return EVOGP_E_BADARG;
+    if (!target || !const_idx || !value || !type || !size || !value_res || !const_samples) return EVOGP_E_NULLPTR;
+    if (mode < 2 && (!u || !var_idx || !roulette_ufuncs || !roulette_bfuncs || !roulette_tfuncs || (modify_output && !out_idx))) return EVOGP_E_NULLPTR;
+    PointParams a{value, type, size, value_res, roulette_ufuncs, roulette_bfuncs, roulette_tfuncs, const_samples, pop_size, gp_len, mode, skip_rows,
+                  0, modify_output, fix_roulette, input_len, output_len, n_consts, 0.0f, 0.0f, 0ull, target, u, var_idx, const_idx, out_idx};
+    long blocks = ((long)pop_size + 3) / 4;
+    const long cap = (long)device_info().num_cus * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(point_mutate_kernel, dim3((unsigned)blocks), dim3(kRepBlock), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
@@ -277,7 +358,7 @@ extern "C" int evogp_hip_insert_mutate(int pop_size, int gp_len, unsigned mutate
     if (pop_size <= 0 || gp_len <= 0 || gp_len > kMaxStack || skip_rows < 0) return EVOGP_E_BADARG;
     if (!value || !type || !size || !donor_value || !donor_type || !donor_size || !value_res || !type_res || !size_res) return EVOGP_E_NULLPTR;
     InsertParams a{value, type, size, donor_value, donor_type, donor_size, value_res, type_res, size_res, decisions, pop_size, gp_len, skip_rows,
-                   mutate_below, counter_base(seed, call)};
+                   mutate_below, counter_base(seed, call), nullptr};
     long blocks = ((long)pop_size + 3) / 4;
     const long cap = (long)device_info().num_cus * 32;
     if (blocks > cap) blocks = cap;
@@ -295,7 +376,8 @@ extern "C" int evogp_hip_point_mutate(int pop_size, int gp_len, int mode, float 
     if (!value || !type || !size || !value_res || !const_samples) return EVOGP_E_NULLPTR;
     if (mode < 2 && (!roulette_ufuncs || !roulette_bfuncs || !roulette_tfuncs)) return EVOGP_E_NULLPTR;
     PointParams a{value, type, size, value_res, roulette_ufuncs, roulette_bfuncs, roulette_tfuncs, const_samples, pop_size, gp_len, mode, skip_rows,
-                  per_node, modify_output, fix_roulette, input_len, output_len, n_consts, rate, intensity, counter_base(seed, call)};
+                  per_node, modify_output, fix_roulette, input_len, output_len, n_consts, rate, intensity, counter_base(seed, call), nullptr, nullptr, nullptr,
+                  nullptr, nullptr};
     long blocks = ((long)pop_size + 3) / 4;
     const long cap = (long)device_info().num_cus * 32;
     if (blocks > cap) blocks = cap;

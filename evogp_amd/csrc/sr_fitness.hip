@@ -518,6 +518,27 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         std::lock_guard<std::mutex> pl(g_prof_mu);
         g_prof.push_back(prof);
     };
+    // A call WITHOUT a function mask -- torch.ops.evogp_cuda.tree_SR_fitness, the operator the reference's own Python calls
+    // (tree/forest.py:340-351, torch_wrapper.cu:235-284) -- is given the mask that the last completed call on a forest of this shape
+    // OBSERVED on the device (the packed compiler notes which of its lines it needed, the interpreter's launch publishes that to a word
+    // of host memory: sr_tc.hip tc_learned_class): nothing but + - * / -> the arithmetic line and ONE array of records (256 instead of
+    // 768 MB at 1 M trees), the kernels a caller's mask chooses.  The first call on a shape has no observation: it looks (one pass over
+    // the nodes, waited for -- once per shape; inside a stream capture it takes round 5's generic line and three arrays instead).  Only
+    // speed follows the observation: it is of an EARLIER forest, and a tree the chosen line cannot take goes the way it goes under a
+    // mask that promised too much (the register kernels: the same value up to the order of the sum over the rows) -- for one call, whose
+    // own observation corrects the next.  EVOGP_TC_LEARN=0: such calls always take the generic line and three arrays.
+    if (!STORE && asm_depth == 3 && !mo && !p.classify && p.func_mask == 0u && p.gp_len <= 64 && p.marks) {
+        static const int env_learn = env_int("EVOGP_TC_LEARN", 1);
+        constexpr unsigned kArith = (1u << F_ADD) | (1u << F_SUB) | (1u << F_MUL) | (1u << F_DIV);
+        constexpr unsigned kUnaryOwn = (1u << F_SIN) | (1u << F_COS) | (1u << F_TAN) | (1u << F_LOG) | (1u << F_LOOSE_LOG) | (1u << F_EXP) | (1u << F_INV) |
+                                       (1u << F_NEG) | (1u << F_ABS) | (1u << F_SQRT) | (1u << F_LOOSE_SQRT);
+        if (env_learn) {
+            int cls = tc_learned_class(p.pop, p.gp_len, stream, &p.feedback, &p.feedback_expected);
+            if (p.feedback && cls < 0) cls = tc_detect_class(p, p.marks + 5, stream);
+            if (p.feedback && cls == 0) p.func_mask = kArith;
+            else if (p.feedback && cls == 1) p.func_mask = kArith | kUnaryOwn;
+        }
+    }
     if (!STORE && asm_depth == 3 && !mo && !profiling && p.func_mask != 0u && p.gp_len <= 64) {
         // The caller knows the forest's function set.  Nothing but + - * / and the unary functions with handlers of their own:
         // no tree can be left for the general compiler (rows of at most 64 nodes), so that launch is not made.  The last follow-up

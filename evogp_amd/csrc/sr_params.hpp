@@ -36,7 +36,11 @@ struct SrParams {
                               // that no tree can be left for it; a tree that carries its sentinel after all is evaluated by the last follow-up kernel
     unsigned func_mask;       // bit f: function id f (defs.h:10-57) may occur in the forest; 0 = unknown.  A caller that knows the
                               // forest's function set (evogp_amd.tree.Forest tracks it from the descriptors its trees came from) lets
-                              // the call skip launches that such a forest cannot need -- decided by the mask, never by history
+                              // the call skip launches that such a forest cannot need.  A call that comes without one (the reference's operator)
+                              // is given the mask the last completed call on a forest of its shape observed (run_population, tc_learned_class)
+    unsigned *feedback;       // a call without a function mask: where its interpreter launch publishes the function class the program compiler
+                              // found (tc_learned_class), or nullptr
+    unsigned feedback_expected;   // ... the word the host read there before the call (the launch writes only what differs)
     unsigned *marks; // [0] != 0: some tree carries kSentinelHeavy, [1] != 0: some tree carries kSentinelDeep,
                      // [2]: how many of the mark_sample sampled trees were marked heavy (may be nullptr)
 };
@@ -45,6 +49,8 @@ struct SrParams {
 // assembly core.  Returns hipSuccess and sets *handled when it took the launch (trees it could not take are
 // marked kSentinelHeavy / NaN in p.fitness for the follow-up kernels); *handled == false means "not eligible".
 hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled, int *mark_sample, int *mark_chunks);
+int tc_learned_class(int pop, int gp_len, hipStream_t stream, unsigned **publish, unsigned *word);
+int tc_detect_class(const SrParams &p, unsigned *flags, hipStream_t stream);
 
 // Classification epilogue on the threaded code (sr_fitness.hip: it shares the call-scratch chain with the fitness calls):
 // counts[t] = rows whose arg-max output equals labels[row]; trees the path cannot take come back with kDeepCountBit set and

@@ -290,7 +290,13 @@ int evogp_hip_evaluate_prepared(unsigned pop_size, unsigned gp_len, unsigned var
  *     bytes = ceil(pop_size * 256 / 4096) * 4096 * max(2, ceil((gp_len + 2) / 31))    (+ 1/8 slack when it grows)
  * i.e. 768 MB for 1 M trees of gp_len 64 (three arrays of records; two up to gp_len 60), 8.7 GB for 1 M trees of gp_len 1024.
  * A single-output forest of gp_len <= 64 whose function mask (evogp_hip_sr_fitness_hinted) holds no unary function has programs of at
- * most 32 words: ONE array, 256 MB at 1 M trees (round 4).
+ * most 32 words: ONE array, 256 MB at 1 M trees (round 4).  Round 6: evogp_hip_sr_fitness -- the call WITHOUT a mask, the reference's
+ * own operator (torch_wrapper.cu:235-284) -- is given the mask the engine observes on the device: the first call on a population
+ * shape (pop_size, gp_len) looks at its forest (one pass over the nodes, waited for once per shape; not inside a stream capture,
+ * where the call takes the law above), every later call reads what the last completed call on that shape observed.  The observation
+ * decides which kernels run and how many arrays are held, never a result: a tree the chosen compiler cannot take is evaluated by the
+ * register kernels (the value up to the order of the sum over the rows), and the call's own observation corrects the next call.
+ * EVOGP_TC_LEARN=0 switches the observations off (unmasked calls then always hold three arrays).
  *   evogp_hip_set_program_buffer_limit  caps the buffer (default 16 GiB): a call that would need more runs on the register
  *                                       interpreters instead (same results, 3-6x slower); 0 disables the compiled path.
  *   evogp_hip_program_buffer_bytes      bytes currently held on the current device (the eager buffer + the graphs').
@@ -317,49 +323,8 @@ unsigned long long evogp_hip_program_buffer_bytes(void);
 unsigned long long evogp_hip_record_ring_bytes(void);
 int evogp_hip_release_workspaces(void);
 
-/* Average duration in milliseconds of the most recent `evogp_hip_*` launch sequence that was
- * bracketed by evogp_hip_timer_begin/_end on `stream` (hipEvent pair recorded on that stream).
- * Used by bench.py to time the kernel on the stream it is launched on. */
-int evogp_hip_timer_begin(evogp_stream_t stream);
-int evogp_hip_timer_end(evogp_stream_t stream, float *elapsed_ms);
-
-/* Profiling hook (no counterpart in the reference): when device_counters != NULL the threaded-code fitness
- * kernel adds per-wave shader-clock cycle counts to device_counters[0..7] = {interpreter core, batch loop,
- * barrier wait, trees, nodes, whole kernel, waves, unused}; NULL (the default) disables the accounting. */
-int evogp_hip_debug_set_stats(unsigned long long *device_counters);
-
-/* Per-stage timing of evogp_hip_sr_fitness (profiling, no counterpart in the reference).  While enabled, every call records
- * HIP events on its launch stream: before the call, between the program compiler and the interpreter kernel, behind the
- * interpreter, behind the follow-up kernels.  _read waits for the recorded calls and returns the average duration in ms
- * of {compiler, interpreter, follow-ups} over the calls the threaded-code path took; enable(…) also clears the record.
- * enable == 2: as 1, and the calls STOP behind the threaded code -- trees it leaves to the register kernels keep their sentinel
- * words (0x7FC0FEED, 0x7FC0BEEF, 0x7FC0DEED) in the fitness vector, so a script can count them (bench.py). */
-int evogp_hip_debug_profile(int enable);
-int evogp_hip_debug_profile_read(float *stage_ms /* [3] */, int *calls);
-
-/* Which program compiler evogp_hip_sr_fitness uses for single-output trees of at most 64 nodes (tests and A/B measurements; no
- * counterpart in the reference): -1 = the packed compiler with the batch size chosen by the population (DEFAULT), 0 = the older one-tree-per-pass
- * compiler, 8 / 16 / 32 / 64 = the packed compiler with that many trees per wave.  The fitness words do not depend on the choice
- * (tests/test_gpu_tc_wide.py compares them bit for bit).  The environment variable EVOGP_TC_PACKED sets the same before the first call. */
-int evogp_hip_debug_compile_batch(int trees);
-/* Which compiler takes single-output trees of MORE than 64 nodes over + - * / and the unary functions with handlers of their own (tests
- * and A/B measurements): 1 = the straight-line staged compiler of round 5 (DEFAULT; csrc/sr_tc.hip compile_long_arith), 0 = the general
- * compiler's staged passes, as every other long tree; -1 = back to the default / the environment (EVOGP_TC_LONG_FAST).  Same fitness words. */
-int evogp_hip_debug_long_compiler(int fast);
-/* Whether a program word whose successor has no variable operand names its handler's twin that does not prefetch:
- * -1 = by the launch's trees per CU (DEFAULT: from 900 on; the environment variable EVOGP_TC_TWINS = 0 / 2 sets never / always before the
- * first call), 0 = never, 1 = always.  The fitness words do not depend on the choice (tests/test_gpu_tc_wide.py compares them bit for bit). */
-int evogp_hip_debug_twins(int mode);
-
-/* Handler histogram of the program records the most recent evogp_hip_sr_fitness call on the current device compiled:
- * device_hist[flavour * N + id] = number of program words with that handler among the first `pop` trees, N =
- * evogp_hip_debug_tc_nhandlers(), hist_len >= 2 N.  Handler ids and their instruction counts: evogp_amd/lib/tc_handlers.json
- * (written by csrc/gen/gen_tc_asm.py).  bench.py derives the VALU-issue roofline of the interpreter from it. */
-int evogp_hip_debug_tc_histogram(unsigned pop, unsigned long long *device_hist, int hist_len, evogp_stream_t stream);
-int evogp_hip_debug_tc_nhandlers(void);
-/* The program of one tree as that call compiled it (diagnostics; waits for the device): up to max_words pairs {word 0, word 1} in execution
- * order, NEXT words followed; returns the number of words (END / SKIP included), -1 on error. */
-int evogp_hip_debug_tc_program(unsigned tree, unsigned *host_words, int max_words);
+/* Timers, per-stage profiling, compiler / twin selection for A/B runs, handler histograms and the test entries of the native mutation
+ * kernels are not part of this boundary: include/evogp_hip_debug.h. */
 
 /* Human-readable text for a return code of any function above. */
 const char *evogp_hip_error_string(int code);
@@ -393,7 +358,7 @@ const char *evogp_hip_error_string(int code);
 int evogp_hip_set_sr_division(int mode);
 int evogp_hip_get_sr_division(void);
 
-/* ABI version of this header (4): bumped when a signature changes or an entry point is added. */
+/* ABI version of this header (5): bumped when a signature changes or an entry point is added (5: the debug hooks moved to evogp_hip_debug.h). */
 int evogp_hip_abi_version(void);
 
 #ifdef __cplusplus

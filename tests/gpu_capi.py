@@ -1,4 +1,4 @@
-"""GPU-side test helper: call the C ABI (include/evogp_hip.h) directly with device pointers.
+"""GPU-side test helper: call the C ABI (include/evogp_hip.h; the test entries of include/evogp_hip_debug.h) directly with device pointers.
 numpy in, numpy out; torch is only used to own device memory."""
 import numpy as np
 import torch
@@ -70,9 +70,14 @@ def evaluate(value, type_, size, X, out_len):
     return res.cpu().numpy()
 
 
-def sr_fitness(value, type_, size, X, y, use_mse=True, kernel_type=0, func_mask=0):
-    """func_mask != 0: evogp_hip_sr_fitness_hinted with that function-set mask (what evogp_amd.tree.Forest.SR_fitness and bench.py call)"""
+def sr_fitness(value, type_, size, X, y, use_mse=True, kernel_type=0, func_mask=0, forget=True):
+    """func_mask != 0: evogp_hip_sr_fitness_hinted with that function-set mask (what evogp_amd.tree.Forest.SR_fitness and bench.py call).
+    Without a mask the engine chooses its program compiler by what the last call on a forest of this shape observed; `forget` drops
+    those observations first (include/evogp_hip_debug.h), so that the call looks at ITS forest and a test's kernels do not depend on the
+    tests before it.  tests/test_gpu_learned.py is about the observations themselves."""
     pop, gp_len = value.shape
+    if forget and not func_mask:
+        assert L.evogp_hip_debug_forget_function_classes() == 0
     a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(X, np.float32), dev(y, np.float32)]
     D, var_len = a[3].shape
     fit = torch.full((pop,), 12345.0, dtype=torch.float32, device=DEV)
@@ -179,3 +184,48 @@ def evaluate_prepared(value, type_, size, X, out_len, steps=1):
         assert rc == 0, L.evogp_hip_error_string(rc)
     torch.cuda.synchronize()
     return res.cpu().numpy(), left
+
+
+def structural_mutate_given(value, type_, size, mode, given, inner_is_offset=False, skip_rows=0):
+    """Delete (mode 0) / Hoist (mode 1) with the reference's own draws: given int32 [pop][3] = {mutates, node, child number / inner position}"""
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16)]
+    gd = dev(given, np.int32)
+    v, t, s = _out3(pop, gp_len)
+    rc = L.evogp_hip_debug_structural_mutate_given(pop, gp_len, mode, int(inner_is_offset), skip_rows, gd.data_ptr(), *[x.data_ptr() for x in a],
+                                                   v.data_ptr(), t.data_ptr(), s.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    return _np3(v, t, s)
+
+
+def insert_mutate_given(value, type_, size, given, fresh, skip_rows=0):
+    """Insert with the reference's own draws: given int32 [pop][3] = {mutates, node, position inside the fresh tree}; fresh = (value, type, size), row n for tree n"""
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16), dev(fresh[0], np.float32), dev(fresh[1], np.int16), dev(fresh[2], np.int16)]
+    gd = dev(given, np.int32)
+    v, t, s = _out3(pop, gp_len)
+    rc = L.evogp_hip_debug_insert_mutate_given(pop, gp_len, skip_rows, gd.data_ptr(), *[x.data_ptr() for x in a], v.data_ptr(), t.data_ptr(), s.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    return _np3(v, t, s)
+
+
+def point_mutate_given(value, type_, size, mode, target, u, var_idx, const_idx, out_idx, roulettes, consts, input_len, output_len, modify_output=False,
+                       fix_roulette=False, skip_rows=0):
+    """the point mutations with the reference's own per-node draws (all [pop][gp_len]); -> new values"""
+    pop, gp_len = value.shape
+    a = [dev(value, np.float32), dev(type_, np.int16), dev(size, np.int16)]
+    tg = dev(target, np.uint8)
+    ud = dev(u, np.float32) if u is not None else None
+    vi = dev(var_idx, np.int32) if var_idx is not None else None
+    ci = dev(const_idx, np.int32)
+    oi = dev(out_idx, np.int32) if out_idx is not None else None
+    rs = [dev(r, np.float32) for r in roulettes] if roulettes is not None else [None] * 3
+    cs = dev(consts, np.float32)
+    out = torch.full((pop, gp_len), float("nan"), dtype=torch.float32, device=DEV)
+    ptr = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
+    rc = L.evogp_hip_debug_point_mutate_given(pop, gp_len, mode, int(modify_output), int(fix_roulette), skip_rows, input_len, output_len, cs.shape[0],
+                                              tg.data_ptr(), ptr(ud), ptr(vi), ci.data_ptr(), ptr(oi), *[x.data_ptr() for x in a], *[ptr(r) for r in rs],
+                                              cs.data_ptr(), out.data_ptr(), _stream())
+    assert rc == 0, L.evogp_hip_error_string(rc)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()

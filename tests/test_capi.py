@@ -7,8 +7,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "evogp_hip.h")).read()
+def declared_symbols(header="evogp_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(evogp_hip_\w+)\s*\(", text)))
 
@@ -28,6 +28,11 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.PROTOTYPES) | {"evogp_hip_error_string", "evogp_hip_evaluate_workspace_bytes", "evogp_hip_select_workspace_bytes",
                                   "evogp_hip_program_buffer_bytes", "evogp_hip_record_ring_bytes"} == set(declared_symbols())
     assert lib.evogp_hip_abi_version() == _lib.ABI_VERSION
+    # the measurement and test hooks live in a header of their own: the boundary a maintainer of the reference binds holds none of them
+    assert not [s for s in declared_symbols() if "debug" in s or "timer" in s]
+    for sym in declared_symbols("evogp_hip_debug.h"):
+        assert hasattr(lib, sym), f"libevogp_hip.so does not export {sym}"
+    assert set(_lib.DEBUG_PROTOTYPES) == set(declared_symbols("evogp_hip_debug.h"))
 
 
 def test_error_strings_and_argument_errors_without_gpu():

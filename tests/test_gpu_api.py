@@ -190,9 +190,15 @@ def test_program_record_buffer_is_capped_and_released():
     law = array                       # include/evogp_hip.h: ONE array of records for a forest whose function mask holds no unary function
     held = evogp_amd.program_buffer_bytes()
     assert law <= held <= law + law // 8 + 8 * 256, (held, law)
-    # the same trees without a mask (a forest built from raw tensors): programs may have up to 64 words, three arrays at gp_len 64
+    # the same trees without a mask (a forest built from raw tensors, the reference's own operator): the engine looks at the forest
+    # (round 6: include/evogp_hip.h, tests/test_gpu_learned.py) and still holds ONE array
     plain = Forest(f.input_len, f.output_len, f.batch_node_value, f.batch_node_type, f.batch_subtree_size)
     assert torch.equal(plain.SR_fitness(X, y).view(torch.int32), a.view(torch.int32))
+    assert evogp_amd.program_buffer_bytes() == held
+    # ... and a forest with unary functions: programs may have up to 64 words, three arrays at gp_len 64
+    du = GenerateDescriptor(max_tree_len=64, input_len=4, output_len=1, using_funcs=["+", "-", "*", "/", "sin"], max_layer_cnt=5, const_samples=[-1, 0, 1])
+    fu = Forest.random_generate(pop, du, keys=torch.tensor([3, 4], dtype=torch.uint32, device=dev))
+    fu.SR_fitness(X, y)
     law3 = array * max(2, (64 + 2 + 30) // 31)
     assert law3 <= evogp_amd.program_buffer_bytes() <= law3 + law3 // 8 + 8 * 256, (evogp_amd.program_buffer_bytes(), law3)
     evogp_amd.release_workspaces()

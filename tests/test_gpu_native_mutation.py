@@ -252,3 +252,108 @@ def test_generation_step_with_the_reference_paper_operator_set(g, oracle):
             assert torch.equal(again.sort().values, best), "the first rows of the next generation are not the elites"
         trees = (f.batch_node_value.cpu().numpy(), f.batch_node_type.cpu().numpy(), f.batch_subtree_size.cpu().numpy())
         assert_close_classes(f.SR_fitness(Xd, yd).cpu().numpy(), oracle.sr_fitness(*trees, X, y), 1e-5, what=f"generation 3 under {[type(o).__name__ for o in ops]}")
+
+
+# ---- the native kernels on the REFERENCE's own draws ------------------------------------------------------------
+# tests/golden/mutation_*.npz hold, for thirteen runs of the reference's Python operators (tests/golden/make_mutation_golden.py), the
+# input forest, every random number the operator drew and its result.  evogp_hip_debug_*_given (include/evogp_hip_debug.h) run the
+# kernels of csrc/mutate_ops.hip with those draws handed in instead of hashed: the forests must equal the reference's, bit for bit on
+# the live prefix of every tree.  (The draws arrive in the reference's meaning: a node index, a child number, a uniform number for the
+# roulette search, an index into the constants -- what the kernels compute from their counter words in the tests above.)
+def _native_on_the_reference_draws(g, case):
+    import torch
+
+    import mutation_replay as mr
+    from evogp_amd.algorithm import MultiConstMutation, MultiPointMutation, SingleConstMutation, SinglePointMutation
+    from evogp_amd.tree import Forest, GenerateDescriptor, set_default_device
+
+    set_default_device("cpu")
+    z, meta, log = mr.load(case)
+    v, t, s = z["in_value"], z["in_type"], z["in_size"]
+    pop, L = v.shape
+    dk, par, kind = meta["descriptor"], meta["params"], meta["operator"]
+    rate = par["mutation_rate"]
+    mask = log[0] < np.float32(rate)
+    if kind == "DeleteMutation":
+        mask = mask & (s[:, 0] > 1)
+    idx = np.nonzero(mask)[0]
+
+    def per_tree(a, fill=0):
+        full = np.full((pop,) + a.shape[1:], fill, dtype=a.dtype)
+        full[idx] = a
+        return full
+
+    if kind == "HoistMutation":
+        given = np.stack([mask.astype(np.int64), per_tree(log[1]).astype(np.int64), per_tree(log[2]).astype(np.int64)], 1)
+        return g.structural_mutate_given(v, t, s, 1, given)
+    if kind == "DeleteMutation":
+        # delete.py:66-85: the node is the arg-max of the uniform scores over the function nodes that are small enough (0: the root)
+        sizes = s.astype(np.int64)
+        score = per_tree(log[1]) * (np.arange(L)[None, :] < sizes[:, :1])
+        score = np.where(sizes == 1, 0, score)
+        if par.get("max_mutatable_size"):
+            score = np.where(sizes > par["max_mutatable_size"], 0, score)
+        given = np.stack([mask.astype(np.int64), np.argmax(score, 1), per_tree(log[2]).astype(np.int64)], 1)
+        return g.structural_mutate_given(v, t, s, 0, given)
+    if kind == "InsertMutation":
+        od = meta["op_descriptor"]
+        set_default_device("cuda:0")
+        fresh = Forest.random_generate(len(idx), GenerateDescriptor(**od), keys=torch.from_numpy(log[2].astype(np.int64)).to(torch.uint32).to("cuda:0"))
+        fr = [np.zeros((pop, L), a.dtype) for a in (v, t, s)]
+        for dst, src in zip(fr, (fresh.batch_node_value, fresh.batch_node_type, fresh.batch_subtree_size)):
+            dst[idx] = src.cpu().numpy()      # the reference generates the fresh trees for the mutating trees only: row = rank among them
+        given = np.stack([mask.astype(np.int64), per_tree(log[1]).astype(np.int64), per_tree(log[3]).astype(np.int64)], 1)
+        return g.insert_mutate_given(v, t, s, given, fr)
+    desc = GenerateDescriptor(**dk)
+    forest = Forest(dk["input_len"], dk["output_len"], torch.from_numpy(v), torch.from_numpy(t), torch.from_numpy(s))
+    tm, consts = torch.from_numpy(mask), desc.const_samples.numpy()
+    rous = [r.numpy() for r in (desc.roulette_ufuncs, desc.roulette_bfuncs, desc.roulette_tfuncs)]
+    if kind in ("SinglePointMutation", "MultiPointMutation"):
+        modify = par.get("modify_output", False)
+        if kind == "SinglePointMutation":
+            targets = SinglePointMutation(rate, desc, modify_output=modify).targets(forest, tm, torch.from_numpy(per_tree(log[1]))).numpy()
+        else:
+            targets = MultiPointMutation(rate, desc, par["mutation_intensity"], modify_output=modify).targets(forest, tm, torch.from_numpy(per_tree(log[1], fill=2.0))).numpy()
+        names = ["u_uf", "u_bf", "u_tf"] + (["out_idx"] if modify else []) + ["var_idx", "const_idx"]
+        draws = {}
+        for name, a in zip(names, log[2:]):
+            full = np.zeros((pop, L), a.dtype)
+            full[targets] = a                  # the reference draws one number per target, in row-major order of the mutating trees
+            draws[name] = full
+        k = t.astype(np.int64) & 0x7F
+        u = np.where(k >= 4, draws["u_tf"], np.where(k == 3, draws["u_bf"], draws["u_uf"]))   # the draw of the node's own arity class (single_point.py:86-89)
+        out = g.point_mutate_given(v, t, s, 1 if kind == "SinglePointMutation" else 0, targets, u, draws["var_idx"], draws["const_idx"], draws.get("out_idx"),
+                                   rous, consts, dk["input_len"], dk["output_len"], modify_output=modify)
+        return out, t, s
+    if kind == "SingleConstMutation":
+        targets = SingleConstMutation(rate, desc).targets(forest, tm, torch.from_numpy(per_tree(log[1]))).numpy()
+        ci = np.broadcast_to(per_tree(log[2])[:, None], (pop, L))
+        return g.point_mutate_given(v, t, s, 3, targets, None, None, ci, None, None, consts, dk["input_len"], dk["output_len"]), t, s
+    assert kind == "MultiConstMutation", kind
+    targets = MultiConstMutation(rate, desc, par["mutation_intensity"]).targets(forest, tm, torch.from_numpy(per_tree(log[1], fill=2.0))).numpy()
+    ci = np.zeros((pop, L), np.int64)
+    ci[targets] = log[2]
+    return g.point_mutate_given(v, t, s, 2, targets, None, None, ci, None, None, consts, dk["input_len"], dk["output_len"]), t, s
+
+
+def _golden_cases():
+    import mutation_replay as mr
+
+    return mr.cases()
+
+
+@pytest.mark.parametrize("case", _golden_cases())
+def test_native_kernels_reproduce_the_reference_operators_from_its_own_draws(g, case):
+    import mutation_replay as mr
+
+    got = _native_on_the_reference_draws(g, case)
+    z, _, _ = mr.load(case)
+    want = (z["out_value"], z["out_type"], z["out_size"])
+    assert np.array_equal(got[2][:, 0], want[2][:, 0]), f"{case}: tree lengths differ"
+    live = np.arange(got[2].shape[1])[None, :] < got[2][:, :1].astype(np.int64)      # the reference leaves the tails undefined
+    assert (want[0].view(np.uint32) != z["in_value"].view(np.uint32)).any(), "the recorded run changed nothing"
+    for name, a, b in zip(("value", "type", "size"), got, want):
+        a = a.view(np.uint32) if a.dtype == np.float32 else a
+        b = b.view(np.uint32) if b.dtype == np.float32 else b
+        bad = np.argwhere((a != b) & live)
+        assert bad.size == 0, f"{case}: {name} differs at tree {bad[0][0]} node {bad[0][1]} ({len(bad)} entries)"
