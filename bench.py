@@ -256,16 +256,23 @@ def main():
         dist.all_reduce(tsum)
         return int(tsum.item())
 
-    def timed_steps(forest, Xd, yd, warmup, steps):
+    def reference_op(forest, Xd, yd):
+        """the reference's OWN operator, as its unchanged Python calls it (/root/reference/src/evogp/tree/forest.py:340-351): no function mask"""
+        return torch.ops.evogp_cuda.tree_SR_fitness(forest.pop_size, Xd.shape[0], forest.max_tree_len, forest.input_len, forest.output_len, True,
+                                                    forest.batch_node_value, forest.batch_node_type, forest.batch_subtree_size, Xd, yd, 4)
+
+    def timed_steps(forest, Xd, yd, warmup, steps, call=None):
         """W untimed + exactly K timed fitness passes, barrier + synchronize on both sides, max over ranks;
-        also the average duration of one call from a HIP event pair on the launch stream (this rank)."""
+        also the average duration of one call from a HIP event pair on the launch stream (this rank).
+        call: the pass (default Forest.SR_fitness, which hands the engine the forest's function mask)"""
+        call = call or (lambda f, X_, y_: f.SR_fitness(X_, y_, True, "auto"))
         for _ in range(warmup):
-            forest.SR_fitness(Xd, yd, True, "auto")
+            call(forest, Xd, yd)
         barrier()
         _lib.check(_lib.lib.evogp_hip_timer_begin(stream), "timer_begin")
         t0 = time.perf_counter()
         for _ in range(steps):
-            forest.SR_fitness(Xd, yd, True, "auto")
+            call(forest, Xd, yd)
         ev_ms = ctypes.c_float(0)
         _lib.check(_lib.lib.evogp_hip_timer_end(stream, ctypes.byref(ev_ms)), "timer_end")
         barrier()
@@ -289,6 +296,14 @@ def main():
     torch.cuda.synchronize()
     elapsed, call_ms = timed_steps(forest, Xd, yd, args.warmup, args.steps)
     all_nodes = sum_over_ranks(total_nodes)
+    # the same steps through torch.ops.evogp_cuda.tree_SR_fitness -- the operator a drop-in under the reference's own Python is called
+    # through: same protocol, right behind the headline's
+    for _ in range(3):
+        reference_op(forest, Xd, yd)
+    ref_elapsed, ref_call_ms = timed_steps(forest, Xd, yd, args.warmup, args.steps, call=reference_op)
+    torch.cuda.synchronize()
+    ref_record_bytes = int(evogp_amd.program_buffer_bytes())
+    ref_same = bool(torch.equal(reference_op(forest, Xd, yd).view(torch.int32), forest.SR_fitness(Xd, yd, True, "auto").view(torch.int32)))
 
     # the same steps once more with per-stage events inside the call (compiler | interpreter | follow-ups): the duration of the
     # dominant kernel itself.  Kept out of the timed region above.
@@ -409,6 +424,11 @@ def main():
                 # (both numbers: the timed K steps follow PREWARM untimed passes -- the device's clock ramp --; the same W + K steps of a
                 # fresh process are cold_start.ms_per_step)
                 "device_prewarm_calls": PREWARM, "ms_per_step_after_prewarm": elapsed / args.steps * 1000.0, "ms_per_step_fresh_process": cold_elapsed / args.steps * 1e3,
+                # the same K steps through the reference's own operator (no function mask): what a drop-in under the reference's unchanged Python runs
+                "ms_per_step_reference_op": ref_elapsed / args.steps * 1000.0,
+                "reference_op": {"op": "torch.ops.evogp_cuda.tree_SR_fitness", "ms_per_step": ref_elapsed / args.steps * 1000.0, "call_ms_events": ref_call_ms,
+                                 "gap_vs_masked_call": ref_elapsed / elapsed - 1.0, "record_buffer_bytes": ref_record_bytes,
+                                 "fitness_words_equal_masked_call": ref_same},
             },
             "node_evals_per_s": float(all_nodes) * DATAPOINTS * args.steps / elapsed,
             "roofline": {
@@ -541,6 +561,9 @@ def main():
         forest1, _, _, _, _ = sr_inputs(rank * pop1, pop1, device)
         nodes1 = int(forest1.batch_subtree_size[:, 0].to(torch.int64).sum())
         e1, call1_ms = timed_steps(forest1, Xd, yd, args.warmup, args.steps)
+        for _ in range(3):
+            reference_op(forest1, Xd, yd)
+        e1_ref, _ = timed_steps(forest1, Xd, yd, args.warmup, args.steps, call=reference_op)
         algo = GeneticProgramming(forest1, DefaultCrossover(), DefaultMutation(0.2, mdesc), DefaultSelection(0.3, elite_rate=0.01))
         gen_ms = []
         neg_inf = torch.full((pop1,), float("-inf"), dtype=torch.float32, device=device)
@@ -554,11 +577,73 @@ def main():
             "workload": "BASELINE configs[1]: SymbolicRegression synthetic 10-var, pop=100k per GPU, 1024 datapoints, max_tree_len=64, "
                         "funcs + - * /, one tree_SR_fitness pass per step",
             "scaling": "weak", "pop_per_gpu": pop1, "ms_per_step": e1 / args.steps * 1000.0, "call_ms_events": call1_ms,
+            "ms_per_step_reference_op": e1_ref / args.steps * 1000.0, "reference_op_gap": e1_ref / e1 - 1.0,
             "tree_evals_per_s": float(pop1) * DATAPOINTS * world * args.steps / e1,
             "mean_tree_len": nodes1 / pop1,
             "generation_ms": {"median": float(np.median(gen_ms[1:])), "first": gen_ms[0],
                               "what": "fitness + DefaultSelection + DefaultCrossover + DefaultMutation(0.2) on one shard"},
         }
+
+    if not args.headline_only and rank == 0:
+        # ONE generation on a FIXED workload with a stage split (the step of /root/reference/src/evogp/pipeline/standard.py:38-54,
+        # algorithm/genetic_programming.py:105-124): the same forest and the same random words every repetition (the population is put back
+        # and the step counter reset), HIP events between the stages -- fitness (the pass + its sign and NaN -> -inf, what
+        # SymbolicRegression.evaluate hands the algorithm) | selection | masked donor generation | breeding pass --, and the whole
+        # generation once more WITHOUT events in it (wall clock over the repetitions); for DefaultSelection and for the tournament
+        # selection configs[2] names, at the headline population and at configs[1].
+        def generation_stages(f0, selection, sel_name, reps=10):
+            algo = GeneticProgramming(f0, DefaultCrossover(), DefaultMutation(0.2, mdesc), selection)
+            neg_inf = torch.full((f0.pop_size,), float("-inf"), dtype=torch.float32, device=device)
+            names = ["fitness", "select", "donors", "breeding"]
+
+            def one(events):
+                algo.forest = f0
+                algo._steps = 0
+                k = [0]
+
+                def mark(_name=None):
+                    if events is not None:
+                        events[k[0]].record()
+                        k[0] += 1
+                algo.stage_marker = mark if events is not None else None
+                mark()
+                f = -f0.SR_fitness(Xd, yd, True, "auto")
+                f = torch.where(torch.isnan(f), neg_inf, f)
+                mark()
+                algo.step(f)
+                return k[0]
+
+            for _ in range(3):
+                one(None)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps):
+                one(None)
+            torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / reps * 1e3
+            per = {n: [] for n in names}
+            for _ in range(reps):
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                got = one(evs)
+                torch.cuda.synchronize()
+                if got != 5:
+                    return {"selection": sel_name, "error": f"the fused step recorded {got} of 5 events (composed operators ran)"}
+                for i, n in enumerate(names):
+                    per[n].append(evs[i].elapsed_time(evs[i + 1]))
+            stage = {n: float(np.median(v)) for n, v in per.items()}
+            total = sum(stage.values())
+            return {"selection": sel_name, "trees": f0.pop_size, "mean_tree_len": float(f0.batch_subtree_size[:, 0].float().mean()),
+                    "generation_ms": wall, "stage_ms": stage, "stage_sum_ms": total, "stage_sum_over_generation": total / wall}
+
+        try:
+            extras["generation_fixed_workload"] = {
+                "headline_population": [generation_stages(forest, default_sel(), "DefaultSelection(0.3, elite_rate=0.01)"),
+                                        generation_stages(forest, tournament_sel(), "TournamentSelection(20, survivor_rate=0.5, elite_rate=0.1)")],
+                "configs1": [generation_stages(forest1, default_sel(), "DefaultSelection(0.3, elite_rate=0.01)"),
+                             generation_stages(forest1, tournament_sel(), "TournamentSelection(20, survivor_rate=0.5, elite_rate=0.1)")],
+                "what": "one generation of a FIXED forest (population and random words restored every repetition): generation_ms = wall clock per "
+                        "repetition without events inside; stage_ms = medians of HIP-event intervals fitness | select | donors | breeding "
+                        "(DefaultCrossover + DefaultMutation(0.2, max_layer_cnt 3) in one breeding pass)"}
+        except Exception as exc:
+            extras["generation_fixed_workload"] = {"error": repr(exc)[:300]}
 
     if not args.headline_only:
         # BASELINE configs[4] (example/brax_task.py:19-32 shape: policy trees pop 50 000, 17 observations, 6 actions, max_tree_len 256,

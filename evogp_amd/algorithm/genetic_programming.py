@@ -97,8 +97,14 @@ class GeneticProgramming:
         rest = ops[1:] if first is not None else ops
         if first is not None and first.descriptor.max_tree_len != f.max_tree_len:
             return None
-        if any(not getattr(op, "takes_skip_rows", False) for op in rest):
-            return None   # (an operator of the caller's own: it sees the offspring forest alone, as the reference hands it over)
+        from . import mutation as _m
+
+        built_in = (_m.DefaultMutation, _m.HoistMutation, _m.DeleteMutation, _m.InsertMutation, _m.MultiPointMutation, _m.SinglePointMutation,
+                    _m.MultiConstMutation, _m.SingleConstMutation)
+        if any(type(op) not in built_in for op in rest):
+            # an operator of the caller's own -- also a SUBCLASS of a built-in one, whose __call__ may have the reference's signature
+            # (forest) and would not take skip_rows: it sees the offspring forest alone, as the reference hands it over
+            return None
         if rest and os.environ.get("EVOGP_NATIVE_MUTATION", "1") == "0":
             return None
         if type(self.selection) is DefaultSelection:
@@ -121,6 +127,7 @@ class GeneticProgramming:
 
         if not fitness.is_cuda or fitness.device != dev:
             return None   # (a fitness vector on another device: the operators' own torch programs deal with it)
+        mark = getattr(self, "stage_marker", None) or (lambda name: None)   # (bench.py: an event behind every stage of the step)
         if type(self.selection) is DefaultSelection:
             if fitness.dtype != torch.float32:
                 return None   # (a cast could merge ties of a float64 fitness: the selection operator ranks what it was given)
@@ -140,6 +147,7 @@ class GeneticProgramming:
                 self._replay_lists = (elites, parents)
                 return None
             elites, parents = elites.to(device=dev, dtype=torch.int32).contiguous(), parents.to(device=dev, dtype=torch.int32).contiguous()
+        mark("select")
         n_elite = elites.numel()
         n_new = pop - n_elite
         # no draw at all: the donor kernel and the breeding pass compute the six words of offspring i (and the two generation keys) as
@@ -163,7 +171,9 @@ class GeneticProgramming:
             donors = (torch.empty((n_new, L), dtype=torch.float32, device=dev), torch.empty((n_new, L), dtype=torch.int16, device=dev),
                       torch.empty((n_new, L), dtype=torch.int16, device=dev))
             mask = f.func_mask
+        mark("donors")
         nv, nt, ns = torch.ops.evogp_hip.breed_rows_hashed(pop, L, value, ntype, size, elites, parents, self._word_seed, self._steps,
                                                            below, *donors, 0, pop)
+        mark("breeding")
         self.forest = Forest(f.input_len, f.output_len, nv, nt, ns, func_mask=mask)
         return self.forest

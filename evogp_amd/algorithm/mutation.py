@@ -24,8 +24,22 @@ class BaseMutation:
 # are copied whatever is drawn -- GeneticProgramming.step hands over the whole next generation, elites first, instead of the offspring
 # alone.  The torch programs (`draw` + `apply`) stay: they are what reproduces the reference bit for bit from ITS draws
 # (tests/test_gpu_mutation_parity.py), the CPU path, and EVOGP_NATIVE_MUTATION=0.
-def _native(forest: Forest) -> bool:
-    return forest.batch_node_value.is_cuda and os.environ.get("EVOGP_NATIVE_MUTATION", "1") != "0"
+def _native(forest: Forest, descriptor: GenerateDescriptor = None, same_shape: bool = False) -> bool:
+    """the native launch takes the call: a device forest and, where the operator has a descriptor, its tables on the forest's device
+    (a CPU descriptor goes through the torch program, which moves what it needs); `same_shape`: the descriptor generates
+    rows of the forest's own width, inputs and outputs (InsertMutation's fresh trees are grafted row by row)"""
+    if not forest.batch_node_value.is_cuda or os.environ.get("EVOGP_NATIVE_MUTATION", "1") == "0":
+        return False
+    if descriptor is not None:
+        dev = forest.batch_node_value.device
+        tables = (descriptor.const_samples, descriptor.roulette_funcs, descriptor.depth2leaf_probs, descriptor.roulette_ufuncs,
+                  descriptor.roulette_bfuncs, descriptor.roulette_tfuncs)
+        if any(t is not None and t.device != dev for t in tables) or descriptor.roulette_ufuncs is None:
+            return False   # (a descriptor given a ready-made roulette has no per-arity tables: the torch programs)
+        if same_shape and (descriptor.max_tree_len != forest.max_tree_len or descriptor.input_len != forest.input_len
+                           or descriptor.output_len != forest.output_len):
+            return False
+    return True
 
 
 def _next_call(op):
@@ -226,7 +240,7 @@ class InsertMutation(BaseMutation):
 
     def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
         d = self.descriptor
-        if _native(forest):
+        if _native(forest, d, same_shape=True):
             # two launches: fresh trees for the rows whose word lies under the rate (the donor kernel of the fused default step), then
             # csrc/mutate_ops.hip insert_mutate_kernel under the same words -- no list of mutating trees, no host sync
             seed, call = _next_call(self)
@@ -343,7 +357,7 @@ class MultiPointMutation(BaseMutation):
 
     def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
         d = self.descriptor
-        if _native(forest) and d.roulette_ufuncs is not None:
+        if _native(forest, d):
             seed, call = _next_call(self)
             value = torch.ops.evogp_hip.point_mutate(self._native_mode, float(self.mutation_rate), float(self.mutation_intensity), bool(self.per_node),
                                                      bool(self.modify_output), bool(self.fix_roulette), int(skip_rows), forest.input_len, forest.output_len,
@@ -409,7 +423,7 @@ class MultiConstMutation(BaseMutation):
 
     def __call__(self, forest: Forest, skip_rows: int = 0) -> Forest:
         d = self.descriptor
-        if _native(forest) and d.roulette_ufuncs is not None:   # (the kernel's argument list wants the roulettes; the constant modes do not read them)
+        if _native(forest, d):   # (the kernel's argument list wants the roulettes; the constant modes do not read them)
             seed, call = _next_call(self)
             value = torch.ops.evogp_hip.point_mutate(self._native_mode, float(self.mutation_rate), float(self.mutation_intensity), bool(self.per_node),
                                                      False, False, int(skip_rows), forest.input_len, forest.output_len, seed, call,

@@ -14,6 +14,7 @@
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPCachingAllocator.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -594,6 +595,11 @@ TORCH_LIBRARY_IMPL(evogp_cuda, CUDA, m) {
 // (include/evogp_hip.h evogp_hip_set_allocator; EVOGP_TORCH_ALLOCATOR=0: plain hipMalloc as in rounds 1-4)
 static void *torch_pool_alloc(size_t bytes) {
     try {
+        // Not while ANY stream of this thread's device is being captured: raw_alloc may then hand out memory of the
+        // capture's private pool, and the device-wide wait the engine makes before it first touches a block would invalidate the
+        // capture.  nullptr: the engine takes the call on kernels that need no record buffer.  (Blocks are returned to the pool only
+        // by evogp_hip_release_workspaces, after a device-wide wait.)
+        if (c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None) return nullptr;
         return c10::hip::HIPCachingAllocator::raw_alloc(bytes);
     } catch (...) {
         return nullptr;

@@ -11,7 +11,7 @@ csrc/sr_tc.hip tc_learned_class / tc_detect_class, csrc/sr_fitness.hip run_popul
 import numpy as np
 import pytest
 
-from helpers import ARITH, assert_close_classes, c2_dataset, depth2leaf, roulette_uniform
+from helpers import ARITH, assert_close_classes, assert_within_sensitivity, c2_dataset, depth2leaf, per_tree_tolerance, roulette_uniform
 from test_gpu_tc_wide import handler_histogram
 
 pytestmark = pytest.mark.gpu
@@ -66,7 +66,8 @@ def test_out_of_date_observation_costs_speed_not_results(g, oracle, funcs, name)
     pop = 20_000
     X, y = c2_dataset()
     fa, fu = forest_of(oracle, pop, ARITH, 5), forest_of(oracle, pop, funcs, 6)
-    want_a, want_u = oracle.sr_fitness(*fa, X, y), oracle.sr_fitness(*fu, X, y)
+    want_a = oracle.sr_fitness(*fa, X, y)
+    want_u, tol_u, unstable_u = per_tree_tolerance(oracle, fu, X, y)   # (sin: the device library against the host's, tests/helpers.py)
     evogp_amd.release_workspaces()
     exact = g.sr_fitness(*fu, X, y, forget=True)                   # looked at: every tree through the threaded code
     h_exact = handler_histogram(g, pop)
@@ -75,7 +76,8 @@ def test_out_of_date_observation_costs_speed_not_results(g, oracle, funcs, name)
     stale = g.sr_fitness(*fu, X, y, forget=False)                  # ... which is wrong for this forest
     h_stale = handler_histogram(g, pop)
     assert h_stale["skip"] > 0.3 * pop, "the out-of-date observation was not used"
-    assert_close_classes(stale, want_u, 1e-5, what=f"{name}: call under an out-of-date observation")
+    assert_within_sensitivity(exact.astype(np.float64), want_u, tol_u, unstable_u, f"{name}: the call that looked")
+    assert_within_sensitivity(stale.astype(np.float64), want_u, tol_u, unstable_u, f"{name}: call under an out-of-date observation")
     healed = g.sr_fitness(*fu, X, y, forget=False)                 # the stale call's own observation
     assert handler_histogram(g, pop)["skip"] == h_exact["skip"]
     assert same_words(healed, exact)
@@ -108,9 +110,14 @@ def test_unhinted_call_inside_a_capture_does_not_wait(g, oracle):
     eager = g.sr_fitness(*f, X, y, forget=True)
     a = [g.dev(f[0], np.float32), g.dev(f[1], np.int16), g.dev(f[2], np.int16), g.dev(X, np.float32), g.dev(y, np.float32)]
     fit = torch.zeros(pop, dtype=torch.float32, device=g.DEV)
-    g.L.evogp_hip_debug_forget_function_classes()                 # no observation: a capture cannot look (nothing is waited for inside one)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                 # (a stream's first fitness call allocates its scratch block: not inside a capture)
+        rc = g.L.evogp_hip_sr_fitness_hinted(pop, X.shape[0], 64, X.shape[1], 1, 1, *[x.data_ptr() for x in a], fit.data_ptr(), 0, ARITH_MASK | (1 << SIN),
+                                             side.cuda_stream)
+        assert rc == 0
+    side.synchronize()
+    g.L.evogp_hip_debug_forget_function_classes()                 # no observation: a capture cannot look (nothing is waited for inside one)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):

@@ -261,6 +261,16 @@ def test_generation_step_with_the_reference_paper_operator_set(g, oracle):
 # the live prefix of every tree.  (The draws arrive in the reference's meaning: a node index, a child number, a uniform number for the
 # roulette search, an index into the constants -- what the kernels compute from their counter words in the tests above.)
 def _native_on_the_reference_draws(g, case):
+    from evogp_amd.tree import utils as tree_utils
+
+    before = tree_utils._DEVICE            # (the descriptors and forests below are built on the CPU; the suite's default goes back in place)
+    try:
+        return _native_on_the_reference_draws_cpu_tables(g, case)
+    finally:
+        tree_utils._DEVICE = before
+
+
+def _native_on_the_reference_draws_cpu_tables(g, case):
     import torch
 
     import mutation_replay as mr
