@@ -157,6 +157,12 @@ __global__ __launch_bounds__(kGenBlock) void generate_kernel(GenParams p) {
 //     a workgroup looks at 64 * G consecutive rows (G = 0.8 / the expected share of live rows) and works through the list of
 //     live ones 64 at a time, so the serial loop runs with ~80 % of its lanes live instead of 20 % (1 M rows: 152 -> 82 us, DESIGN
 //     section 3.3).  Which lane generates a tree does not matter: the draw order belongs to the tree (its index seeds the stream).
+__device__ inline uint32_t fast_mod(uint32_t x, uint32_t d, uint32_t m) {   // x % d with m = floor(2^32 / d) (d == 1: 2^32 - 1): the quotient estimate is at most one short
+    const uint32_t r = x - __umulhi(x, m) * d;
+    return r >= d ? r - d : r;
+}
+__device__ inline uint32_t fast_mod_magic(unsigned d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
+
 constexpr int kGenChunk = 16;
 constexpr int kGenMaxGather = 16;     // G: at most 1024 rows per workgroup
 constexpr int kGenPitch = 68;         // == 4 (mod 64): the 16x4 flush pattern and the per-lane pattern are both conflict-free
@@ -234,6 +240,8 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         }
     }
 
+    const uint32_t m_const = uni(fast_mod_magic(p.n_const)), m_var = uni(fast_mod_magic(p.var_len)), m_out = uni(fast_mod_magic(p.out_len));
+
     for (unsigned b0 = 0; b0 < n_rows; b0 += kWave) {   // 64 rows of the list at a time
     const bool active = b0 + lane < n_rows;
     const unsigned n = active ? rows_s[b0 + lane] : 0u;
@@ -260,62 +268,73 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         }
     };
 
+    // Round 6, per node: the frame on top of the pending-children stack stays in registers (LDS holds the frames below it: a push when a
+    // function has siblings left, a pop when a subtree is complete -- every second node instead of every node); a leaf's size is 1 when it
+    // is emitted, so only FUNCTION nodes are "open" and a new node closes the functions at its depth and below (one every second node
+    // instead of at least one per node, and the longest such loop in the wave is what every lane waits for); the second draw is common to
+    // both kinds of node and the third to both kinds of leaf; x % n is a multiplication by floor(2^32 / n) and one correction.  The draw
+    // order is the reference's (generate.cu:55-172): the same trees, bit for bit.
     Taus88 rng(gen_seed(p, n));
-    int top = 1, deepest_open = -1;
+    int tos_childs = 1, tos_depth = 0, sp = 0, deepest_open = -1;
+    bool running = active;
     unsigned cnt = 0, it = 0;
-    frame_s[lane] = 1u;  // {childs = 1, depth = 0}
     for (;; ++it) {
-        const bool live = active && top > 0 && it < (unsigned)kMaxStack;
+        const bool live = running && it < (unsigned)kMaxStack;
         if (!__any(live)) break;
         float v = 0.0f;
         int t = 0;
         if (live) {
-            const uint32_t fr = frame_s[(--top) * kWave + lane];
-            const int childs = (int)(fr & 0xFu) - 1;
-            const int depth = (int)(fr >> 4);
+            const int childs = tos_childs - 1, depth = tos_depth;
             const int dl = depth < kMaxFullDepth ? depth : kMaxFullDepth;
-            int new_childs = 0;
-            if (rng.uniform() >= misc_s[dl]) {  // function node (generate.cu:71-100)
-                const float r = rng.uniform();
+            const float u1 = rng.uniform(), u2 = rng.uniform();
+            const bool is_func = u1 >= misc_s[dl];
+            for (int dd = depth; dd <= deepest_open; ++dd) {   // the functions at this depth and below ended with the node before this one
+                const unsigned start = open_s[dd * kWave + lane];
+                if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint16_t)(it - start);
+            }
+            if (is_func) {  // function node (generate.cu:71-100)
                 int k = 0;  // largest i with r >= roulette[i], plus one (:77-84)
                 if (n_thr <= kGenThr) {
 #pragma unroll
-                    for (int m = 0; m < kGenThr; ++m) k = r >= thr[m] ? kv[m] : k;
+                    for (int m = 0; m < kGenThr; ++m) k = u2 >= thr[m] ? kv[m] : k;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < kNumFuncs; ++i) k = r >= misc_s[16 + i] ? i + 1 : k;
+                    for (int i = 0; i < kNumFuncs; ++i) k = u2 >= misc_s[16 + i] ? i + 1 : k;
                 }
                 t = k <= F_IF ? T_TFUNC : (k <= F_GE ? T_BFUNC : T_UFUNC);
                 v = (float)k;
-                new_childs = t - 1;
+                const int arity = t - 1;
                 if (MO) {
                     if (rng.uniform() <= p.out_prob) {  // output node (:86-96)
-                        const uint32_t oi = rng.next() % p.out_len;
+                        const uint32_t oi = fast_mod(rng.next(), p.out_len, m_out);
                         v = bits2f(((oi & 0xFFFFu) << 16) | ((uint32_t)k & 0xFFFFu));
                         t |= T_OUT;
                     }
                 }
+                open_s[depth * kWave + lane] = (uint16_t)it;
+                deepest_open = depth;
+                if (childs > 0) frame_s[(sp++) * kWave + lane] = (uint16_t)((unsigned)childs | ((unsigned)depth << 4));
+                tos_childs = arity; tos_depth = depth + 1;
             } else {  // leaf (:104-123)
-                if (rng.uniform() <= p.const_prob) {
-                    const uint32_t ci = rng.next() % p.n_const;
+                const uint32_t r3 = rng.next();
+                if (u2 <= p.const_prob) {
+                    const uint32_t ci = fast_mod(r3, p.n_const, m_const);
                     if (consts_in_lds) v = const_s[ci];  // wave-uniform choice: a ds_read, not a flat load
                     else v = p.consts[ci];
                     t = T_CONST;
                 } else {
-                    v = (float)(rng.next() % p.var_len);
+                    v = (float)fast_mod(r3, p.var_len, m_var);
                     t = T_VAR;
                 }
+                if (it < p.gp_len) size_s[it * kGenPitch + lane] = 1;
+                deepest_open = min(deepest_open, depth - 1);
+                if (childs > 0) tos_childs = childs;
+                else if (sp > 0) {
+                    const unsigned fr = frame_s[(--sp) * kWave + lane];
+                    tos_childs = (int)(fr & 0xFu); tos_depth = (int)(fr >> 4);
+                } else running = false;
             }
-            // close every open node at depth >= this depth: its subtree ended at this index
-            for (int dd = depth; dd <= deepest_open; ++dd) {
-                const unsigned start = open_s[dd * kWave + lane];
-                if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint16_t)(it - start);
-            }
-            open_s[depth * kWave + lane] = (uint16_t)it;
-            deepest_open = depth;
             cnt = it + 1;
-            if (childs > 0) frame_s[(top++) * kWave + lane] = (uint16_t)((unsigned)childs | ((unsigned)depth << 4));
-            if (new_childs > 0) frame_s[(top++) * kWave + lane] = (uint16_t)((unsigned)new_childs | ((unsigned)(depth + 1) << 4));
         }
         const unsigned slot = it & (kGenChunk - 1);
         ring_v[slot * kGenPitch + lane] = v;
