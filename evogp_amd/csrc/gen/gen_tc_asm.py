@@ -305,6 +305,17 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a("global_atomic_add v12, v[10:11], v9, off sc0")
         a("s_mov_b64 exec, -1")
 
+    def pool_grab():
+        """the next batch of the WORKGROUP's pool: a counter in LDS (STRIDE holds its address), a few hundred clocks, no traffic beyond
+        the CU.  LDS operations complete in order, so the handlers' counted waits (s_waitcnt lgkmcnt(n)) stay right with this one in
+        flight ahead of their reads."""
+        dyn_batch(T1)
+        a("s_mov_b64 exec, 1")
+        a(f"v_mov_b32 v9, s{T1}")
+        a(f"v_mov_b32 v4, {STRIDE}")
+        a("ds_add_rtn_u32 v12, v4, v9")
+        a("s_mov_b64 exec, -1")
+
     # ------------------------------------------------------------------ prologue
     if fused:
         # entry of a batch: the records were written by this wave's vector stores a moment ago -- wait for them, and drop what the
@@ -375,11 +386,13 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a("v_lshl_add_u32 v13, v9, 4, v13")
         a(f"s_load_dwordx4 s[{P1_}:{P4_}], %[karg], 0x48")  # static trees per workgroup, first dynamic tree, waves per workgroup
         a("s_waitcnt lgkmcnt(0)")
-        a(f"s_mul_i32 {CUR}, {CUR}, s{P1_}")          # CUR carries the workgroup id on entry: first tree of its static share
-        a(f"s_add_u32 {END_}, {CUR}, s{P1_}")         # end of the static share
-        a(f"s_mul_i32 {STRIDE}, {STRIDE}, s16")       # STRIDE carries the wave id on entry
-        a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")        # this wave's first static batch
-        a(f"s_mul_i32 {STRIDE}, s{P3_}, s16")         # distance between two batches of one wave
+        # Round 6: a workgroup's share of the population is a POOL its waves draw small batches from through a counter in LDS (STRIDE
+        # carries its address on entry, zeroed by the kernel's prologue) instead of a fixed round-robin split between the waves: the waves
+        # of a CU finish their share together whatever their trees cost, so the share can be most of the population and the counters in
+        # global memory -- one line per XCD, saturated at ~90 grabs per microsecond: 17 % of a wave's clocks at 100 k trees, round 5 --
+        # only hand out the rest, which evens out the workgroups.
+        a(f"s_mul_i32 {CUR}, {CUR}, s{P1_}")          # CUR carries the workgroup id on entry: first tree of its pool
+        a(f"s_add_u32 {END_}, {CUR}, s{P1_}")         # end of the pool
         a(f"s_mov_b32 {DYN}, s{P2_}")                 # first tree of the dynamic region
         # one dynamic region and one counter line per XCD: region = XCC_ID & flags[15:12], s18 still holds trees per region
         a(f"s_getreg_b32 s{P1_}, hwreg(HW_REG_XCC_ID, 0, 4)")
@@ -418,41 +431,32 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
             a(f"s_memtime s[{T1}:{T2}]")
             a("s_waitcnt lgkmcnt(0)")
             a(f"v_mov_b32 v{A_START}, s{T1}")
-        a("s_mov_b32 s18, 1")  # 1 while this wave's part of the static share lasts
-        a(f"s_cmp_lt_u32 {CUR}, {END_}")
-        a(f"s_cbranch_scc0 {lab('batch')}")
-        warm(CUR)
+        a("s_mov_b32 s18, 1")  # 1 while the workgroup's pool lasts
+        pool_grab()
+        a("s_waitcnt lgkmcnt(0)")
+        a(f"v_readfirstlane_b32 s{sT0N}, v12")
+        a(f"s_add_u32 s{sT0N}, s{sT0N}, {CUR}")
         # ------------------------------------------------------------------ batch loop
         a(f"{lab('batch')}:")
         a("s_cmp_eq_u32 s18, 0")
         a(f"s_cbranch_scc1 {lab('dyn')}")
-        a(f"s_cmp_lt_u32 {CUR}, {END_}")
+        a(f"s_mov_b32 s{sT0}, s{sT0N}")
+        a(f"s_cmp_lt_u32 s{sT0}, {END_}")
         a(f"s_cbranch_scc0 {lab('to_dyn')}")
-        a(f"s_mov_b32 s{sT0}, {CUR}")
+        pool_grab()                                    # the next batch, one batch ahead: consumed behind this batch's second tree
+        warm(f"s{sT0}")
         a(f"s_sub_u32 s{sNB}, {END_}, s{sT0}")
-        a(f"s_min_u32 s{sNB}, s{sNB}, s16")
-        a(f"s_add_u32 {CUR}, {CUR}, {STRIDE}")
-        a(f"s_cmp_lt_u32 {CUR}, {END_}")
-        a(f"s_cbranch_scc0 {lab('last_static')}")
-        warm(CUR)                                      # the records of this wave's NEXT batch
+        dyn_batch(T1)
+        a(f"s_min_u32 s{sNB}, s{sNB}, s{T1}")
         a(f"s_branch {lab('have_batch')}")
-        # this was the wave's last static batch: reserve its first dynamic batch now, one batch ahead like every later
-        # one (asked for only when the static share is used up, all waves queue at the counter at the same moment:
-        # ~11 ns per same-address atomic, 45 us for 4096 waves)
-        a(f"{lab('last_static')}:")
-        grab()
-        a("s_mov_b32 s18, 2")
-        a(f"s_branch {lab('have_batch')}")
+        # the pool is used up (every wave of the workgroup finds that out by itself, a batch after its last one): the rest of the launch
+        # comes from this XCD's region.  The one grab whose latency nothing hides.
         a(f"{lab('to_dyn')}:")
-        a("s_cmp_eq_u32 s18, 2")
         a("s_mov_b32 s18, 0")
-        a(f"s_cbranch_scc1 {lab('to_dyn_got')}")
         tick_begin()
-        grab()  # a wave without a static batch (tiny populations)
+        grab()
         a("s_waitcnt vmcnt(0)")
         tick_end(A_WORK)
-        a(f"{lab('to_dyn_got')}:")
-        a("s_waitcnt vmcnt(0)")
         a(f"v_readfirstlane_b32 s{sT0N}, v12")
         a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
         a(f"{lab('dyn')}:")
@@ -482,6 +486,26 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     a(f"s_mov_b32 s{sTILE}, 0")
     a("s_waitcnt lgkmcnt(0)")
     tick_end(A_REC)
+    if not fused:
+        # the second tree of a pool batch: the grab made at the batch's start has landed (nothing is in flight behind the wait above),
+        # so the NEXT batch is known -- its records are pulled into L2 while the rest of this one runs
+        a(f"s_cmp_eq_u32 s{sB}, 1")
+        a(f"s_cbranch_scc0 {lab('no_prewarm')}")
+        a("s_cmp_eq_u32 s18, 1")
+        a(f"s_cbranch_scc0 {lab('no_prewarm')}")
+        a(f"v_readfirstlane_b32 s{sT0N}, v12")
+        a(f"s_add_u32 s{sT0N}, s{sT0N}, {CUR}")
+        a(f"s_cmp_lt_u32 s{sT0N}, {END_}")
+        a(f"s_cbranch_scc0 {lab('pool_dry')}")
+        warm(f"s{sT0N}")
+        a(f"s_branch {lab('no_prewarm')}")
+        # ... or the pool has run dry: this wave's next batch comes from its XCD's region, and the grab goes out now -- a tree ahead of
+        # its use, and at a moment of this wave's own (left to the batch's end, all waves of a workgroup -- of most workgroups -- would
+        # queue at the counters together, with nothing to do meanwhile)
+        a(f"{lab('pool_dry')}:")
+        grab()
+        a("s_mov_b32 s18, 2")
+        a(f"{lab('no_prewarm')}:")
     if stats:
         a(f"v_add_u32 v{A_TREES}, 1, v{A_TREES}")
     elif KWARM and not fused:
@@ -2366,15 +2390,31 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
     # batch finished: everything outstanding has long landed (warm-up load, the next dynamic grab); take the grab
     # first, then mean = sum / D and one coalesced store for the evaluated trees
     tick_begin()
-    a("s_waitcnt vmcnt(0)")
+    if fused:
+        a("s_waitcnt vmcnt(0)")
+    else:
+        # the grab of the NEXT batch.  From an XCD's region it is a global atomic, the oldest of the vector-memory operations in flight (the
+        # warm-up loads behind it may stay out: nobody reads their registers); from the workgroup's pool it is an LDS operation, and the
+        # warm-up loads -- issued one tree ago -- are not waited for at all (round 6: they were, with the pool's first build: 20-30 %
+        # of a wave's clocks at 100 k trees)
+        a("s_cmp_eq_u32 s18, 1")
+        a(f"s_cbranch_scc1 {lab('pool_batch_end')}")
+        a("s_cmp_eq_u32 s18, 0")
+        a(f"s_cbranch_scc1 {lab('dyn_batch_end')}")
+        a("s_waitcnt vmcnt(0)")                       # (s18 == 2: the pool ran dry during this batch; the region's grab is the youngest operation in flight)
+        a("s_mov_b32 s18, 0")
+        a(f"s_branch {lab('pool_batch_end')}")
+        a(f"{lab('dyn_batch_end')}:")
+        a(f"s_waitcnt vmcnt({2 if L2WARM else 0})")
+        a(f"{lab('pool_batch_end')}:")
+        a("s_waitcnt lgkmcnt(0)")
     tick_end(A_WORK)
     NEXT_BATCH = lab('exit') if fused else lab('batch')
     if not fused:
-        a("s_cmp_eq_u32 s18, 0")
-        a(f"s_cbranch_scc0 {lab('no_grab')}")
         a(f"v_readfirstlane_b32 s{sT0N}, v12")
-        a(f"s_add_u32 s{sT0N}, s{sT0N}, {DYN}")
-        a(f"{lab('no_grab')}:")
+        a("s_cmp_eq_u32 s18, 0")
+        a(f"s_cselect_b32 s{T1}, {DYN}, {CUR}")
+        a(f"s_add_u32 s{sT0N}, s{sT0N}, s{T1}")
     a(f"s_cmp_eq_u64 s[{sOK}:{sOK + 1}], 0")
     a(f"s_cbranch_scc1 {NEXT_BATCH}")
     a(f"s_mov_b64 exec, s[{sOK}:{sOK + 1}]")
