@@ -1,8 +1,6 @@
-"""tree_generate: the persistent-lane kernel (generate_rows_kernel, round 6) against the staged kernel (EVOGP_GEN_ROWS=0 in a second
-process: the switch is read once) -- per-launch time at 100 k and 1 M rows of 64 nodes, the masked donor launch of a generation, and
-the rows themselves (a hash per output tensor, compared between the two runs by the caller).
-    python scripts/gen_ab.py            # this build's default
-    EVOGP_GEN_ROWS=0 python scripts/gen_ab.py"""
+"""tree_generate per launch at 100 k and 1 M rows of 64 nodes (and two other shapes), the masked donor launch of a generation, and a hash
+of the rows -- for A/B runs of two builds of csrc/generate.hip (round 6: the persistent-lane and straight-line kernels against the
+staged one, profiles/r06_generate_depth_sweep.log): the hashes must agree."""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +10,6 @@ from bench_ops_common import depth2leaf, roulette_uniform, timed
 
 L_ = g.L
 S = g._stream
-print("EVOGP_GEN_ROWS =", os.environ.get("EVOGP_GEN_ROWS", "(default 0)"), " EVOGP_GEN_TPW =", os.environ.get("EVOGP_GEN_TPW", "-"))
 keys = g.dev([42, 0], np.uint32); d2l = g.dev(depth2leaf(6), np.float32); rou = g.dev(roulette_uniform([1, 2, 3, 4]), np.float32); cs = g.dev([-1, 0, 1], np.float32)
 d2l3 = g.dev(depth2leaf(3), np.float32)
 
