@@ -515,8 +515,7 @@ def main():
                 neg_inf = torch.full((pop,), float("-inf"), dtype=torch.float32, device=device)
                 for _ in range(5):
                     barrier(); g0 = time.perf_counter()
-                    f = -sg.forest.SR_fitness(Xd, yd, True, "auto")
-                    f = torch.where(torch.isnan(f), neg_inf, f)
+                    f = torch.ops.evogp_hip.fitness_scores(sg.forest.SR_fitness(Xd, yd, True, "auto"), True)   # (sign + NaN -> -inf: SymbolicRegression.scores)
                     sg.step(f)
                     barrier(); ms.append(max_over_ranks((time.perf_counter() - g0) * 1000))
                 sent = dict(sg.last_exchange)
@@ -573,8 +572,7 @@ def main():
         neg_inf = torch.full((pop1,), float("-inf"), dtype=torch.float32, device=device)
         for _ in range(6):
             torch.cuda.synchronize(); g0 = time.perf_counter()
-            f = -algo.forest.SR_fitness(Xd, yd, True, "auto")
-            f = torch.where(torch.isnan(f), neg_inf, f)  # no boolean-mask assignment: that one syncs with the host
+            f = torch.ops.evogp_hip.fitness_scores(algo.forest.SR_fitness(Xd, yd, True, "auto"), True)   # (sign + NaN -> -inf in one launch: SymbolicRegression.scores, what StandardPipeline.step calls)
             algo.step(f)
             torch.cuda.synchronize(); gen_ms.append((time.perf_counter() - g0) * 1000)
         extras["configs1"] = {
@@ -611,8 +609,7 @@ def main():
                         k[0] += 1
                 algo.stage_marker = mark if events is not None else None
                 mark()
-                f = -f0.SR_fitness(Xd, yd, True, "auto")
-                f = torch.where(torch.isnan(f), neg_inf, f)
+                f = torch.ops.evogp_hip.fitness_scores(f0.SR_fitness(Xd, yd, True, "auto"), True)
                 mark()
                 algo.step(f)
                 return k[0]
@@ -768,8 +765,7 @@ def main():
             ugen = []
             for g_ in range(30):
                 torch.cuda.synchronize(); g0 = time.perf_counter()
-                f = -ualgo.forest.SR_fitness(Xd, yd, True, "auto")
-                ualgo.step(torch.where(torch.isnan(f), uneg, f))
+                ualgo.step(torch.ops.evogp_hip.fitness_scores(ualgo.forest.SR_fitness(Xd, yd, True, "auto"), True))
                 torch.cuda.synchronize(); ugen.append((time.perf_counter() - g0) * 1000)
             upoints["generation_30"] = uci_point(ualgo.forest)
             extras["uci_sr_shape"] = {
@@ -795,8 +791,7 @@ def main():
             vneg = torch.full((100_000,), float("-inf"), dtype=torch.float32, device=device)
             for g_ in range(40):
                 torch.cuda.synchronize(); g0 = time.perf_counter()
-                f = -valgo.forest.SR_fitness(vX, vy, True, "auto")
-                valgo.step(torch.where(torch.isnan(f), vneg, f))
+                valgo.step(torch.ops.evogp_hip.fitness_scores(valgo.forest.SR_fitness(vX, vy, True, "auto"), True))
                 torch.cuda.synchronize(); vms.append((time.perf_counter() - g0) * 1000)
                 if g_ in (0, 39):
                     vlen.append(float(valgo.forest.batch_subtree_size[:, 0].float().mean()))

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "evogp_hip_insert_mutate": [_i, _i, C.c_uint, _i, C.c_longlong, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_point_mutate": [_i, _i, _i, _f, _f, _i, _i, _i, _i, _i, _i, _i, C.c_longlong, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_random_words": [C.c_longlong, C.c_longlong, _i, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp],
+    "evogp_hip_fitness_scores": [_u, _i, _vp, _vp, _vp],
     "evogp_hip_select": [_u, _u, _u, _vp, _vp, _vp, _vp],
     "evogp_hip_select_alternating": [_u, _u, _u, _vp, _vp, _vp, _vp, _vp],
     "evogp_hip_tournament_select": [_u, _u, _u, C.c_longlong, C.c_longlong, _vp, _vp, _vp],

@@ -322,6 +322,17 @@ Tensor tree_evaluate_prepared(int64_t pop_size, int64_t gp_len, int64_t var_len,
 
 // int32[rows][n_cols] whose columns [lo, hi) hold the counter-based random words of (seed, generation) (breed.hip); the other
 // columns are uninitialised
+// scores = NaN -> -inf, else -errors (negate) or errors: the sign of SymbolicRegression.evaluate and the NaN scrub of StandardPipeline.step in one launch
+Tensor fitness_scores(const Tensor &errors, bool negate) {
+    TORCH_CHECK(errors.is_cuda() && errors.scalar_type() == at::kFloat && errors.is_contiguous() && errors.dim() == 1 && errors.numel() > 0,
+                "fitness_scores: errors must be a non-empty contiguous float32 CUDA vector");
+    const c10::DeviceGuard guard(errors.device());
+    Tensor out = at::empty_like(errors);
+    check_rc(evogp_hip_fitness_scores((unsigned)errors.numel(), negate ? 1 : 0, errors.data_ptr<float>(), out.data_ptr<float>(), current_stream(errors.device())),
+             "fitness_scores");
+    return out;
+}
+
 Tensor random_words(int64_t seed, int64_t generation, int64_t rows, int64_t n_cols, int64_t lo, int64_t hi, c10::Device device) {
     TORCH_CHECK(device.is_cuda(), "random_words: the native generator runs on the GPU");
     TORCH_CHECK(rows > 0 && n_cols > 0 && lo >= 0 && lo <= hi && hi <= n_cols, "random_words: column range out of the array");
@@ -627,6 +638,7 @@ TORCH_LIBRARY(evogp_hip, m) {
     m.def("tree_evaluate_prepared(int pop_size, int gp_len, int var_len, int out_len, Tensor value, Tensor node_type, Tensor subtree_size,"
           " Tensor workspace, bool with_fallback, Tensor variables) -> Tensor results");
     m.def("random_words(int seed, int generation, int rows, int n_cols, int lo, int hi, Device device) -> Tensor");
+    m.def("fitness_scores(Tensor errors, bool negate) -> Tensor");
     m.def("select_survivors(Tensor fitness, int n_elite, int n_keep) -> Tensor");
     m.def("tournament_select(Tensor fitness, int n_tournaments, int t_size, int seed, int generation) -> Tensor");
     m.def("breed_default(int pop_size, int gp_len, int n_elite, int n_surv, Tensor value, Tensor node_type, Tensor subtree_size,"
@@ -674,5 +686,6 @@ TORCH_LIBRARY_IMPL(evogp_hip, CUDA, m) {
     m.impl("point_mutate", &point_mutate);
     m.impl("tree_SR_fitness_masked", &tree_SR_fitness_masked);
     m.impl("select_survivors", &select_survivors);
+    m.impl("fitness_scores", &fitness_scores);
     m.impl("tournament_select", &tournament_select);
 }

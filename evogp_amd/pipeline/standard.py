@@ -39,8 +39,12 @@ class StandardPipeline(BasePipeline):
         hides a host sync), and the fitness vector is brought to the host AFTER ``algorithm.step`` has queued the
         selection / breeding kernels, so the copy overlaps them instead of idling the GPU."""
         forest = self.algorithm.forest  # step() builds a new forest; the best tree comes from this one
-        fitness = self.problem.evaluate(forest)
-        fitness = torch.where(torch.isnan(fitness), torch.full_like(fitness, float("-inf")), fitness)  # standard.py:43
+        scores = getattr(self.problem, "scores", None)
+        if scores is not None:   # (a problem that hands over the scrubbed fitness itself: SymbolicRegression, one launch)
+            fitness = scores(forest)
+        else:
+            fitness = self.problem.evaluate(forest)
+            fitness = torch.where(torch.isnan(fitness), torch.full_like(fitness, float("-inf")), fitness)  # standard.py:43
         self.algorithm.step(fitness)
         host = fitness.cpu()
         best = int(torch.argmax(host))

@@ -223,6 +223,11 @@ int evogp_hip_point_mutate(int pop_size, int gp_len, int mode, float rate, float
 int evogp_hip_random_words(long long seed, long long generation, int rows, long long n_cols, long long lo, long long hi,
                            int *out, evogp_stream_t stream);
 
+/* scores[i] = -inf where errors[i] is NaN, else -errors[i] (negate != 0) or errors[i] (no counterpart in the reference's ABI: its
+ * SymbolicRegression.evaluate negates in torch, problem/symbolic_regression.py:82-96, and its pipeline scrubs NaN with a boolean-mask
+ * assignment, pipeline/standard.py:41-43 -- four small launches and a host sync per generation).  errors and scores may be the same array. */
+int evogp_hip_fitness_scores(unsigned n, int negate, const float *errors, float *scores, evogp_stream_t stream);
+
 /* Selection in one launch (no counterpart in the reference, whose DefaultSelection sorts the whole fitness vector,
  * src/evogp/algorithm/selection/default.py:21-39): order[0 .. n_elite) = the n_elite trees of highest fitness, order[n_elite ..
  * n_keep) = the next n_keep - n_elite, each group in ascending tree index.  Ties at a threshold go to the lower index, so both

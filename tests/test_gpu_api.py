@@ -292,3 +292,28 @@ def test_record_memory_is_visible_to_torchs_allocator():
     del fit
     evogp_amd.release_workspaces()
     assert evogp_amd.program_buffer_bytes() == 0 and torch.cuda.memory_allocated() <= before + 4096
+
+
+def test_fitness_scores_is_the_sign_and_the_nan_scrub_of_a_generation():
+    """evogp_hip::fitness_scores = SymbolicRegression.evaluate's sign + StandardPipeline.step's NaN -> -inf (pipeline/standard.py:41-43)
+    in one launch; SymbolicRegression.scores and the pipeline's step use it"""
+    import torch
+
+    import evogp_amd  # noqa: F401
+    from evogp_amd.problem import SymbolicRegression
+    from evogp_amd.tree import Forest, GenerateDescriptor
+
+    dev = torch.device("cuda", 0)
+    e = torch.tensor([1.5, float("nan"), 0.0, float("inf"), -2.0, float("-inf")], device=dev)
+    for negate in (True, False):
+        got = torch.ops.evogp_hip.fitness_scores(e, negate)
+        f = -e if negate else e
+        want = torch.where(torch.isnan(f), torch.full_like(f, float("-inf")), f)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    desc = GenerateDescriptor(max_tree_len=32, input_len=3, output_len=1, using_funcs=["+", "-", "*", "/"], max_layer_cnt=4, const_samples=[-1, 0, 1])
+    f = Forest.random_generate(3000, desc, keys=torch.tensor([1, 2], dtype=torch.uint32, device=dev))
+    X = torch.rand(64, 3, device=dev) * 2 - 1
+    prob = SymbolicRegression(datapoints=X, labels=(X[:, :1] * X[:, 1:2]).contiguous())
+    ev = prob.evaluate(f)
+    want = torch.where(torch.isnan(ev), torch.full_like(ev, float("-inf")), ev)
+    assert torch.isnan(ev).any() and torch.equal(prob.scores(f).view(torch.int32), want.view(torch.int32))
