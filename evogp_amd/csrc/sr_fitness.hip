@@ -534,7 +534,10 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
                                        (1u << F_NEG) | (1u << F_ABS) | (1u << F_SQRT) | (1u << F_LOOSE_SQRT);
         if (env_learn) {
             int cls = tc_learned_class(p.pop, p.gp_len, stream, &p.feedback, &p.feedback_expected);
-            if (p.feedback && cls < 0) cls = tc_detect_class(p, p.marks + 5, stream);
+            if (p.feedback && cls < 0) {
+                cls = tc_detect_class(p, p.marks + 5, stream);
+                if (cls >= 0) p.feedback_expected = tc_store_class(p.feedback, cls);
+            }
             if (p.feedback && cls == 0) p.func_mask = kArith;
             else if (p.feedback && cls == 1) p.func_mask = kArith | kUnaryOwn;
         }

@@ -51,6 +51,7 @@ struct SrParams {
 hipError_t launch_threaded_code(const SrParams &p, hipStream_t stream, bool *handled, int *mark_sample, int *mark_chunks);
 int tc_learned_class(int pop, int gp_len, hipStream_t stream, unsigned **publish, unsigned *word);
 int tc_detect_class(const SrParams &p, unsigned *flags, hipStream_t stream);
+unsigned tc_store_class(unsigned *publish, int cls);
 
 // Classification epilogue on the threaded code (sr_fitness.hip: it shares the call-scratch chain with the fitness calls):
 // counts[t] = rows whose arg-max output equals labels[row]; trees the path cannot take come back with kDeepCountBit set and
