@@ -170,41 +170,50 @@ constexpr int kGenConstLds = 256;
 constexpr int kGenThr = 8;
 constexpr int kStagedMaxLen = 256;
 
-static size_t staged_lds_bytes(unsigned gp_len, unsigned gather) {
-    return (size_t)kGenChunk * kGenPitch * 4 + (size_t)kGenChunk * kGenPitch * 2 + (size_t)gp_len * kGenPitch * 2 +
-           2 * (size_t)kLevels * kWave * 2 + kGenConstLds * 4 + 64 * 4 + (size_t)gather * kWave * 4;
+// LDS of a wave (round 6: byte-sized where a byte will do -- node types in the ring, subtree sizes, frames -- and constants by their number:
+// 12.6 instead of 19.8 KB at rows of 64 nodes, twelve instead of eight waves per CU; with the kernel held to 168 VGPRs that is three
+// waves per SIMD instead of two.  A subtree size beyond 255 does not fit its byte: the (rare) tree of more than 255 nodes has its sizes
+// written again, straight to memory, by a second walk over the same draws: generate_staged_kernel `replay`)
+static size_t staged_consts_in_lds(unsigned n_const) { return n_const <= (unsigned)kGenConstLds ? (size_t)((n_const + 3u) & ~3u) : 0; }
+static size_t staged_lds_bytes(unsigned gp_len, unsigned gather, unsigned n_const) {
+    return (size_t)kGenChunk * kGenPitch * 4 + staged_consts_in_lds(n_const) * 4 + 64 * 4 + (size_t)gather * kWave * 4 + (size_t)kLevels * kWave * 2 +
+           (size_t)kGenChunk * kGenPitch + (size_t)gp_len * kGenPitch + (size_t)kLevels * kWave + 16;
 }
 
 template <bool MO>
-__global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, unsigned gather) {
+__global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, unsigned gather, unsigned consts_lds) {
     extern __shared__ uint32_t gen_lds[];
     float *ring_v = reinterpret_cast<float *>(gen_lds);                                // [kGenChunk][kGenPitch]
-    uint16_t *ring_t = reinterpret_cast<uint16_t *>(ring_v + kGenChunk * kGenPitch);   // [kGenChunk][kGenPitch]
-    uint16_t *size_s = ring_t + kGenChunk * kGenPitch;                                 // [gp_len][kGenPitch]
-    uint16_t *frame_s = size_s + (size_t)p.gp_len * kGenPitch;                         // [kLevels][64]: childs | depth << 4
-    uint16_t *open_s = frame_s + kLevels * kWave;                                      // [kLevels][64]
-    float *const_s = reinterpret_cast<float *>(open_s + kLevels * kWave);              // [kGenConstLds]
-    float *misc_s = const_s + kGenConstLds;                                            // leaf probs [11], roulette [29]
+    float *const_s = ring_v + kGenChunk * kGenPitch;                                   // [consts_lds]: the constants, when there are at most kGenConstLds
+    float *misc_s = const_s + consts_lds;                                              // leaf probs [11], roulette [29]
     unsigned *rows_s = reinterpret_cast<unsigned *>(misc_s + 64);                      // [64 * gather]: the rows to generate
+    uint16_t *open_s = reinterpret_cast<uint16_t *>(rows_s + (size_t)gather * kWave);  // [kLevels][64]: index of the open function at a depth
+    uint8_t *ring_t = reinterpret_cast<uint8_t *>(open_s + kLevels * kWave);           // [kGenChunk][kGenPitch]: node types (0 .. 0x84)
+    uint8_t *size_s = ring_t + kGenChunk * kGenPitch;                                  // [gp_len][kGenPitch]: subtree sizes up to 255 (else: replay)
+    uint8_t *frame_s = size_s + (size_t)p.gp_len * kGenPitch;                          // [kLevels][64]: childs | depth << 4 (depth <= 11)
 
     const int lane = threadIdx.x;
     // ---- the rows of this workgroup's 64 * gather that are to be generated, in index order ----
     unsigned n_rows = 0;
-    unsigned word[kGenMaxGather];   // all loads first: one memory latency, not one per 64 rows
+    // (four groups of 64 rows at a time: their mask words are loaded together -- one memory latency per four groups -- without the sixteen
+    // registers and the sixteen unrolled hashes that held the kernel at two waves per SIMD)
+    for (unsigned g0 = 0; g0 < gather; g0 += 4u) {
+        unsigned word[4];
 #pragma unroll
-    for (unsigned g = 0; g < (unsigned)kGenMaxGather; ++g) {
-        const unsigned idx = (blockIdx.x * gather + g) * kWave + lane;
-        word[g] = 0u;
-        if (g < gather && idx < p.pop && p.active_word != nullptr && !p.hashed) word[g] = (unsigned)p.active_word[idx];
-    }
+        for (unsigned g = 0; g < 4u; ++g) {
+            const unsigned idx = (blockIdx.x * gather + g0 + g) * kWave + lane;
+            word[g] = 0u;
+            if (g0 + g < gather && idx < p.pop && p.active_word != nullptr && !p.hashed) word[g] = (unsigned)p.active_word[idx];
+        }
 #pragma unroll
-    for (unsigned g = 0; g < (unsigned)kGenMaxGather; ++g) {
-        if (g >= gather) break;
-        const unsigned idx = (blockIdx.x * gather + g) * kWave + lane;
-        const bool a = idx < p.pop && (p.hashed ? gen_active(p, idx) : (p.active_word == nullptr || word[g] < p.active_below));
-        const unsigned long long m = __ballot(a);
-        if (a) rows_s[n_rows + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = idx;
-        n_rows += (unsigned)__popcll(m);
+        for (unsigned g = 0; g < 4u; ++g) {
+            if (g0 + g >= gather) break;
+            const unsigned idx = (blockIdx.x * gather + g0 + g) * kWave + lane;
+            const bool a = idx < p.pop && (p.hashed ? gen_active(p, idx) : (p.active_word == nullptr || word[g] < p.active_below));
+            const unsigned long long m = __ballot(a);
+            if (a) rows_s[n_rows + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = idx;
+            n_rows += (unsigned)__popcll(m);
+        }
     }
     if (n_rows == 0u) return;  // nothing to generate in these rows: they stay untouched
 
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
     if (lane == kMaxFullDepth) misc_s[lane] = 1.0f;  // depths past the table are leaves
     const float my_roul = lane < kNumFuncs ? p.roulette[lane] : 0.0f;
     if (lane < kNumFuncs) misc_s[16 + lane] = my_roul;
-    const bool consts_in_lds = p.n_const <= (unsigned)kGenConstLds;
+    const bool consts_in_lds = consts_lds != 0u;
     if (consts_in_lds)
         for (unsigned i = lane; i < p.n_const; i += kWave) const_s[i] = p.consts[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         for (unsigned r4 = 0; r4 < 16; ++r4) {
             const unsigned row = r4 * 4 + rs;
             float v = 0.0f;
-            uint16_t t = 0;
+            unsigned t = 0;
             if (j < filled) {
                 v = ring_v[j * kGenPitch + row];
                 t = ring_t[j * kGenPitch + row];
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
             const bool is_func = u1 >= misc_s[dl];
             for (int dd = depth; dd <= deepest_open; ++dd) {   // the functions at this depth and below ended with the node before this one
                 const unsigned start = open_s[dd * kWave + lane];
-                if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint16_t)(it - start);
+                if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint8_t)min(it - start, 255u);
             }
             if (is_func) {  // function node (generate.cu:71-100)
                 int k = 0;  // largest i with r >= roulette[i], plus one (:77-84)
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
                 }
                 open_s[depth * kWave + lane] = (uint16_t)it;
                 deepest_open = depth;
-                if (childs > 0) frame_s[(sp++) * kWave + lane] = (uint16_t)((unsigned)childs | ((unsigned)depth << 4));
+                if (childs > 0) frame_s[(sp++) * kWave + lane] = (uint8_t)((unsigned)childs | ((unsigned)depth << 4));
                 tos_childs = arity; tos_depth = depth + 1;
             } else {  // leaf (:104-123)
                 const uint32_t r3 = rng.next();
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         }
         const unsigned slot = it & (kGenChunk - 1);
         ring_v[slot * kGenPitch + lane] = v;
-        ring_t[slot * kGenPitch + lane] = (uint16_t)t;
+        ring_t[slot * kGenPitch + lane] = (uint8_t)t;
         if (slot == kGenChunk - 1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -350,8 +359,9 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
     if (active)
         for (int dd = 0; dd <= deepest_open; ++dd) {
             const unsigned start = open_s[dd * kWave + lane];
-            if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint16_t)(cnt - start);
+            if (start < p.gp_len) size_s[start * kGenPitch + lane] = (uint8_t)min(cnt - start, 255u);
         }
+    const unsigned long long bigmask = __ballot(active && cnt > 255u);   // trees whose sizes do not fit a byte: written again below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -370,11 +380,63 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
             for (unsigned r4 = 0; r4 < 16; ++r4) {
                 const unsigned row = r4 * 4 + rs;
                 const unsigned len = (unsigned)__shfl((int)cnt, (int)row, 64);
-                uint16_t sz = 0;
+                unsigned sz = 0;
                 if (node < len && node < p.gp_len) sz = size_s[node * kGenPitch + row];
-                if (node < p.gp_len && ((amask >> row) & 1ull)) p.size[(size_t)rows_s[b0 + row] * p.gp_len + node] = (int16_t)sz;
+                if (node < p.gp_len && (((amask & ~bigmask) >> row) & 1ull)) p.size[(size_t)rows_s[b0 + row] * p.gp_len + node] = (int16_t)sz;
             }
         }
+    }
+    // ---- a tree of more than 255 nodes (deep descriptors on rows it overflows): the same draws once more, the sizes of the nodes its row
+    // holds written straight to memory as they close (generate_kernel's way: scattered stores, rare)
+    if (bigmask != 0ull) {
+        const bool mine = ((bigmask >> lane) & 1ull) != 0ull;
+        const size_t row = (size_t)n * p.gp_len;
+        Taus88 r2(gen_seed(p, n));
+        int c2 = 1, d2 = 0, sp2 = 0, deep2 = -1;
+        bool run2 = mine;
+        unsigned cnt2 = 0;
+        for (unsigned i2 = 0;; ++i2) {
+            const bool live = run2 && i2 < (unsigned)kMaxStack;
+            if (!__any(live)) break;
+            if (live) {
+                const int childs = c2 - 1, depth = d2;
+                const int dl = depth < kMaxFullDepth ? depth : kMaxFullDepth;
+                const float u1 = r2.uniform(), u2 = r2.uniform();
+                for (int dd = depth; dd <= deep2; ++dd) {
+                    const unsigned start = open_s[dd * kWave + lane];
+                    if (start < p.gp_len) p.size[row + start] = (int16_t)(i2 - start);
+                }
+                if (u1 >= misc_s[dl]) {
+                    int k = 0;
+                    if (n_thr <= kGenThr) {
+#pragma unroll
+                        for (int m = 0; m < kGenThr; ++m) k = u2 >= thr[m] ? kv[m] : k;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < kNumFuncs; ++i) k = u2 >= misc_s[16 + i] ? i + 1 : k;
+                    }
+                    const int arity = (k <= F_IF ? T_TFUNC : (k <= F_GE ? T_BFUNC : T_UFUNC)) - 1;
+                    if (MO) { if (r2.uniform() <= p.out_prob) (void)r2.next(); }
+                    open_s[depth * kWave + lane] = (uint16_t)i2;
+                    deep2 = depth;
+                    if (childs > 0) frame_s[(sp2++) * kWave + lane] = (uint8_t)((unsigned)childs | ((unsigned)depth << 4));
+                    c2 = arity; d2 = depth + 1;
+                } else {
+                    (void)r2.next();
+                    if (i2 < p.gp_len) p.size[row + i2] = 1;
+                    deep2 = min(deep2, depth - 1);
+                    if (childs > 0) c2 = childs;
+                    else if (sp2 > 0) { const unsigned fr = frame_s[(--sp2) * kWave + lane]; c2 = (int)(fr & 0xFu); d2 = (int)(fr >> 4); }
+                    else run2 = false;
+                }
+                cnt2 = i2 + 1;
+            }
+        }
+        if (mine)
+            for (int dd = 0; dd <= deep2; ++dd) {
+                const unsigned start = open_s[dd * kWave + lane];
+                if (start < p.gp_len) p.size[row + start] = (int16_t)(cnt2 - start);
+            }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the rings and frames are reused by the next 64 rows
     __builtin_amdgcn_wave_barrier();
@@ -450,16 +512,17 @@ static int generate_impl(unsigned pop_size, unsigned gp_len, unsigned var_len, u
             gather = share > 0.0 ? (unsigned)(0.8 / share) : (unsigned)kGenMaxGather;
             // ... but only as far as the gathered grid still fills the chip: a launch whose workgroups are all resident at once
             // (pop 100 k: 1563 of them) lasts as long as one workgroup, and a gathered workgroup lasts longer (22.7 -> 37.5 us)
-            const unsigned resident = (unsigned)device_info().num_cus * 8u;
+            const unsigned resident = (unsigned)device_info().num_cus * 12u;
             const unsigned rounds = ((pop_size + kWave - 1) / kWave) / resident;
             if (gather > rounds) gather = rounds;
             if (env_gather > 0) gather = (unsigned)env_gather;
             gather = gather < 1u ? 1u : (gather > (unsigned)kGenMaxGather ? (unsigned)kGenMaxGather : gather);
         }
         const unsigned wgs = (pop_size + kWave * gather - 1) / (kWave * gather);
-        const size_t lds = staged_lds_bytes(gp_len, gather);
-        if (out_len > 1) hipLaunchKernelGGL(generate_staged_kernel<true>, dim3(wgs), dim3(kWave), lds, stream, p, gather);
-        else hipLaunchKernelGGL(generate_staged_kernel<false>, dim3(wgs), dim3(kWave), lds, stream, p, gather);
+        const size_t lds = staged_lds_bytes(gp_len, gather, const_samples_len);
+        const unsigned consts_lds = (unsigned)staged_consts_in_lds(const_samples_len);
+        if (out_len > 1) hipLaunchKernelGGL(generate_staged_kernel<true>, dim3(wgs), dim3(kWave), lds, stream, p, gather, consts_lds);
+        else hipLaunchKernelGGL(generate_staged_kernel<false>, dim3(wgs), dim3(kWave), lds, stream, p, gather, consts_lds);
         return (int)hipGetLastError();
     }
     const unsigned blocks = (pop_size + kGenBlock - 1) / kGenBlock;
