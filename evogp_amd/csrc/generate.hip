@@ -260,8 +260,9 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         const unsigned j = lane & 15, rs = lane >> 4;
         const unsigned node = chunk * kGenChunk + j;
         const bool in_row = node < p.gp_len;
+        const unsigned steps = (unsigned)(64 - __builtin_clzll(amask | 1ull) + 3) / 4;   // (a masked launch's list is short: its live rows are the first ones)
 #pragma unroll 4
-        for (unsigned r4 = 0; r4 < 16; ++r4) {
+        for (unsigned r4 = 0; r4 < steps; ++r4) {
             const unsigned row = r4 * 4 + rs;
             float v = 0.0f;
             unsigned t = 0;
@@ -376,8 +377,9 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         const unsigned j = lane & 15, rs = lane >> 4;
         for (unsigned ch = 0; ch < nchunks; ++ch) {
             const unsigned node = ch * kGenChunk + j;
+            const unsigned steps = (unsigned)(64 - __builtin_clzll(amask | 1ull) + 3) / 4;
 #pragma unroll 4
-            for (unsigned r4 = 0; r4 < 16; ++r4) {
+            for (unsigned r4 = 0; r4 < steps; ++r4) {
                 const unsigned row = r4 * 4 + rs;
                 const unsigned len = (unsigned)__shfl((int)cnt, (int)row, 64);
                 unsigned sz = 0;
