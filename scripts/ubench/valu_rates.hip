@@ -67,6 +67,32 @@ KERNEL_IDX(k_fixup_idx_dst, "0x8", I4("v_div_fixup_f32", "v28, v30, v24"))
     "v_fma_f32 v39, -v36, v37, 1.0\n\tv_fmac_f32 v37, v39, v37\n\tv_mul_f32 v39, v38, v37\n\tv_fma_f32 v20, -v36, v39, v38\n\tv_fmac_f32 v39, v20, v37\n\tv_fma_f32 v36, -v36, v39, v38\n\tv_div_fmas_f32 " q ", v36, v37, v39\n\t"
 KERNEL(k_divrow4, DIVROW("v30", "v28", "v32") DIVROW("v31", "v29", "v33") DIVROW("v30", "v29", "v34") DIVROW("v31", "v28", "v35"))
 
+// integer / bit work of the program compilers and of tree_generate (round 6): is anything but the fp32 VOP2 forms double rate?
+KERNEL(k_and_vvv, I4("v_and_b32", "v28, v30"))
+KERNEL(k_and_lit, I4("v_and_b32", "0xffe00000, v30"))
+KERNEL(k_and_inl, I4("v_and_b32", "7, v30"))
+KERNEL(k_addu_vvv, I4("v_add_u32", "v28, v30"))
+KERNEL(k_addu_inl, I4("v_add_u32", "1, v30"))
+KERNEL(k_lshl_vvv, I4("v_lshlrev_b32", "v28, v30"))
+KERNEL(k_lshl_inl, I4("v_lshlrev_b32", "3, v30"))
+KERNEL(k_xor_vvv, I4("v_xor_b32", "v28, v30"))
+KERNEL(k_bfe, I4("v_bfe_u32", "v28, 3, 5"))
+KERNEL(k_and_or, I4("v_and_or_b32", "v28, v30, v24"))
+KERNEL(k_lshl_add, I4("v_lshl_add_u32", "v28, 2, v24"))
+KERNEL(k_cmp_u32, "v_cmp_eq_u32 vcc, v28, v30\n\tv_cmp_eq_u32 vcc, v29, v30\n\tv_cmp_eq_u32 vcc, v28, v31\n\tv_cmp_eq_u32 vcc, v29, v31\n\t")
+KERNEL(k_cndmask_s, I4("v_cndmask_b32_e64", "v27, v28, s[20:21]"))
+KERNEL(k_mul_lo, I4("v_mul_lo_u32", "v28, v30"))
+KERNEL(k_mul_u24, I4("v_mul_u32_u24", "v28, v30"))
+KERNEL(k_mov_dpp, I4("v_mov_b32_dpp", "v28 wave_shl:1 row_mask:0xf bank_mask:0xf"))
+KERNEL(k_mbcnt, I4("v_mbcnt_lo_u32_b32", "s20, v28"))
+KERNEL(k_cvt_f32_u32, I4("v_cvt_f32_u32", "v28"))
+KERNEL(k_add_f32_inl, I4("v_add_f32", "1.0, v30"))
+KERNEL(k_mul_f32_lit, I4("v_mul_f32", "0x2f800000, v30"))
+KERNEL(k_max_f32, I4("v_max_f32", "v28, v30"))
+KERNEL(k_min_u32, I4("v_min_u32", "v28, v30"))
+KERNEL(k_readlane, "v_readlane_b32 s20, v28, 3\n\tv_readlane_b32 s21, v29, 3\n\tv_readlane_b32 s20, v30, 5\n\tv_readlane_b32 s21, v31, 7\n\t")
+KERNEL(k_salu, "s_add_u32 s20, s20, 1\n\ts_and_b32 s21, s21, 7\n\ts_add_u32 s20, s20, 1\n\ts_and_b32 s21, s21, 7\n\t")
+
 template <typename K> static void run(const char *name, K kern, int instrs_per_rep, unsigned long long *dout, float *dsink) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int blocks = 256 * 4;  // 4 workgroups of 4 waves per CU = 4 waves per SIMD
@@ -91,5 +117,8 @@ int main() {
     RUN(k_add_idx_src0, 4); RUN(k_add_idx_dst, 4); RUN(k_add_idx_s0s1d, 4); RUN(k_mov_idx_dst, 4); RUN(k_fixup_idx_dst, 4);
     RUN(k_divrow4, 48);
     RUN(k_add_vop2, 4); RUN(k_pk_add, 4); RUN(k_add_vop2, 4); RUN(k_pk_fma, 4); RUN(k_fma_vop3, 4);
+    RUN(k_and_vvv, 4); RUN(k_and_lit, 4); RUN(k_and_inl, 4); RUN(k_addu_vvv, 4); RUN(k_addu_inl, 4); RUN(k_lshl_vvv, 4); RUN(k_lshl_inl, 4); RUN(k_xor_vvv, 4); RUN(k_bfe, 4);
+    RUN(k_and_or, 4); RUN(k_lshl_add, 4); RUN(k_cmp_u32, 4); RUN(k_cndmask_s, 4); RUN(k_mul_lo, 4); RUN(k_mul_u24, 4); RUN(k_mov_dpp, 4); RUN(k_mbcnt, 4); RUN(k_cvt_f32_u32, 4);
+    RUN(k_add_f32_inl, 4); RUN(k_mul_f32_lit, 4); RUN(k_max_f32, 4); RUN(k_min_u32, 4); RUN(k_readlane, 4); RUN(k_salu, 4); RUN(k_add_vop2, 4);
     return 0;
 }

@@ -35,3 +35,20 @@ def test_sr_fitness_random_function_sets_match_batch_evaluate(oracle, seed):
         fin = np.isfinite(got) & np.isfinite(ref)
         rel = np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30)
         assert rel.size == 0 or rel.max() <= 1e-4, (funcs, D, float(rel.max()))
+
+
+def test_fitness_words_do_not_depend_on_the_work_distribution():
+    """scripts/dbg/pool_soak.py in two processes -- the round-6 workgroup pools (default) and every batch drawn from the XCD counters
+    (EVOGP_TC_STATIC=0, round 5's distribution): random populations up to 450 k trees, five function sets, rows of 16 .. 128 nodes; each
+    configuration called through the reference's operator, under the forest's mask and on a second stream.  Inside a process all words
+    must be equal (the script's exit code); between the processes the per-configuration checksums must be."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logs = []
+    for extra in ({}, {"EVOGP_TC_STATIC": "0"}):
+        env = dict(os.environ, SOAK_CASES="14", SOAK_SEED="3", **extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dbg", "pool_soak.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        logs.append([l for l in r.stdout.splitlines() if l.startswith("case")])
+    assert len(logs[0]) == 14 and logs[0] == logs[1]
