@@ -113,6 +113,7 @@ TRIGPK = True    # sin / cos / tan over row pairs with packed multiplications an
 LIBPK = True     # pow / sinh / cosh: the library's sequences over row PAIRS (gen/pair_rows.py; EVOGP_TC_GEN_LIBPK=0: row by row)
 RECGLC = False   # fused build: the record loads carry glc (EVOGP_TC_GEN_RECGLC=1) instead of one s_dcache_inv per batch
 CODEWARM = False  # EVOGP_TC_GEN_CODEWARM=1: every wave pulls the handler table and the bodies behind it into its XCD's L2 before it starts (experiment: 4-5 us SLOWER at 250 k - 1 M trees, no change at 125 k: profiles/r05Z_codewarm_ab.log)
+CNDE64 = False  # EVOGP_TC_GEN_CNDE64=1: every VOP2 v_cndmask_b32 ..., vcc in its 64-bit encoding (scripts/ubench/valu_rates.hip: the VOP2 form costs a SIMD ~4 issue slots of the VOP3 form)
 KWARM = False  # scalar-cache warm-up of the next record (EVOGP_TC_GEN_KWARM=1 at generation time enables it): +1.5 % in round 2, -0.5 % since the division was rebuilt (profiles/r03E_div_range_ab.log)
 
 
@@ -2486,6 +2487,10 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
         a("s_endpgm")
     sect[0] = L
     a(f"{lab('code_end')}:")
+    if CNDE64:
+        import re
+        L[:] = [re.sub(r"^v_cndmask_b32 (.*), vcc$", r"v_cndmask_b32_e64 \1, vcc", x) for x in L]
+        tail[:] = [re.sub(r"^v_cndmask_b32 (.*), vcc$", r"v_cndmask_b32_e64 \1, vcc", x) for x in tail]
     at = L.index(".p2align 16")
     L[at:at] = tail
     if fused:
@@ -2534,6 +2539,7 @@ def gen(K, DEPTH, stats=False, fast=0, info=None, fused=False, wide=False):
 if __name__ == "__main__":
     import os
     KWARM = os.environ.get("EVOGP_TC_GEN_KWARM", "0") == "1"
+    CNDE64 = os.environ.get("EVOGP_TC_GEN_CNDE64", "0") == "1"
     CODEWARM = os.environ.get("EVOGP_TC_GEN_CODEWARM", "0") == "1"
     L2WARM = os.environ.get("EVOGP_TC_GEN_L2WARM", "1") != "0"
     EARLYREC = os.environ.get("EVOGP_TC_GEN_EARLYREC", "1") != "0"

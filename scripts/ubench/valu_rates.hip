@@ -93,6 +93,18 @@ KERNEL(k_min_u32, I4("v_min_u32", "v28, v30"))
 KERNEL(k_readlane, "v_readlane_b32 s20, v28, 3\n\tv_readlane_b32 s21, v29, 3\n\tv_readlane_b32 s20, v30, 5\n\tv_readlane_b32 s21, v31, 7\n\t")
 KERNEL(k_salu, "s_add_u32 s20, s20, 1\n\ts_and_b32 s21, s21, 7\n\ts_add_u32 s20, s20, 1\n\ts_and_b32 s21, s21, 7\n\t")
 
+// v_cndmask forms (the VOP2 form read 21.9 ticks in round 1's log: is it the form, the NaN source, or vcc never written?)
+KERNEL(k_cndmask_v24, I4("v_cndmask_b32", "v24, v28, vcc"))
+KERNEL(k_cndmask_e64vcc, I4("v_cndmask_b32_e64", "v24, v28, vcc"))
+KERNEL(k_cndmask_wr, "v_cmp_neq_f32 vcc, 0, v28\n\ts_nop 1\n\tv_cndmask_b32 v32, v24, v28, vcc\n\tv_cndmask_b32 v33, v24, v28, vcc\n\tv_cndmask_b32 v34, v24, v28, vcc\n\t")
+KERNEL(k_cndmask_inl, I4("v_cndmask_b32", "0, v28, vcc"))
+KERNEL(k_or_vvv, I4("v_or_b32", "v28, v30"))
+KERNEL(k_subu_vvv, I4("v_sub_u32", "v28, v30"))
+KERNEL(k_lshr_inl, I4("v_lshrrev_b32", "3, v30"))
+KERNEL(k_bfi, I4("v_bfi_b32", "v28, v30, v24"))
+KERNEL(k_and_sgpr, I4("v_and_b32", "s20, v30"))
+KERNEL(k_cmp_e64, "v_cmp_eq_u32_e64 s[20:21], v28, v30\n\tv_cmp_eq_u32_e64 s[20:21], v29, v30\n\tv_cmp_eq_u32_e64 s[20:21], v28, v31\n\tv_cmp_eq_u32_e64 s[20:21], v29, v31\n\t")
+
 template <typename K> static void run(const char *name, K kern, int instrs_per_rep, unsigned long long *dout, float *dsink) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int blocks = 256 * 4;  // 4 workgroups of 4 waves per CU = 4 waves per SIMD
@@ -120,5 +132,6 @@ int main() {
     RUN(k_and_vvv, 4); RUN(k_and_lit, 4); RUN(k_and_inl, 4); RUN(k_addu_vvv, 4); RUN(k_addu_inl, 4); RUN(k_lshl_vvv, 4); RUN(k_lshl_inl, 4); RUN(k_xor_vvv, 4); RUN(k_bfe, 4);
     RUN(k_and_or, 4); RUN(k_lshl_add, 4); RUN(k_cmp_u32, 4); RUN(k_cndmask_s, 4); RUN(k_mul_lo, 4); RUN(k_mul_u24, 4); RUN(k_mov_dpp, 4); RUN(k_mbcnt, 4); RUN(k_cvt_f32_u32, 4);
     RUN(k_add_f32_inl, 4); RUN(k_mul_f32_lit, 4); RUN(k_max_f32, 4); RUN(k_min_u32, 4); RUN(k_readlane, 4); RUN(k_salu, 4); RUN(k_add_vop2, 4);
+    RUN(k_cndmask, 4); RUN(k_cndmask_v24, 4); RUN(k_cndmask_e64vcc, 4); RUN(k_cndmask_wr, 4); RUN(k_cndmask_inl, 4); RUN(k_or_vvv, 4); RUN(k_subu_vvv, 4); RUN(k_lshr_inl, 4); RUN(k_bfi, 4); RUN(k_and_sgpr, 4); RUN(k_cmp_e64, 4);
     return 0;
 }
