@@ -42,6 +42,8 @@ struct GenParams {
     unsigned active_below;
     int hashed;                // != 0: no keys / active_word arrays -- the two keys are word (7, 0 / 1) % 10^6 and tree n is generated
     unsigned long long hash_base;  // when word (4, n + index_offset) < active_below, of the counter-based words of (seed, generation)
+    unsigned hkey0, hkey1;     // hashed: the two keys, worked out by the host (generate_impl)
+    uint32_t m_const, m_var, m_out;   // fast_mod_magic of n_const / var_len / out_len (a 64-bit division each: the host's)
 };
 
 __device__ inline bool gen_active(const GenParams &p, unsigned n) {
@@ -49,7 +51,7 @@ __device__ inline bool gen_active(const GenParams &p, unsigned n) {
     return p.active_word == nullptr || (unsigned)p.active_word[n] < p.active_below;
 }
 __device__ inline uint32_t gen_seed(const GenParams &p, unsigned n) {
-    if (p.hashed) return seed_hash(n + p.index_offset, counter_word(p.hash_base, 7u, 0ull) % 1000000u, counter_word(p.hash_base, 7u, 1ull) % 1000000u);
+    if (p.hashed) return seed_hash(n + p.index_offset, p.hkey0, p.hkey1);
     return seed_hash(n + p.index_offset, p.keys[0], p.keys[1]);
 }
 
@@ -161,7 +163,7 @@ __device__ inline uint32_t fast_mod(uint32_t x, uint32_t d, uint32_t m) {   // x
     const uint32_t r = x - __umulhi(x, m) * d;
     return r >= d ? r - d : r;
 }
-__device__ inline uint32_t fast_mod_magic(unsigned d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
+__host__ __device__ inline uint32_t fast_mod_magic(unsigned d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); }
 
 constexpr int kGenChunk = 16;
 constexpr int kGenMaxGather = 16;     // G: at most 1024 rows per workgroup
@@ -227,11 +229,13 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         for (unsigned i = lane; i < p.n_const; i += kWave) const_s[i] = p.consts[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    bool surv = lane < kNumFuncs && my_roul == my_roul;
-    for (int j = 1; j < kNumFuncs; ++j) {
-        const float rj = misc_s[16 + j];
-        if (j > lane && rj <= my_roul) surv = false;  // a later entry that qualifies whenever this one does
-    }
+    // entry i survives unless a later entry qualifies whenever it does (r_j <= r_i for some j > i): the minimum over the later lanes,
+    // five shuffles (NaN entries qualify for nothing and fminf passes them over; the lanes behind the table hold +inf)
+    float later = lane < kNumFuncs ? my_roul : __builtin_inff();
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) later = fminf(later, __shfl_down(later, d, 64));
+    later = __shfl_down(later, 1, 64);
+    const bool surv = lane < kNumFuncs && my_roul == my_roul && !(lane + 1 < kWave && later <= my_roul);
     unsigned long long smask = __ballot(surv);
     const int n_thr = __popcll(smask);
     float thr[kGenThr];
@@ -249,13 +253,15 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         }
     }
 
-    const uint32_t m_const = uni(fast_mod_magic(p.n_const)), m_var = uni(fast_mod_magic(p.var_len)), m_out = uni(fast_mod_magic(p.out_len));
+    const uint32_t m_const = p.m_const, m_var = p.m_var, m_out = p.m_out;
 
     for (unsigned b0 = 0; b0 < n_rows; b0 += kWave) {   // 64 rows of the list at a time
     const bool active = b0 + lane < n_rows;
     const unsigned n = active ? rows_s[b0 + lane] : 0u;
     const unsigned long long amask = __ballot(active);
-    auto flush_chunk = [&](unsigned chunk, unsigned filled) {
+    // sizes_of: the rows whose subtree sizes go out with the chunk (the chunks behind a tree's last node leave once, values, types and
+    // sizes together; the chunks flushed inside the loop get their sizes when the trees are complete)
+    auto flush_chunk = [&](unsigned chunk, unsigned filled, unsigned long long sizes_of) {
         // lanes: 16 columns x 4 rows per instruction
         const unsigned j = lane & 15, rs = lane >> 4;
         const unsigned node = chunk * kGenChunk + j;
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
                 const size_t at = (size_t)rows_s[b0 + row] * p.gp_len + node;
                 p.value[at] = v;
                 p.type[at] = (int16_t)t;
+                if ((sizes_of >> row) & 1ull) p.size[at] = (int16_t)size_s[node * kGenPitch + row];
             }
         }
     };
@@ -284,6 +291,13 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
     // instead of at least one per node, and the longest such loop in the wave is what every lane waits for); the second draw is common to
     // both kinds of node and the third to both kinds of leaf; x % n is a multiplication by floor(2^32 / n) and one correction.  The draw
     // order is the reference's (generate.cu:55-172): the same trees, bit for bit.
+    {   // sizes start at zero: the flush below then reads a row's column whatever the row's length (no cross-lane fetch of the length per step)
+        uint32_t *z = reinterpret_cast<uint32_t *>(size_s);
+        const unsigned words = p.gp_len * (unsigned)kGenPitch / 4u;
+        for (unsigned i = lane; i < words; i += kWave) z[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     Taus88 rng(gen_seed(p, n));
     int tos_childs = 1, tos_depth = 0, sp = 0, deepest_open = -1;
     bool running = active;
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
         if (slot == kGenChunk - 1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            flush_chunk(it / kGenChunk, kGenChunk);
+            flush_chunk(it / kGenChunk, kGenChunk, 0ull);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -366,28 +380,25 @@ __global__ __launch_bounds__(kWave) void generate_staged_kernel(GenParams p, uns
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- the partially filled chunk, then zeros up to gp_len ----
+    // ---- subtree sizes of the chunks that left inside the loop ----
     const unsigned nchunks = (p.gp_len + kGenChunk - 1) / kGenChunk;
-    unsigned c = it / kGenChunk;
-    if ((it & (kGenChunk - 1)) && c < nchunks) { flush_chunk(c, it & (kGenChunk - 1)); ++c; }
-    for (; c < nchunks; ++c) flush_chunk(c, 0);
-
-    // ---- subtree sizes ----
+    const unsigned first_tail = min(it / kGenChunk, nchunks);
     {
         const unsigned j = lane & 15, rs = lane >> 4;
-        for (unsigned ch = 0; ch < nchunks; ++ch) {
+        for (unsigned ch = 0; ch < first_tail; ++ch) {
             const unsigned node = ch * kGenChunk + j;
             const unsigned steps = (unsigned)(64 - __builtin_clzll(amask | 1ull) + 3) / 4;
 #pragma unroll 4
             for (unsigned r4 = 0; r4 < steps; ++r4) {
                 const unsigned row = r4 * 4 + rs;
-                const unsigned len = (unsigned)__shfl((int)cnt, (int)row, 64);
-                unsigned sz = 0;
-                if (node < len && node < p.gp_len) sz = size_s[node * kGenPitch + row];
-                if (node < p.gp_len && (((amask & ~bigmask) >> row) & 1ull)) p.size[(size_t)rows_s[b0 + row] * p.gp_len + node] = (int16_t)sz;
+                if (node < p.gp_len && (((amask & ~bigmask) >> row) & 1ull))
+                    p.size[(size_t)rows_s[b0 + row] * p.gp_len + node] = (int16_t)size_s[node * kGenPitch + row];
             }
         }
     }
+    // ---- the partially filled chunk, then zeros up to gp_len: values, types and sizes in one walk ----
+    for (unsigned c = first_tail; c < nchunks; ++c) flush_chunk(c, c == first_tail ? (it & (kGenChunk - 1)) : 0u, amask & ~bigmask);
+
     // ---- a tree of more than 255 nodes (deep descriptors on rows it overflows): the same draws once more, the sizes of the nodes its row
     // holds written straight to memory as they close (generate_kernel's way: scattered stores, rare)
     if (bigmask != 0ull) {
@@ -501,7 +512,9 @@ static int generate_impl(unsigned pop_size, unsigned gp_len, unsigned var_len, u
     if ((!keys && !hashed) || !depth2leaf_probs || !roulette_funcs || !const_samples || !value_res || !type_res || !size_res)
         return EVOGP_E_NULLPTR;
     GenParams p{pop_size, gp_len, var_len, out_len, const_samples_len, out_prob, const_prob, keys, depth2leaf_probs,
-                roulette_funcs, const_samples, value_res, type_res, size_res, tree_index_offset, active_word, active_below, hashed, hash_base};
+                roulette_funcs, const_samples, value_res, type_res, size_res, tree_index_offset, active_word, active_below, hashed, hash_base,
+                hashed ? counter_word(hash_base, 7u, 0ull) % 1000000u : 0u, hashed ? counter_word(hash_base, 7u, 1ull) % 1000000u : 0u,
+                fast_mod_magic(const_samples_len), fast_mod_magic(var_len), fast_mod_magic(out_len)};
     hipStream_t stream = (hipStream_t)stream_;
     static const bool staged_ok = [] { const char *e = getenv("EVOGP_GEN_STAGED"); return !(e && e[0] == '0'); }();
     if (staged_ok && gp_len <= (unsigned)kStagedMaxLen) {
