@@ -376,10 +376,13 @@ __device__ inline int classify_tree(const int16_t *__restrict__ type, const floa
 // cannot take; correctness first.  `x_row` points at this lane's input row in global memory.
 constexpr int kGeneralOuts = 256;
 
-template <bool MO>
+// STRIDE: entry h of the lane's stack is stk[h * STRIDE] -- 1: a private array; 64: a column of an LDS block the wave's lanes share
+// (sr_fast_kernel's folded deep path: no private array, so no scratch segment for the launch to set up)
+template <bool MO, int STRIDE = 1>
 __device__ inline float run_general(const int16_t *__restrict__ type, const float *__restrict__ value, int len,
                                     const float *__restrict__ x_row, int var_len, int out_len, float *outs,
-                                    float *stk /* [kMaxStack + 2] private */) {
+                                    float *stk_ /* [kMaxStack + 2] private, or the lane's column of [len + 2][64] */) {
+    struct { float *q; __device__ float &operator[](int h) const { return q[h * STRIDE]; } } stk{stk_};
     int h = 0;
     if (MO) for (int o = 0; o < out_len; ++o) outs[o] = 0.0f;
     for (int i = len - 1; i >= 0; --i) {

@@ -67,7 +67,9 @@ __device__ inline float err_term(float diff, int use_mse) { return use_mse ? dif
 // The fitness of ONE single-output tree with the operand stack in scratch memory (sr_general_kernel's per-tree work): one wave, lanes are
 // datapoints.  sr_fast_kernel's build behind the threaded code runs it itself for the rare tree whose stack its registers do not hold
 // (only_marked == 5, round 5: the scratch-stack kernel is then not launched at all -- two launches that find nothing were 10 us of every call).
-__device__ __attribute__((noinline)) void general_tree_fitness(const SrParams &p, int t, float *stk) {
+constexpr int kFoldMaxLen = 126;   // (gp_len + 2) * 256 B of LDS for the folded deep path: 32 KB
+template <int STRIDE>
+__device__ __attribute__((always_inline)) inline void general_tree_fitness(const SrParams &p, int t, float *stk) {
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)t * p.gp_len;
     const float *tv = p.value + row;
@@ -83,7 +85,7 @@ __device__ __attribute__((noinline)) void general_tree_fitness(const SrParams &p
     for (int base = 0; base < p.D; base += kWave) {
         const int d = base + lane;
         const int dc = d < p.D ? d : p.D - 1;
-        const float res = run_general<false>(tt, tv, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, outs, stk);
+        const float res = run_general<false, STRIDE>(tt, tv, len, p.X + (size_t)dc * p.var_len, p.var_len, p.out_len, outs, stk);
         const float e = err_term(p.y[dc] - res, p.use_mse);
         acc += d < p.D ? e : 0.0f;
     }
@@ -312,10 +314,10 @@ __global__ __launch_bounds__(MAXW * 64, (LEAN && K == 4 && VL <= 16) ? EVOGP_LEA
             for (int b = 0; b < nb; ++b) deep_any |= uni(cls_s[par][b]) == TREE_DEEP;
             if (deep_any) {
                 __syncthreads();   // (phase 3's sentinel words are written before the values replace them)
-                if (w == 0) {
-                    float stk[kMaxStack + 2];
+                if (w == 0) {   // (the stack: the lane's column of [gp_len + 2][64] floats of dynamic LDS, launch_fast -- a private array is a scratch segment, ~3 us of every launch)
+                    extern __shared__ float deep_stack_lds[];
                     for (int b = 0; b < nb; ++b)
-                        if (uni(cls_s[par][b]) == TREE_DEEP) general_tree_fitness(p, uni(tree_of(b)), stk);
+                        if (uni(cls_s[par][b]) == TREE_DEEP) general_tree_fitness<kWave>(p, uni(tree_of(b)), deep_stack_lds + lane);
                 }
             }
         }
@@ -436,7 +438,9 @@ static hipError_t launch_fast(SrParams p, int only_marked, hipStream_t stream, u
     hipError_t e;
     p.counter = zeroed_counter ? zeroed_counter : acquire_counter(stream, &e);
     if (!p.counter) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), 0, stream, p);
+    // only_marked == 5: wave 0 evaluates a tree too deep for the register stack on a stack in LDS (run_population folds only rows of at most kFoldMaxLen nodes)
+    const size_t lds = only_marked == 5 ? (size_t)(p.gp_len + 2) * kWave * sizeof(float) : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -585,7 +589,7 @@ static int run_population(const SrParams &p_in, hipStream_t stream) {
         // (one follow-up launch: the FULL register build takes what the threaded code marked and runs the scratch stack itself for the rare
         // tree that is too deep for its registers; EVOGP_SR_FOLD=0: the scratch-stack kernel as a launch of its own, as in round 4)
         static const int env_fold = env_int("EVOGP_SR_FOLD", 1);
-        folded = env_fold != 0 && !STORE;
+        folded = env_fold != 0 && !STORE && p.gp_len <= kFoldMaxLen;   // (longer rows: the scratch-stack kernel as a launch of its own)
         const int om = folded ? 5 : 1;
         if (p.var_len <= 10) e = launch_fast<4, 16, 10, false, 4, STORE, false>(p, om, stream, p.marks + 3);
         else if (p.var_len <= 12) e = launch_fast<4, 16, 12, false, 4, STORE, false>(p, om, stream, p.marks + 3);
