@@ -525,6 +525,8 @@ def test_sr_fitness_repeated_calls_streams_and_graph_replay(g, oracle, rng):
     outs = []
     for i in range(7):
         out = torch.full((3000,), 777.0, dtype=torch.float32, device=g.DEV)
+        if i % 3 == 2:
+            side.wait_stream(main)   # (the fill above is main's work: without this the side stream's result can be overwritten by it)
         call(out, side if i % 3 == 2 else main)
         if i == 3:  # a call of another shape (fallback kernels, different scratch use) in between
             g.sr_fitness(v[:50], t[:50], s[:50], X[:100], np.tile(y[:100], (1, 1)), use_mse=False, kernel_type=2)
