@@ -543,8 +543,7 @@ def main():
             sm_trees, sm_ms = [], []
             for nshard in (8, 4, 2, 1):
                 n_s = P // nshard
-                fs = forest if nshard == 1 else Forest(forest.input_len, forest.output_len, forest.batch_node_value[:n_s], forest.batch_node_type[:n_s],
-                                                       forest.batch_subtree_size[:n_s])
+                fs = forest if nshard == 1 else forest[:n_s]   # (a view that keeps the forest's function mask: the call a rank of an N-rank run makes on its shard)
                 for _ in range(10):
                     fs.SR_fitness(Xd, yd, True, "auto")
                 reps = []
@@ -556,7 +555,7 @@ def main():
                     reps.append((time.perf_counter() - t0) / 20 * 1e3)
                 sm_trees.append(n_s); sm_ms.append(float(np.median(reps)))
             extras["shard_model"] = {"trees": sm_trees, "ms": sm_ms, "efficiency_vs_linear": [sm_ms[-1] * t / P / m for t, m in zip(sm_trees, sm_ms)],
-                                     "what": "tree_SR_fitness (through the reference's operator: the shards are views without a function mask) on the first P/8, P/4, P/2, P trees of the headline population on one GPU: the per-rank time "
+                                     "what": "tree_SR_fitness (Forest.SR_fitness, the timed step's call) on the first P/8, P/4, P/2, P trees of the headline population on one GPU: the per-rank time "
                                              "an N-rank strong-scaling run cannot beat; efficiency = (time of P trees x share) / time of the shard"}
 
         # BASELINE configs[1]: 100k trees per GPU (weak), same protocol
