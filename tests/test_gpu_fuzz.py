@@ -52,3 +52,19 @@ def test_fitness_words_do_not_depend_on_the_work_distribution():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         logs.append([l for l in r.stdout.splitlines() if l.startswith("case")])
     assert len(logs[0]) == 14 and logs[0] == logs[1]
+
+
+def test_fitness_words_do_not_depend_on_the_compilers_workgroup_size():
+    """scripts/dbg/packed_wg_check.py in two processes: the packed program compiler as workgroups of 256 threads and of 64 (one wave, the
+    default from 120 k trees on) on forests beyond that size in the modes the soak above does not reach -- 4, 6 and 10 outputs, rows of
+    128 and 256 nodes, functions behind the generic stubs.  The checksums of the fitness words must be equal."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logs = []
+    for wg in ("256", "64"):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dbg", "packed_wg_check.py")], env=dict(os.environ, EVOGP_TC_PACKED_WG=wg),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        logs.append([l for l in r.stdout.splitlines() if l.startswith("case")])
+    assert len(logs[0]) == 5 and all("repeat equal True" in l for l in logs[0]) and logs[0] == logs[1]
