@@ -8,7 +8,8 @@ the oracle (VERDICT r03 "missing" #2 and #3):
     the whole population (prepared forward pass inside a replayed HIP graph) against the oracle's loop on a sample of trees;
   * the reference's own SR script shape (example/uci_sr.py:45-75): max_tree_len 512, max_layer_cnt 9, 10 000 constants in [-5, 5],
     functions + - * / sin cos tan, layer_leaf_prob 0.3, pop 100 000 x 1024 rows: a 5 000-tree sample against the oracle, the
-    population against its halves."""
+    population against its halves;
+  * the headline itself (round 6): all 1 M trees x 1024 rows of BASELINE's north_star against the oracle on the host's cores."""
 import numpy as np
 import pytest
 
@@ -221,3 +222,29 @@ def test_evolved_uci_sr_population_stays_in_the_threaded_code(g, oracle):
             assert len(bad) == 0, (fast, len(bad), bad[:5], w[:, bad[:3]], got.view(np.uint32)[bad[:3]])
     finally:
         _lib.lib.evogp_hip_debug_long_compiler(-1)
+
+
+def test_headline_population_at_full_size_against_the_oracle(g, oracle):
+    """BASELINE north_star / configs[2]'s population in full -- 1 M trees x 1024 datapoints, + - * / -- on the GPU against the plain-C oracle
+    on the host's cores (OpenMP over trees: seconds): the same NaN and inf sets, every finite fitness within 1e-5 (the order of the sum
+    over the rows is the only difference; scripts/dbg/headline_vs_oracle.py prints the figures, profiles/r06Z_headline_vs_oracle.log)."""
+    import os, sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    argv, sys.argv = sys.argv, [sys.argv[0]]
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    dev = torch.device("cuda", 0)
+    forest, Xd, yd, X, y = bench.sr_inputs(0, 1_000_000, dev)
+    got = forest.SR_fitness(Xd, yd, True, "auto").cpu().numpy().astype(np.float64)
+    want = oracle.sr_fitness(forest.batch_node_value.cpu().numpy(), forest.batch_node_type.cpu().numpy(), forest.batch_subtree_size.cpu().numpy(),
+                             X, y, True, 0).astype(np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    fin = np.isfinite(want)
+    rel = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-30)
+    assert fin.sum() > 600_000 and rel.max() <= 1e-5, float(rel.max())
