@@ -248,3 +248,15 @@ def test_headline_population_at_full_size_against_the_oracle(g, oracle):
     fin = np.isfinite(want)
     rel = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-30)
     assert fin.sum() > 600_000 and rel.max() <= 1e-5, float(rel.max())
+
+
+def test_headline_forest_is_the_oracles_bit_for_bit(g, oracle):
+    """tree_generate at the headline's size -- 1 M rows of 64 nodes, keys [42, 0], the descriptor of bench.sr_inputs -- against the oracle's
+    generator: all three arrays equal, zero tails included (the staged kernel: three waves per SIMD, byte-sized LDS arrays, sizes read back
+    without the row length -- DESIGN.md section 3.4a)."""
+    pop = 1_000_000
+    args = (pop, 64, 10, 1, 0.0, 0.5, [42, 0], depth2leaf(6), roulette_uniform(ARITH), [-1.0, 0.0, 1.0])
+    gv, gt, gs = g.generate(*args)
+    ov, ot, os_ = oracle.generate(*args)
+    assert np.array_equal(gt, ot) and np.array_equal(gs, os_)
+    assert np.array_equal(gv.view(np.uint32), ov.view(np.uint32))
