@@ -61,6 +61,8 @@ def _expected(oracle, forest, order, rnd, below, n_elite, n_surv, donors, parent
     (64, 16, 3, 2, ARITH, 0.0, 0.5, 0.3),
     (900, 50, 5, 3, ARITH, 0.4, 0.03, 0.3),    # row length no multiple of 4: the one-row-per-wave kernel
     (1100, 400, 7, 4, ARITH, 0.3, 0.02, 0.4),  # staging rows of 16 groups would not fit: the one-row-per-wave kernel
+    (100_000, 64, 6, 3, ARITH, 0.2, 0.01, 0.3),    # BASELINE configs[1] at its full size: the generation step of bench.py's configs1
+    (1_000_000, 64, 6, 3, ARITH, 0.2, 0.01, 0.3),  # ... and the headline population (four chunks per workgroup unit, gathered donor launch)
 ])
 def test_breed_default_bit_exact(g, oracle, pop, L, mlc, dmlc, funcs, rate, elite_rate, surv_rate):
     rng = np.random.default_rng(pop + L)
