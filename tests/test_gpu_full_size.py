@@ -260,3 +260,29 @@ def test_headline_forest_is_the_oracles_bit_for_bit(g, oracle):
     ov, ot, os_ = oracle.generate(*args)
     assert np.array_equal(gt, ot) and np.array_equal(gs, os_)
     assert np.array_equal(gv.view(np.uint32), ov.view(np.uint32))
+
+
+def test_crossover_and_mutate_at_the_headline_size_bit_for_bit(g, oracle):
+    """tree_crossover (300 k parents -> 990 k children) and tree_mutate (1 M trees, every one with a donor) on rows of 64 nodes against
+    the oracle: node indices inside and outside the live trees, right parents out of range (the copy-left fallbacks of mutation.cu:150-180,
+    :256-289), children that would overflow the row."""
+    rng = np.random.default_rng(6)
+    pop = 1_000_000
+    v, t, s = oracle.generate(pop, 64, 10, 1, 0.0, 0.5, [42, 0], depth2leaf(6), roulette_uniform(ARITH), [-1.0, 0.0, 1.0])
+    n_new, n_par = 990_000, 300_000
+    li = rng.integers(0, n_par, n_new).astype(np.int32); ri = rng.integers(-2, n_par + 2, n_new).astype(np.int32)
+    sizes = s[:, 0].astype(np.int64)
+    ln = (rng.integers(0, 1 << 30, n_new) % sizes[li]).astype(np.int32); rn = (rng.integers(0, 1 << 30, n_new) % sizes[np.clip(ri, 0, pop - 1)]).astype(np.int32)
+    odd = rng.random(n_new) < 0.02
+    ln[odd] = rng.integers(-3, 70, int(odd.sum())).astype(np.int32)          # outside the live tree, outside the row
+    got = g.crossover(v, t, s, li, ri, ln, rn)
+    want = oracle.crossover(v, t, s, li, ri, ln, rn)
+    for a, b, name in zip(got, want, ("value", "type", "size")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"crossover at 1 M: {name} differs"
+    dv, dt, ds = oracle.generate(pop, 64, 10, 1, 0.0, 0.5, [7, 9], depth2leaf(4), roulette_uniform(ARITH), [-1.0, 0.0, 1.0])
+    idx = (rng.integers(0, 1 << 30, pop) % sizes).astype(np.int32)
+    idx[rng.random(pop) < 0.02] = -1                                         # the copy-old fallback
+    got = g.mutate(v, t, s, idx, dv, dt, ds)
+    want = oracle.mutate(v, t, s, idx, dv, dt, ds)
+    for a, b, name in zip(got, want, ("value", "type", "size")):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"mutate at 1 M: {name} differs"
