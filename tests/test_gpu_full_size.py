@@ -286,3 +286,19 @@ def test_crossover_and_mutate_at_the_headline_size_bit_for_bit(g, oracle):
     want = oracle.mutate(v, t, s, idx, dv, dt, ds)
     for a, b, name in zip(got, want, ("value", "type", "size")):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"mutate at 1 M: {name} differs"
+
+
+@pytest.mark.parametrize("out_len", [1, 6])
+def test_tree_evaluate_at_the_headline_size_bit_for_bit(g, oracle, out_len):
+    """tree_evaluate -- one input row per tree (forward.cu:304-351) -- on 1 M trees of + - * /: single-output trees through the lane
+    kernels, six outputs through the direct kernel (evaluate_prepared.hip); every result word equal to the oracle's (the arithmetic of
+    the register interpreters and of the OUT-node reading is IEEE operation for operation)."""
+    rng = np.random.default_rng(60 + out_len)
+    pop, L, var_len = 1_000_000, 64, 10
+    v, t, s = oracle.generate(pop, L, var_len, out_len, 0.5 if out_len > 1 else 0.0, 0.5, [42, out_len], depth2leaf(6), roulette_uniform(ARITH), [-1.0, 0.0, 1.0])
+    x = rng.uniform(-5, 5, (pop, var_len)).astype(np.float32)
+    got = g.evaluate(v, t, s, x, out_len)
+    want = oracle.evaluate(v, t, s, x, out_len)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(np.where(nan, 0, got).view(np.uint32), np.where(nan, 0, want).view(np.uint32))
